@@ -1,0 +1,576 @@
+// HBM-bound kernels of the DDPO hot path: JAX-compatible Threefry normal generator, fused CFG + DDIM step +
+// log-prob, fused scoring-mode log-prob + PPO-clip forward/backward, fused AdamW(bf16 mu) with global-norm
+// clip and accumulation scaling, plus the small layout / activation kernels of the U-Net.
+// Built with -ffp-contract=off so the fp32 operation order matches the CPU oracle.
+#include "common.h"
+#include <math.h>
+
+extern "C" int ddpo_abi_version(void) { return 1; }
+extern "C" size_t ddpo_sizeof_gemm_desc(void) { return sizeof(ddpo_gemm_desc); }
+extern "C" size_t ddpo_sizeof_ddim_consts(void) { return sizeof(ddpo_ddim_consts); }
+
+// ------------------------------------------------------------------------------------------------
+// Threefry-2x32 (20 rounds) — jax/_src/prng.py semantics (reference call sites in ddpo_hip.h)
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+
+__host__ __device__ __forceinline__ void threefry2x32(uint32_t k0, uint32_t k1, uint32_t& x0, uint32_t& x1) {
+  const uint32_t ks[3] = {k0, k1, k0 ^ k1 ^ 0x1BD11BDAu};
+  const int R[2][4] = {{13, 15, 26, 6}, {17, 29, 16, 24}};
+  x0 += ks[0];
+  x1 += ks[1];
+#pragma unroll
+  for (int g = 0; g < 5; ++g) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      x0 += x1;
+      x1 = rotl32(x1, R[g & 1][i]);
+      x1 ^= x0;
+    }
+    x0 += ks[(g + 1) % 3];
+    x1 += ks[(g + 2) % 3] + (uint32_t)(g + 1);
+  }
+}
+
+extern "C" int ddpo_threefry_bits_host(uint32_t k0, uint32_t k1, int64_t n, uint32_t* out) {
+  if (n < 0 || (!out && n)) return DDPO_EINVAL;
+  const int64_t half = (n + 1) / 2;
+  for (int64_t j = 0; j < half; ++j) {
+    uint32_t x0 = (uint32_t)j, x1 = (j + half < n) ? (uint32_t)(j + half) : 0u;
+    threefry2x32(k0, k1, x0, x1);
+    out[j] = x0;
+    if (j + half < n) out[j + half] = x1;
+  }
+  return DDPO_OK;
+}
+
+// XLA ErfInv32 (Giles' single-precision polynomial), operation order as xla/client/lib/math.cc.
+__device__ __forceinline__ float erfinv_xla(float x) {
+  float w = -log1pf(-(x * x));
+  const bool lt = w < 5.0f;
+  float p;
+  if (lt) {
+    w = w - 2.5f;
+    p = 2.81022636e-08f;
+    p = 3.43273939e-07f + p * w;
+    p = -3.5233877e-06f + p * w;
+    p = -4.39150654e-06f + p * w;
+    p = 0.00021858087f + p * w;
+    p = -0.00125372503f + p * w;
+    p = -0.00417768164f + p * w;
+    p = 0.246640727f + p * w;
+    p = 1.50140941f + p * w;
+  } else {
+    w = sqrtf(w) - 3.0f;
+    p = -0.000200214257f;
+    p = 0.000100950558f + p * w;
+    p = 0.00134934322f + p * w;
+    p = -0.00367342844f + p * w;
+    p = 0.00573950773f + p * w;
+    p = -0.0076224613f + p * w;
+    p = 0.00943887047f + p * w;
+    p = 1.00167406f + p * w;
+    p = 2.83297682f + p * w;
+  }
+  float r = p * x;
+  if (fabsf(x) == 1.0f) r = x * INFINITY;
+  return r;
+}
+
+__device__ __forceinline__ float bits_to_normal(uint32_t bits) {
+  const float lo = -0.99999994f;   // nextafter(-1, 0)
+  float f = __uint_as_float((bits >> 9) | 0x3F800000u) - 1.0f;
+  float u = f * 2.0f + lo;         // (maxval - minval) rounds to 2.0f in f32
+  u = fmaxf(lo, u);
+  return 1.41421354f * erfinv_xla(u);   // float32(sqrt(2))
+}
+
+__global__ void __launch_bounds__(256) threefry_normal_kernel(uint32_t k0, uint32_t k1, float* __restrict__ out,
+                                                              uint32_t* __restrict__ bits_out, int64_t n, int64_t half) {
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < half; j += (int64_t)gridDim.x * blockDim.x) {
+    const bool has1 = (j + half) < n;
+    uint32_t x0 = (uint32_t)j, x1 = has1 ? (uint32_t)(j + half) : 0u;
+    threefry2x32(k0, k1, x0, x1);
+    out[j] = bits_to_normal(x0);
+    if (has1) out[j + half] = bits_to_normal(x1);
+    if (bits_out) {
+      bits_out[j] = x0;
+      if (has1) bits_out[j + half] = x1;
+    }
+  }
+}
+
+extern "C" int ddpo_threefry_normal(uint32_t k0, uint32_t k1, float* out, uint32_t* bits_out, int64_t n, void* stream) {
+  if (!out || n <= 0 || n > 0xFFFFFFFFll) return DDPO_EINVAL;
+  const int64_t half = (n + 1) / 2;
+  int grid = (int)((half + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(threefry_normal_kernel, dim3(grid), dim3(256), 0, as_stream(stream), k0, k1, out, bits_out, n, half);
+  DDPO_LAUNCH_CHECK();
+  return DDPO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// DDIM step (scheduling_ddim_flax.py:279-359)
+// ------------------------------------------------------------------------------------------------
+struct DdimCoef {
+  float sqrt_at, sqrt_bt, sqrt_ap, dirc, std, std_c;
+};
+
+__device__ __forceinline__ DdimCoef ddim_coef(const ddpo_ddim_consts c, int t) {
+  const int p = t - c.step_ratio;
+  const float a_t = c.alphas_cumprod[t];
+  const float a_p = (p >= 0) ? c.alphas_cumprod[p] : c.final_alpha_cumprod;
+  const float b_t = 1.0f - a_t;
+  const float var = ((1.0f - a_p) / (1.0f - a_t)) * (1.0f - a_t / a_p);
+  DdimCoef k;
+  k.std = c.eta * sqrtf(var);
+  k.sqrt_at = sqrtf(a_t);
+  k.sqrt_bt = sqrtf(b_t);
+  k.sqrt_ap = sqrtf(a_p);
+  k.dirc = sqrtf(1.0f - a_p - k.std * k.std);
+  k.std_c = fmaxf(k.std, 1e-6f);
+  return k;
+}
+
+// mean of the DDIM posterior given the (guided) model output e and the current sample x
+__device__ __forceinline__ float ddim_mean(const DdimCoef& k, int pred_type, float e, float x) {
+  float x0;
+  if (pred_type == DDPO_PRED_EPSILON) {
+    x0 = (x - k.sqrt_bt * e) / k.sqrt_at;
+  } else if (pred_type == DDPO_PRED_V) {
+    x0 = k.sqrt_at * x - k.sqrt_bt * e;
+    e = k.sqrt_at * e + k.sqrt_bt * x;
+  } else {
+    x0 = e;
+  }
+  return k.sqrt_ap * x0 + k.dirc * e;
+}
+
+#define LOG_SQRT_2PI 0.9189385332046727f
+
+__global__ void __launch_bounds__(1024) ddim_step_kernel(const float* __restrict__ eps_u, const float* __restrict__ eps_c,
+                                                        const float* __restrict__ x, const float* __restrict__ z,
+                                                        const int32_t* __restrict__ ts, float g, ddpo_ddim_consts c,
+                                                        float* __restrict__ x_next, float* __restrict__ logp, int chw) {
+  __shared__ float red[16];
+  const int b = blockIdx.x;
+  const DdimCoef k = ddim_coef(c, ts[b]);
+  const int64_t base = (int64_t)b * chw;
+  const float inv2v = 1.0f / (2.0f * (k.std_c * k.std_c));
+  const float cst = -logf(k.std_c) - LOG_SQRT_2PI;
+  float acc = 0.f;
+  for (int i = threadIdx.x * 4; i < chw; i += blockDim.x * 4) {
+    const float4 eu = *reinterpret_cast<const float4*>(eps_u + base + i);
+    const float4 ec = *reinterpret_cast<const float4*>(eps_c + base + i);
+    const float4 xv = *reinterpret_cast<const float4*>(x + base + i);
+    const float4 zv = *reinterpret_cast<const float4*>(z + base + i);
+    float4 o;
+    const float* peu = &eu.x; const float* pec = &ec.x; const float* px = &xv.x; const float* pz = &zv.x;
+    float* po = &o.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float e = peu[j] + g * (pec[j] - peu[j]);
+      const float mu = ddim_mean(k, c.pred_type, e, px[j]);
+      const float xn = mu + k.std * pz[j];
+      const float d = xn - mu;
+      acc += -(d * d) * inv2v + cst;
+      po[j] = xn;
+    }
+    *reinterpret_cast<float4*>(x_next + base + i) = o;
+  }
+  const float tot = block_sum(acc, red);
+  if (threadIdx.x == 0) logp[b] = tot / (float)chw;
+}
+
+extern "C" int ddpo_ddim_step_fwd(const float* eps_u, const float* eps_c, const float* x, const float* z,
+                                  const int32_t* ts, float guidance_scale, const ddpo_ddim_consts* c,
+                                  float* x_next, float* logp, int B, int chw, void* stream) {
+  if (!eps_u || !eps_c || !x || !z || !ts || !c || !x_next || !logp || B <= 0 || chw <= 0 || (chw & 3)) return DDPO_EINVAL;
+  hipLaunchKernelGGL(ddim_step_kernel, dim3(B), dim3(1024), 0, as_stream(stream), eps_u, eps_c, x, z, ts,
+                     guidance_scale, *c, x_next, logp, chw);
+  DDPO_LAUNCH_CHECK();
+  return DDPO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// scoring-mode log-prob + PPO-clip forward/backward (ddpo/training/policy_gradient.py:95-139)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) ppo_fwd_bwd_kernel(const float* __restrict__ eps_c, const float* __restrict__ eps_u,
+                                                          const float* __restrict__ x, const float* __restrict__ x_next,
+                                                          const int32_t* __restrict__ ts, const float* __restrict__ old_logp,
+                                                          const float* __restrict__ adv_in, float g, float clip, int train_cfg,
+                                                          ddpo_ddim_consts c, float* __restrict__ d_eps_c,
+                                                          float* __restrict__ d_eps_u, float* __restrict__ per_sample,
+                                                          int B, int chw) {
+  __shared__ float red[16];
+  __shared__ float s_dl;
+  const int b = blockIdx.x;
+  const DdimCoef k = ddim_coef(c, ts[b]);
+  const int64_t base = (int64_t)b * chw;
+  const float inv2v = 1.0f / (2.0f * (k.std_c * k.std_c));
+  const float cst = -logf(k.std_c) - LOG_SQRT_2PI;
+  float acc = 0.f;
+  for (int i = threadIdx.x * 4; i < chw; i += blockDim.x * 4) {
+    const float4 ec = *reinterpret_cast<const float4*>(eps_c + base + i);
+    float4 eu = ec;
+    if (train_cfg) eu = *reinterpret_cast<const float4*>(eps_u + base + i);
+    const float4 xv = *reinterpret_cast<const float4*>(x + base + i);
+    const float4 xn = *reinterpret_cast<const float4*>(x_next + base + i);
+    const float* pec = &ec.x; const float* peu = &eu.x; const float* px = &xv.x; const float* pn = &xn.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float e = train_cfg ? (peu[j] + g * (pec[j] - peu[j])) : pec[j];
+      const float d = pn[j] - ddim_mean(k, c.pred_type, e, px[j]);
+      acc += -(d * d) * inv2v + cst;
+    }
+  }
+  const float tot = block_sum(acc, red);
+  if (threadIdx.x == 0) {
+    const float lp = tot / (float)chw;
+    const float A = fminf(fmaxf(adv_in[b], -10.0f), 10.0f);        // ADV_CLIP_MAX
+    const float ratio = expf(lp - old_logp[b]);
+    const float unclipped = -A * ratio;
+    const float clipped = -A * fminf(fmaxf(ratio, 1.0f - clip), 1.0f + clip);
+    const bool use_unclipped = unclipped >= clipped;
+    s_dl = use_unclipped ? (-A * ratio / (float)B) : 0.0f;
+    per_sample[b * 4 + 0] = lp;
+    per_sample[b * 4 + 1] = ratio;
+    per_sample[b * 4 + 2] = fmaxf(unclipped, clipped);
+    per_sample[b * 4 + 3] = (fabsf(ratio - 1.0f) > clip) ? 1.0f : 0.0f;
+  }
+  __syncthreads();
+  // d logp / d mu = (x' - mu) / (sigma_c^2 * CHW);  d mu / d e per prediction type
+  float dmu_de;
+  if (c.pred_type == DDPO_PRED_EPSILON) dmu_de = k.dirc - k.sqrt_ap * k.sqrt_bt / k.sqrt_at;
+  else if (c.pred_type == DDPO_PRED_V) dmu_de = k.dirc * k.sqrt_at - k.sqrt_ap * k.sqrt_bt;
+  else dmu_de = k.sqrt_ap;
+  const float coef = s_dl * dmu_de / ((k.std_c * k.std_c) * (float)chw);
+  for (int i = threadIdx.x * 4; i < chw; i += blockDim.x * 4) {
+    const float4 ec = *reinterpret_cast<const float4*>(eps_c + base + i);
+    float4 eu = ec;
+    if (train_cfg) eu = *reinterpret_cast<const float4*>(eps_u + base + i);
+    const float4 xv = *reinterpret_cast<const float4*>(x + base + i);
+    const float4 xn = *reinterpret_cast<const float4*>(x_next + base + i);
+    const float* pec = &ec.x; const float* peu = &eu.x; const float* px = &xv.x; const float* pn = &xn.x;
+    float4 dc, du;
+    float* pdc = &dc.x; float* pdu = &du.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float e = train_cfg ? (peu[j] + g * (pec[j] - peu[j])) : pec[j];
+      const float d = pn[j] - ddim_mean(k, c.pred_type, e, px[j]);
+      const float de = coef * d;
+      pdc[j] = train_cfg ? g * de : de;
+      pdu[j] = (1.0f - g) * de;
+    }
+    *reinterpret_cast<float4*>(d_eps_c + base + i) = dc;
+    if (train_cfg) *reinterpret_cast<float4*>(d_eps_u + base + i) = du;
+  }
+}
+
+__global__ void ppo_info_kernel(const float* __restrict__ per_sample, const float* __restrict__ old_logp,
+                                float* __restrict__ info, int B) {
+  float kl = 0.f, cf = 0.f, ls = 0.f;
+  for (int b = threadIdx.x; b < B; b += 64) {
+    const float d = per_sample[b * 4] - old_logp[b];
+    kl += d * d;
+    cf += per_sample[b * 4 + 3];
+    ls += per_sample[b * 4 + 2];
+  }
+  kl = wave_sum(kl); cf = wave_sum(cf); ls = wave_sum(ls);
+  if (threadIdx.x == 0) {
+    info[0] = 0.5f * kl / (float)B;
+    info[1] = cf / (float)B;
+    info[2] = ls / (float)B;
+  }
+}
+
+extern "C" int ddpo_ddim_logprob_ppo_fwd_bwd(const float* eps_c, const float* eps_u, const float* x, const float* x_next,
+                                             const int32_t* ts, const float* old_logp, const float* advantages,
+                                             float guidance_scale, float clip_range, int train_cfg,
+                                             const ddpo_ddim_consts* c, float* d_eps_c, float* d_eps_u, float* per_sample,
+                                             float* info, int B, int chw, void* stream) {
+  if (!eps_c || !x || !x_next || !ts || !old_logp || !advantages || !c || !d_eps_c || !per_sample || !info) return DDPO_EINVAL;
+  if (train_cfg && (!eps_u || !d_eps_u)) return DDPO_EINVAL;
+  if (B <= 0 || chw <= 0 || (chw & 3)) return DDPO_EINVAL;
+  hipLaunchKernelGGL(ppo_fwd_bwd_kernel, dim3(B), dim3(1024), 0, as_stream(stream), eps_c, eps_u, x, x_next, ts, old_logp,
+                     advantages, guidance_scale, clip_range, train_cfg, *c, d_eps_c, d_eps_u, per_sample, B, chw);
+  DDPO_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ppo_info_kernel, dim3(1), dim3(64), 0, as_stream(stream), per_sample, old_logp, info, B);
+  DDPO_LAUNCH_CHECK();
+  return DDPO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// optimizer (optax clip_by_global_norm + adamw(mu_dtype=bf16)); 24 B/param of HBM traffic per update
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) sqnorm_kernel(const float* __restrict__ g, int64_t n, double* __restrict__ out) {
+  __shared__ double red[4];
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  const int64_t n4 = n >> 2;
+  const float4* g4 = reinterpret_cast<const float4*>(g);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 v = g4[i];
+    a0 += v.x * v.x; a1 += v.y * v.y; a2 += v.z * v.z; a3 += v.w * v.w;
+  }
+  double s = (double)a0 + (double)a1 + (double)a2 + (double)a3;
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (int64_t i = n4 << 2; i < n; ++i) s += (double)g[i] * (double)g[i];
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+extern "C" int ddpo_grad_sqnorm(const float* g, int64_t n, double* out_sq, int zero_first, void* stream) {
+  if (!g || !out_sq || n <= 0 || (reinterpret_cast<uintptr_t>(g) & 15)) return DDPO_EINVAL;
+  if (zero_first && hipMemsetAsync(out_sq, 0, sizeof(double), as_stream(stream)) != hipSuccess) return DDPO_ELAUNCH;
+  int64_t blocks = ((n >> 2) + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(sqnorm_kernel, dim3((int)blocks), dim3(256), 0, as_stream(stream), g, n, out_sq);
+  DDPO_LAUNCH_CHECK();
+  return DDPO_OK;
+}
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
+  uint32_t b = __float_as_uint(f);
+  if ((b & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((b >> 16) | 0x40);   // NaN stays NaN
+  b += 0x7FFFu + ((b >> 16) & 1u);
+  return (uint16_t)(b >> 16);
+}
+__device__ __forceinline__ float bf16_round_f(float f) { return bf16_bits_to_f32(f32_to_bf16_rne(f)); }
+
+struct AdamArgs {
+  float inv_n, lr_neg, b1, omb1, b1_bf16, b2, omb2, eps, wd, max_norm, bc1, bc2;
+  int mu_decay_in_bf16, zero_grad;
+};
+
+__device__ __forceinline__ void adam_one(float& p, float& g, uint16_t& mu, float& nu, const AdamArgs& a, bool clip, float norm) {
+  float ge = g * a.inv_n;
+  if (clip) ge = (ge / norm) * a.max_norm;
+  const float m_old = bf16_bits_to_f32(mu);
+  const float decayed = a.mu_decay_in_bf16 ? bf16_round_f(a.b1_bf16 * m_old) : a.b1 * m_old;
+  const float m = a.omb1 * ge + decayed;
+  const float v = a.omb2 * (ge * ge) + a.b2 * nu;
+  float u = (m / a.bc1) / (sqrtf(v / a.bc2) + a.eps);
+  u = u + a.wd * p;
+  p = p + a.lr_neg * u;
+  mu = f32_to_bf16_rne(m);
+  nu = v;
+  if (a.zero_grad) g = 0.f;
+}
+
+__global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ p, float* __restrict__ g, uint16_t* __restrict__ mu,
+                                                    float* __restrict__ nu, int64_t n, const double* __restrict__ sqn,
+                                                    AdamArgs a) {
+  const float norm = (float)sqrt(*sqn) * a.inv_n;       // ||g_sum * inv_n||
+  const bool clip = !(norm < a.max_norm);
+  const int64_t n4 = n >> 2;
+  float4* p4 = reinterpret_cast<float4*>(p);
+  float4* g4 = reinterpret_cast<float4*>(g);
+  float4* v4 = reinterpret_cast<float4*>(nu);
+  ushort4* m4 = reinterpret_cast<ushort4*>(mu);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    float4 pv = p4[i], gv = g4[i], vv = v4[i];
+    ushort4 mv = m4[i];
+    adam_one(pv.x, gv.x, mv.x, vv.x, a, clip, norm);
+    adam_one(pv.y, gv.y, mv.y, vv.y, a, clip, norm);
+    adam_one(pv.z, gv.z, mv.z, vv.z, a, clip, norm);
+    adam_one(pv.w, gv.w, mv.w, vv.w, a, clip, norm);
+    p4[i] = pv; v4[i] = vv; m4[i] = mv;
+    if (a.zero_grad) g4[i] = gv;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (int64_t i = n4 << 2; i < n; ++i) adam_one(p[i], g[i], mu[i], nu[i], a, clip, norm);
+}
+
+extern "C" int ddpo_adamw_bf16mu_step(float* p, float* g, uint16_t* mu, float* nu, int64_t n, const double* sqnorm_of_sum,
+                                      double inv_n_acc, double lr, double b1, double b2, double eps, double weight_decay,
+                                      double max_grad_norm, int step_t, int mu_decay_in_bf16, int zero_grad, void* stream) {
+  if (!p || !g || !mu || !nu || !sqnorm_of_sum || n <= 0 || step_t < 1) return DDPO_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(nu)) & 15) return DDPO_EINVAL;
+  if (reinterpret_cast<uintptr_t>(mu) & 7) return DDPO_EINVAL;
+  AdamArgs a;
+  a.inv_n = (float)inv_n_acc;
+  a.lr_neg = (float)(-lr);
+  a.b1 = (float)b1;
+  a.omb1 = (float)(1.0 - b1);
+  // weak-typed Python scalar times a bf16 array: the scalar itself is rounded to bf16 first (jax promotion rules)
+  {
+    union { float f; uint32_t u; } cv; cv.f = (float)b1;
+    uint32_t r = cv.u + 0x7FFFu + ((cv.u >> 16) & 1u);
+    cv.u = r & 0xFFFF0000u;
+    a.b1_bf16 = cv.f;
+  }
+  a.b2 = (float)b2;
+  a.omb2 = (float)(1.0 - b2);
+  a.eps = (float)eps;
+  a.wd = (float)weight_decay;
+  a.max_norm = (float)max_grad_norm;
+  a.bc1 = 1.0f - powf((float)b1, (float)step_t);
+  a.bc2 = 1.0f - powf((float)b2, (float)step_t);
+  a.mu_decay_in_bf16 = mu_decay_in_bf16;
+  a.zero_grad = zero_grad;
+  int64_t blocks = ((n >> 2) + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(adamw_kernel, dim3((int)blocks), dim3(256), 0, as_stream(stream), p, g, mu, nu, n, sqnorm_of_sum, a);
+  DDPO_LAUNCH_CHECK();
+  return DDPO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// small element-wise kernels of the U-Net / VAE
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) geglu_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t rows, int F) {
+  const int f4 = F >> 2;
+  const int64_t total = rows * f4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / f4;
+    const int c = (int)(i - r * f4) << 2;
+    const float4 a = *reinterpret_cast<const float4*>(x + r * (2 * (int64_t)F) + c);
+    const float4 b = *reinterpret_cast<const float4*>(x + r * (2 * (int64_t)F) + F + c);
+    float4 o;
+    o.x = a.x * gelu_tanh_f(b.x); o.y = a.y * gelu_tanh_f(b.y); o.z = a.z * gelu_tanh_f(b.z); o.w = a.w * gelu_tanh_f(b.w);
+    *reinterpret_cast<float4*>(y + r * (int64_t)F + c) = o;
+  }
+}
+extern "C" int ddpo_geglu_fwd(const float* x, float* y, int64_t rows, int F, void* stream) {
+  if (!x || !y || rows <= 0 || F <= 0 || (F & 3)) return DDPO_EINVAL;
+  int64_t blocks = (rows * (F >> 2) + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(geglu_kernel, dim3((int)blocks), dim3(256), 0, as_stream(stream), x, y, rows, F);
+  DDPO_LAUNCH_CHECK();
+  return DDPO_OK;
+}
+
+__global__ void __launch_bounds__(256) silu_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) y[i] = silu_f(x[i]);
+}
+extern "C" int ddpo_silu_fwd(const float* x, float* y, int64_t n, void* stream) {
+  if (!x || !y || n <= 0) return DDPO_EINVAL;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(silu_kernel, dim3((int)blocks), dim3(256), 0, as_stream(stream), x, y, n);
+  DDPO_LAUNCH_CHECK();
+  return DDPO_OK;
+}
+
+// get_sinusoidal_embeddings(flip_sin_to_cos=True, freq_shift=0): out[b] = concat(cos(t f_i), sin(t f_i)), f_i = 1e4^(-i/half)
+__global__ void timestep_embedding_kernel(const int32_t* __restrict__ ts, float* __restrict__ out, int B, int dim) {
+  const int half = dim >> 1;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * half) return;
+  const int b = i / half, j = i - b * half;
+  const float freq = expf(-9.210340371976184f * (float)j / (float)half);
+  const float arg = (float)ts[b] * freq;
+  out[b * dim + j] = cosf(arg);
+  out[b * dim + half + j] = sinf(arg);
+}
+extern "C" int ddpo_timestep_embedding(const int32_t* ts, float* out, int B, int dim, void* stream) {
+  if (!ts || !out || B <= 0 || dim <= 0 || (dim & 1)) return DDPO_EINVAL;
+  const int n = B * (dim >> 1);
+  hipLaunchKernelGGL(timestep_embedding_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), ts, out, B, dim);
+  DDPO_LAUNCH_CHECK();
+  return DDPO_OK;
+}
+
+// (B,C,HW) <-> (B,HW,C) for small C (latents: C = 4; images: C = 3)
+__global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int C, int HW) {
+  const int64_t total = (int64_t)B * HW;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = i / HW, p = i - b * HW;
+    for (int c = 0; c < C; ++c) y[i * C + c] = x[(b * C + c) * HW + p];
+  }
+}
+__global__ void __launch_bounds__(256) nhwc_to_nchw_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int C, int HW) {
+  const int64_t total = (int64_t)B * HW;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = i / HW, p = i - b * HW;
+    for (int c = 0; c < C; ++c) y[(b * C + c) * HW + p] = x[i * C + c];
+  }
+}
+extern "C" int ddpo_nchw_to_nhwc(const float* x, float* y, int B, int C, int HW, void* stream) {
+  if (!x || !y || B <= 0 || C <= 0 || HW <= 0) return DDPO_EINVAL;
+  int64_t blocks = ((int64_t)B * HW + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((int)blocks), dim3(256), 0, as_stream(stream), x, y, B, C, HW);
+  DDPO_LAUNCH_CHECK();
+  return DDPO_OK;
+}
+extern "C" int ddpo_nhwc_to_nchw(const float* x, float* y, int B, int C, int HW, void* stream) {
+  if (!x || !y || B <= 0 || C <= 0 || HW <= 0) return DDPO_EINVAL;
+  int64_t blocks = ((int64_t)B * HW + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((int)blocks), dim3(256), 0, as_stream(stream), x, y, B, C, HW);
+  DDPO_LAUNCH_CHECK();
+  return DDPO_OK;
+}
+
+// strided column-block copy (materialises the skip concat: dst[:, off:off+cols] = src)
+__global__ void __launch_bounds__(256) copy_cols_kernel(const float* __restrict__ src, int ld_src, float* __restrict__ dst,
+                                                        int ld_dst, int64_t rows, int cols4) {
+  const int64_t total = rows * cols4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cols4;
+    const int c = (int)(i - r * cols4) << 2;
+    *reinterpret_cast<float4*>(dst + r * ld_dst + c) = *reinterpret_cast<const float4*>(src + r * ld_src + c);
+  }
+}
+extern "C" int ddpo_copy_cols(const float* src, int ld_src, float* dst, int ld_dst, int64_t rows, int cols, void* stream) {
+  if (!src || !dst || rows <= 0 || cols <= 0 || (cols & 3) || (ld_src & 3) || (ld_dst & 3)) return DDPO_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) return DDPO_EINVAL;
+  int64_t blocks = (rows * (cols >> 2) + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(copy_cols_kernel, dim3((int)blocks), dim3(256), 0, as_stream(stream), src, ld_src, dst, ld_dst, rows, cols >> 2);
+  DDPO_LAUNCH_CHECK();
+  return DDPO_OK;
+}
+
+// in-place row softmax of scale*x (VAE mid-block attention, single head, materialised scores)
+__global__ void __launch_bounds__(256) softmax_rows_kernel(float* __restrict__ x, int64_t rows, int cols, float scale) {
+  __shared__ float red[16];
+  for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
+    float* row = x + r * (int64_t)cols;
+    float m = -INFINITY;
+    for (int i = threadIdx.x; i < cols; i += blockDim.x) m = fmaxf(m, row[i] * scale);
+    m = wave_max(m);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float s = 0.f;
+    for (int i = threadIdx.x; i < cols; i += blockDim.x) {
+      const float e = expf(row[i] * scale - m);
+      row[i] = e;
+      s += e;
+    }
+    s = block_sum(s, red);
+    const float inv = 1.0f / s;
+    for (int i = threadIdx.x; i < cols; i += blockDim.x) row[i] *= inv;
+    __syncthreads();
+  }
+}
+extern "C" int ddpo_softmax_rows(float* x, int64_t rows, int cols, float scale, void* stream) {
+  if (!x || rows <= 0 || cols <= 0) return DDPO_EINVAL;
+  int64_t blocks = rows > 65535 ? 65535 : rows;
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((int)blocks), dim3(256), 0, as_stream(stream), x, rows, cols, scale);
+  DDPO_LAUNCH_CHECK();
+  return DDPO_OK;
+}
+
+__global__ void __launch_bounds__(256) scale_shift_clip_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n,
+                                                               float scale, float shift, float lo, float hi) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = fminf(fmaxf(x[i] * scale + shift, lo), hi);
+}
+extern "C" int ddpo_scale_shift_clip(const float* x, float* y, int64_t n, float scale, float shift, float lo, float hi, void* stream) {
+  if (!x || !y || n <= 0) return DDPO_EINVAL;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(scale_shift_clip_kernel, dim3((int)blocks), dim3(256), 0, as_stream(stream), x, y, n, scale, shift, lo, hi);
+  DDPO_LAUNCH_CHECK();
+  return DDPO_OK;
+}

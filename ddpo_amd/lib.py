@@ -1,0 +1,326 @@
+"""ctypes binding of libddpo_hip.so (the C ABI declared in include/ddpo_hip.h).
+
+PyTorch is used only as the device allocator / stream provider: every wrapper takes torch CUDA tensors, passes
+their raw device pointers plus the current HIP stream to the C entry point and returns torch tensors.
+There is NO fallback path: if the shared library is missing or a call fails, an exception is raised.
+"""
+import ctypes
+import os
+from ctypes import c_void_p, c_int, c_int32, c_int64, c_uint32, c_float, c_double, c_size_t, POINTER, byref
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libddpo_hip.so")
+
+PRED_TYPES = {"epsilon": 0, "v_prediction": 1, "sample": 2}
+
+
+class DdimConsts(ctypes.Structure):
+    _fields_ = [("alphas_cumprod", c_void_p), ("num_train_timesteps", c_int), ("step_ratio", c_int),
+                ("final_alpha_cumprod", c_float), ("eta", c_float), ("pred_type", c_int)]
+
+
+class GemmDesc(ctypes.Structure):
+    _fields_ = [("src", c_void_p), ("ld_src", c_int),
+                ("w", c_void_p), ("w_trans", c_int),
+                ("bias", c_void_p),
+                ("rowbias", c_void_p), ("rows_per_batch", c_int), ("ld_rowbias", c_int),
+                ("residual", c_void_p), ("ld_res", c_int),
+                ("out", c_void_p), ("ld_out", c_int),
+                ("alpha", c_float),
+                ("M", c_int), ("N", c_int), ("K", c_int),
+                ("ksize", c_int), ("stride", c_int), ("pad", c_int), ("upsample", c_int),
+                ("B", c_int), ("H", c_int), ("W", c_int), ("Cin", c_int),
+                ("OH", c_int), ("OW", c_int)]
+
+
+_SIGS = {
+    "ddpo_abi_version": (c_int, []),
+    "ddpo_sizeof_gemm_desc": (c_size_t, []),
+    "ddpo_sizeof_ddim_consts": (c_size_t, []),
+    "ddpo_threefry_bits_host": (c_int, [c_uint32, c_uint32, c_int64, c_void_p]),
+    "ddpo_threefry_normal": (c_int, [c_uint32, c_uint32, c_void_p, c_void_p, c_int64, c_void_p]),
+    "ddpo_ddim_step_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, POINTER(DdimConsts),
+                                   c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "ddpo_ddim_logprob_ppo_fwd_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                              c_float, c_float, c_int, POINTER(DdimConsts), c_void_p, c_void_p,
+                                              c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "ddpo_grad_sqnorm": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_void_p]),
+    "ddpo_adamw_bf16mu_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_double, c_double,
+                                       c_double, c_double, c_double, c_double, c_double, c_int, c_int, c_int, c_void_p]),
+    "ddpo_groupnorm_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "ddpo_groupnorm_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                   c_float, c_int, c_void_p, c_void_p]),
+    "ddpo_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
+    "ddpo_gemm_conv_fwd": (c_int, [POINTER(GemmDesc), c_void_p]),
+    "ddpo_attention_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
+                                   c_int, c_int, c_int, c_float, c_void_p]),
+    "ddpo_geglu_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "ddpo_silu_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "ddpo_timestep_embedding": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "ddpo_nchw_to_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ddpo_nhwc_to_nchw": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ddpo_copy_cols": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_void_p]),
+    "ddpo_softmax_rows": (c_int, [c_void_p, c_int64, c_int, c_float, c_void_p]),
+    "ddpo_scale_shift_clip": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGS)
+_lib = None
+
+
+class DdpoHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libddpo_hip.so (idempotent).  Raises if it has not been built — no CPU fallback exists."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DdpoHipError(f"{LIB_PATH} not found: build it with `python __graft_entry__.py` or "
+                           f"`make -C ddpo_amd/csrc` (the DDPO engine has no non-HIP path)")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.ddpo_sizeof_gemm_desc() != ctypes.sizeof(GemmDesc) or lib.ddpo_sizeof_ddim_consts() != ctypes.sizeof(DdimConsts):
+        raise DdpoHipError("struct layout mismatch between include/ddpo_hip.h and ddpo_amd/lib.py")
+    _lib = lib
+    return lib
+
+
+def _check(rc, name):
+    if rc != 0:
+        raise DdpoHipError(f"{name} failed with status {rc} ({'invalid argument' if rc == -1 else 'launch failure'})")
+
+
+def _stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+
+def _f32(t, name="tensor"):
+    if t.dtype != torch.float32 or not t.is_cuda:
+        raise DdpoHipError(f"{name} must be a float32 CUDA tensor, got {t.dtype} on {t.device}")
+    return t
+
+
+# ------------------------------------------------------------------------------------------------ PRNG
+def threefry_bits_host(key, n):
+    """uint32 words of jax `random_bits(key, n)` computed on the host (key bookkeeping)."""
+    import numpy as np
+    out = np.empty(int(n), dtype=np.uint32)
+    _check(load().ddpo_threefry_bits_host(int(key[0]), int(key[1]), int(n), out.ctypes.data_as(c_void_p)), "ddpo_threefry_bits_host")
+    return out
+
+
+def threefry_normal(key, shape, device="cuda", out=None, return_bits=False):
+    """jax.random.normal(key, shape, float32) on the GPU.  key: 2 uint32 words."""
+    n = 1
+    for s in shape:
+        n *= int(s)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float32, device=device)
+    bits = torch.empty(n, dtype=torch.int32, device=out.device) if return_bits else None
+    _check(load().ddpo_threefry_normal(int(key[0]), int(key[1]), _p(out), _p(bits), n, _stream()), "ddpo_threefry_normal")
+    return (out, bits) if return_bits else out
+
+
+# ------------------------------------------------------------------------------------------------ DDIM / PPO
+def make_ddim_consts(alphas_cumprod_dev, step_ratio, final_alpha_cumprod, eta, prediction_type):
+    c = DdimConsts()
+    c.alphas_cumprod = alphas_cumprod_dev.data_ptr()
+    c.num_train_timesteps = alphas_cumprod_dev.numel()
+    c.step_ratio = int(step_ratio)
+    c.final_alpha_cumprod = float(final_alpha_cumprod)
+    c.eta = float(eta)
+    c.pred_type = PRED_TYPES[prediction_type]
+    c._keepalive = alphas_cumprod_dev
+    return c
+
+
+def ddim_step_fwd(eps_u, eps_c, x, z, ts, guidance_scale, consts, x_next=None, logp=None):
+    B = x.shape[0]
+    chw = x.numel() // B
+    if x_next is None:
+        x_next = torch.empty_like(x)
+    if logp is None:
+        logp = torch.empty(B, dtype=torch.float32, device=x.device)
+    _check(load().ddpo_ddim_step_fwd(_p(eps_u), _p(eps_c), _p(x), _p(z), _p(ts), float(guidance_scale), byref(consts),
+                                     _p(x_next), _p(logp), B, chw, _stream()), "ddpo_ddim_step_fwd")
+    return x_next, logp
+
+
+def ddim_logprob_ppo_fwd_bwd(eps_c, eps_u, x, x_next, ts, old_logp, advantages, guidance_scale, clip_range, train_cfg, consts):
+    B = x.shape[0]
+    chw = x.numel() // B
+    d_c = torch.empty_like(eps_c)
+    d_u = torch.empty_like(eps_c) if train_cfg else None
+    per_sample = torch.empty(B, 4, dtype=torch.float32, device=x.device)
+    info = torch.empty(3, dtype=torch.float32, device=x.device)
+    _check(load().ddpo_ddim_logprob_ppo_fwd_bwd(_p(eps_c), _p(eps_u), _p(x), _p(x_next), _p(ts), _p(old_logp), _p(advantages),
+                                                float(guidance_scale), float(clip_range), int(bool(train_cfg)), byref(consts),
+                                                _p(d_c), _p(d_u), _p(per_sample), _p(info), B, chw, _stream()),
+           "ddpo_ddim_logprob_ppo_fwd_bwd")
+    return d_c, d_u, per_sample, info
+
+
+# ------------------------------------------------------------------------------------------------ optimizer
+def grad_sqnorm(g, out_sq=None):
+    if out_sq is None:
+        out_sq = torch.zeros(1, dtype=torch.float64, device=g.device)
+    _check(load().ddpo_grad_sqnorm(_p(g), g.numel(), _p(out_sq), 1, _stream()), "ddpo_grad_sqnorm")
+    return out_sq
+
+
+def adamw_bf16mu_step(p, g, mu, nu, sqnorm, inv_n_acc, lr, b1, b2, eps, weight_decay, max_grad_norm, step_t,
+                      mu_decay_in_bf16=True, zero_grad=True):
+    assert mu.dtype == torch.bfloat16 and nu.dtype == torch.float32 and sqnorm.dtype == torch.float64
+    _check(load().ddpo_adamw_bf16mu_step(_p(p), _p(g), _p(mu), _p(nu), p.numel(), _p(sqnorm), float(inv_n_acc), float(lr),
+                                         float(b1), float(b2), float(eps), float(weight_decay), float(max_grad_norm),
+                                         int(step_t), int(mu_decay_in_bf16), int(zero_grad), _stream()), "ddpo_adamw_bf16mu_step")
+
+
+# ------------------------------------------------------------------------------------------------ U-Net blocks
+_gn_ws = {}
+
+
+def _groupnorm_ws(B, C, G, device):
+    need = load().ddpo_groupnorm_ws_bytes(B, C, G)
+    key = (device, torch.cuda.current_stream().cuda_stream)
+    ws = _gn_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=device)
+        _gn_ws[key] = ws
+    return ws
+
+
+def groupnorm(x, B, HW, gamma, beta, groups, eps, silu, out=None, ld_x=None, ld_out=None):
+    """x: (B*HW, C) NHWC rows (row stride ld_x).  Returns (B*HW, C)."""
+    C = gamma.numel()
+    if out is None:
+        out = torch.empty(B * HW, C, dtype=torch.float32, device=x.device)
+    ws = _groupnorm_ws(B, C, groups, x.device)
+    _check(load().ddpo_groupnorm_fwd(_p(x), int(ld_x or C), _p(out), int(ld_out or C), _p(gamma), _p(beta), B, HW, C, groups,
+                                     float(eps), int(bool(silu)), _p(ws), _stream()), "ddpo_groupnorm_fwd")
+    return out
+
+
+def layernorm(x, gamma, beta, eps=1e-5, out=None):
+    rows, C = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    _check(load().ddpo_layernorm_fwd(_p(x), _p(out), _p(gamma), _p(beta), rows, C, float(eps), _stream()), "ddpo_layernorm_fwd")
+    return out
+
+
+def gemm_conv(src, w, *, M, N, K, bias=None, rowbias=None, rows_per_batch=0, residual=None, out=None, alpha=1.0,
+              w_trans=False, ld_src=None, ld_out=None, ld_res=None, conv=None):
+    """Generic entry: conv = dict(ksize, stride, pad, upsample, B, H, W, Cin, OH, OW) or None for a dense GEMM."""
+    d = GemmDesc()
+    d.src = src.data_ptr(); d.ld_src = int(ld_src if ld_src is not None else (conv["Cin"] if conv else K))
+    d.w = w.data_ptr(); d.w_trans = int(bool(w_trans))
+    d.bias = bias.data_ptr() if bias is not None else None
+    if rowbias is not None:
+        d.rowbias = rowbias.data_ptr(); d.rows_per_batch = int(rows_per_batch); d.ld_rowbias = int(rowbias.shape[-1])
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=src.device)
+    if residual is not None:
+        d.residual = residual.data_ptr(); d.ld_res = int(ld_res if ld_res is not None else N)
+    d.out = out.data_ptr(); d.ld_out = int(ld_out if ld_out is not None else N)
+    d.alpha = float(alpha)
+    d.M, d.N, d.K = int(M), int(N), int(K)
+    if conv:
+        for k in ("ksize", "stride", "pad", "upsample", "B", "H", "W", "Cin", "OH", "OW"):
+            setattr(d, k, int(conv[k]))
+    _check(load().ddpo_gemm_conv_fwd(byref(d), _stream()), "ddpo_gemm_conv_fwd")
+    return out
+
+
+def conv2d(x, w, bias, B, H, W, Cin, Cout, ksize, stride=1, pad=None, upsample=False, **kw):
+    """x: (B*H*W, Cin) NHWC rows; w: (ksize,ksize,Cin,Cout) HWIO.  Returns ((B*OH*OW, Cout), OH, OW)."""
+    if pad is None:
+        pad = ksize // 2
+    VH, VW = (2 * H, 2 * W) if upsample else (H, W)
+    OH = (VH + 2 * pad - ksize) // stride + 1
+    OW = (VW + 2 * pad - ksize) // stride + 1
+    conv = dict(ksize=ksize, stride=stride, pad=pad, upsample=int(upsample), B=B, H=H, W=W, Cin=Cin, OH=OH, OW=OW)
+    out = gemm_conv(x, w, M=B * OH * OW, N=Cout, K=ksize * ksize * Cin, bias=bias, conv=conv, **kw)
+    return out, OH, OW
+
+
+def linear(x, w, bias=None, **kw):
+    """x: (M,K); w: (K,N) (Flax (in,out))."""
+    M, K = x.shape
+    N = w.shape[0] if kw.get("w_trans") else w.shape[1]
+    return gemm_conv(x, w, M=M, N=N, K=K, bias=bias, **kw)
+
+
+def attention(q, k, v, B, heads, Nq, Nk, d, scale=None, out=None, ldq=None, ldk=None, ldv=None, ldo=None):
+    C = heads * d
+    if out is None:
+        out = torch.empty(B * Nq, C, dtype=torch.float32, device=q.device)
+    _check(load().ddpo_attention_fwd(_p(q), int(ldq or C), _p(k), int(ldk or C), _p(v), int(ldv or C), _p(out), int(ldo or C),
+                                     B, heads, Nq, Nk, d, float(scale if scale is not None else d ** -0.5), _stream()),
+           "ddpo_attention_fwd")
+    return out
+
+
+def geglu(x):
+    rows, F2 = x.shape
+    out = torch.empty(rows, F2 // 2, dtype=torch.float32, device=x.device)
+    _check(load().ddpo_geglu_fwd(_p(x), _p(out), rows, F2 // 2, _stream()), "ddpo_geglu_fwd")
+    return out
+
+
+def silu(x):
+    out = torch.empty_like(x)
+    _check(load().ddpo_silu_fwd(_p(x), _p(out), x.numel(), _stream()), "ddpo_silu_fwd")
+    return out
+
+
+def timestep_embedding(ts, dim):
+    B = ts.numel()
+    out = torch.empty(B, dim, dtype=torch.float32, device=ts.device)
+    _check(load().ddpo_timestep_embedding(_p(ts), _p(out), B, dim, _stream()), "ddpo_timestep_embedding")
+    return out
+
+
+def nchw_to_nhwc(x):
+    B, C, H, W = x.shape
+    out = torch.empty(B * H * W, C, dtype=torch.float32, device=x.device)
+    _check(load().ddpo_nchw_to_nhwc(_p(x), _p(out), B, C, H * W, _stream()), "ddpo_nchw_to_nhwc")
+    return out
+
+
+def nhwc_to_nchw(x, B, C, H, W):
+    out = torch.empty(B, C, H, W, dtype=torch.float32, device=x.device)
+    _check(load().ddpo_nhwc_to_nchw(_p(x), _p(out), B, C, H * W, _stream()), "ddpo_nhwc_to_nchw")
+    return out
+
+
+def copy_cols(src, dst, col_off, rows, cols, ld_src=None):
+    """dst[:, col_off:col_off+cols] = src[:, :cols] (dst/src are 2-D row-major)."""
+    ld_dst = dst.shape[1]
+    dptr = c_void_p(dst.data_ptr() + 4 * col_off)
+    _check(load().ddpo_copy_cols(_p(src), int(ld_src or src.shape[1]), dptr, ld_dst, rows, cols, _stream()), "ddpo_copy_cols")
+
+
+def softmax_rows_(x, scale=1.0):
+    rows, cols = x.shape
+    _check(load().ddpo_softmax_rows(_p(x), rows, cols, float(scale), _stream()), "ddpo_softmax_rows")
+    return x
+
+
+def scale_shift_clip(x, scale, shift, lo, hi):
+    out = torch.empty_like(x)
+    _check(load().ddpo_scale_shift_clip(_p(x), _p(out), x.numel(), float(scale), float(shift), float(lo), float(hi), _stream()),
+           "ddpo_scale_shift_clip")
+    return out

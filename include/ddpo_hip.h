@@ -1,0 +1,137 @@
+/* ddpo_hip.h — C ABI of libddpo_hip.so: the MI355X (gfx950) kernels behind the DDPO hot path.
+ *
+ * The reference (jannerm/ddpo) is pure Python/JAX and has no FFI boundary of its own; every entry point
+ * below names the reference call site (file:line under /root/reference) whose arithmetic it replaces.
+ * Conventions: all pointers are DEVICE pointers owned by the caller unless marked "host"; tensors are
+ * fp32 unless stated; `stream` is a hipStream_t passed as void*; functions never allocate, never
+ * synchronise and never throw; they return 0 on success, DDPO_EINVAL (-1) for a bad argument and
+ * DDPO_ELAUNCH (-2) if the launch was rejected.  Activations are NHWC ("pixel-major") inside the U-Net,
+ * latents/trajectories are NCHW at rest exactly as the reference stores them.
+ */
+#ifndef DDPO_HIP_H
+#define DDPO_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DDPO_OK 0
+#define DDPO_EINVAL (-1)
+#define DDPO_ELAUNCH (-2)
+
+#define DDPO_PRED_EPSILON 0
+#define DDPO_PRED_V 1
+#define DDPO_PRED_SAMPLE 2
+
+int ddpo_abi_version(void);
+size_t ddpo_sizeof_gemm_desc(void);     /* for binding self-checks (ctypes / cffi struct mirrors) */
+size_t ddpo_sizeof_ddim_consts(void);
+
+/* ---- PRNG: jax.random (Threefry-2x32) -------------------------------------------------------------
+ * jax.random.split / PRNGKey bookkeeping, pipeline/policy_gradient.py:51,201,244-245 and
+ * ddpo/diffusers_patch/pipeline_flax_stable_diffusion.py:196,232,252.  Host-side, integer-exact. */
+int ddpo_threefry_bits_host(uint32_t k0, uint32_t k1, int64_t n, uint32_t* out_host);
+/* jax.random.normal(key, shape, float32) flattened to n elements:
+ * pipeline_flax_stable_diffusion.py:197 (initial latents), scheduling_ddim_flax.py:347 (step noise).
+ * bits_out (optional, may be NULL) receives the raw uint32 words for bit-exact checks. */
+int ddpo_threefry_normal(uint32_t k0, uint32_t k1, float* out, uint32_t* bits_out, int64_t n, void* stream);
+
+/* ---- DDIM scheduler ------------------------------------------------------------------------------
+ * Scheduler constants shared by both DDIM kernels: alphas_cumprod is the device table ᾱ[0..T_train),
+ * final_alpha_cumprod / step_ratio / eta / pred_type as in scheduling_ddim_flax.py:154-158,279-281,325. */
+typedef struct {
+  const float* alphas_cumprod;   /* device, num_train_timesteps floats */
+  int num_train_timesteps;
+  int step_ratio;                /* num_train_timesteps / num_inference_steps */
+  float final_alpha_cumprod;
+  float eta;
+  int pred_type;                 /* DDPO_PRED_* */
+} ddpo_ddim_consts;
+
+/* Sampling-mode FlaxDDIMScheduler.step fused with the CFG combine:
+ * pipeline_flax_stable_diffusion.py:226-235 + scheduling_ddim_flax.py:279-359.
+ *   eps = eps_u + g (eps_c - eps_u);  x_next = mu(eps, x, t) + sigma z;  logp[b] = mean_chw N(x_next; mu, sigma_c)
+ * eps_u/eps_c/x/z/x_next: (B, chw) contiguous; ts: (B,) int32 device; logp: (B,). */
+int ddpo_ddim_step_fwd(const float* eps_u, const float* eps_c, const float* x, const float* z,
+                       const int32_t* ts, float guidance_scale, const ddpo_ddim_consts* c,
+                       float* x_next, float* logp, int B, int chw, void* stream);
+
+/* Scoring-mode step + PPO-clip loss + its gradient w.r.t. the two U-Net outputs:
+ * ddpo/training/policy_gradient.py:95-125 (forward), jax.grad of it (:138-139) down to d eps_c / d eps_u.
+ * per_sample: (B,4) = {log_prob, ratio, max(unclipped,clipped), clipped?}; info: 3 floats
+ * {approx_kl, clipfrac, loss} (:132-134).  If train_cfg == 0, eps_u/d_eps_u may be NULL. */
+int ddpo_ddim_logprob_ppo_fwd_bwd(const float* eps_c, const float* eps_u, const float* x,
+                                  const float* x_next, const int32_t* ts, const float* old_logp,
+                                  const float* advantages, float guidance_scale, float clip_range,
+                                  int train_cfg, const ddpo_ddim_consts* c, float* d_eps_c,
+                                  float* d_eps_u, float* per_sample, float* info, int B, int chw,
+                                  void* stream);
+
+/* ---- optimizer: optax.chain(clip_by_global_norm, adamw(mu_dtype=bf16)) + AccumulatingTrainState ----
+ * pipeline/policy_gradient.py:130-150; ddpo/training/policy_gradient.py:32-48. */
+/* out_sq (device double, must be zeroed by the caller or zero_first=1) += sum g^2 */
+int ddpo_grad_sqnorm(const float* g, int64_t n, double* out_sq, int zero_first, void* stream);
+/* One update over flat buffers.  g holds the SUM of accumulated grads; inv_n_acc = 1/(n_acc+1);
+ * sqnorm_of_sum = device double holding sum(g^2) of that SUM (the kernel applies inv_n_acc itself).
+ * mu is bf16 (uint16), nu fp32.  step_t is the new count (>=1).  If zero_grad, g is cleared. */
+int ddpo_adamw_bf16mu_step(float* p, float* g, uint16_t* mu, float* nu, int64_t n,
+                           const double* sqnorm_of_sum, double inv_n_acc, double lr, double b1, double b2,
+                           double eps, double weight_decay, double max_grad_norm, int step_t,
+                           int mu_decay_in_bf16, int zero_grad, void* stream);
+
+/* ---- U-Net / VAE building blocks (diffusers FlaxUNet2DConditionModel.apply / FlaxAutoencoderKL.decode;
+ *      call sites pipeline_flax_stable_diffusion.py:219-224, ddpo/training/policy_gradient.py:87-102,
+ *      pipeline/policy_gradient.py:174-182) --------------------------------------------------------- */
+
+/* GroupNorm(+SiLU) over NHWC x:(B,HW,C) with row stride ldx/ldy (floats).
+ * ws: 16-byte aligned scratch of ddpo_groupnorm_ws_bytes(B,C,G) bytes (group sums + per-(b,c) affine). */
+size_t ddpo_groupnorm_ws_bytes(int B, int C, int G);
+int ddpo_groupnorm_fwd(const float* x, int ldx, float* y, int ldy, const float* gamma, const float* beta,
+                       int B, int HW, int C, int G, float eps, int fuse_silu, void* ws, void* stream);
+/* LayerNorm over the last dim: x,y:(rows,C) contiguous. */
+int ddpo_layernorm_fwd(const float* x, float* y, const float* gamma, const float* beta, int rows, int C,
+                       float eps, void* stream);
+
+/* Implicit-GEMM convolution / dense GEMM on the exact-fp32 MFMA datapath (v_mfma_f32_32x32x2_f32).
+ *   out[m][n] = alpha * sum_k A(m,k) * W[k][n] (+ bias[n]) (+ rowbias[m / rows_per_batch][n]) (+ residual[m][n])
+ * conv mode: m = (b, oy, ox), k = (ky, kx, ci); src is NHWC with pixel stride ld_src; optional nearest-2x
+ * upsampling of the source folded into the gather (FlaxUpsample2D), stride 1|2, pad 0|1, ksize 1|3.
+ * dense mode (ksize==0): A = src (M,K) with row stride ld_src.
+ * W is (K, N) row-major (Flax HWIO / (in,out) layout) unless w_trans, then (N, K). */
+typedef struct {
+  const float* src; int ld_src;
+  const float* w; int w_trans;
+  const float* bias;              /* (N) or NULL */
+  const float* rowbias; int rows_per_batch; int ld_rowbias;   /* (Bt, N): time-embedding add, or NULL */
+  const float* residual; int ld_res;                          /* (M, N) or NULL */
+  float* out; int ld_out;
+  float alpha;
+  int M, N, K;
+  /* conv geometry (ksize==0 => dense) */
+  int ksize, stride, pad, upsample;
+  int B, H, W, Cin;               /* source dims (before upsample) */
+  int OH, OW;
+} ddpo_gemm_desc;
+int ddpo_gemm_conv_fwd(const ddpo_gemm_desc* d, void* stream);
+
+/* Fused multi-head attention, softmax(q k^T * scale) v, flash-style on fp32 MFMA (16x16x4).
+ * q:(B,Nq,·) k,v:(B,Nk,·) o:(B,Nq,·): head h occupies columns [h*d,(h+1)*d) of each row; ld* = row strides. */
+int ddpo_attention_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                       float* o, int ldo, int B, int heads, int Nq, int Nk, int d, float scale,
+                       void* stream);
+
+/* Small element-wise pieces. */
+int ddpo_geglu_fwd(const float* x, float* y, int64_t rows, int F, void* stream);      /* y = x[:, :F] * gelu_tanh(x[:, F:]) */
+int ddpo_silu_fwd(const float* x, float* y, int64_t n, void* stream);
+int ddpo_timestep_embedding(const int32_t* ts, float* out, int B, int dim, void* stream); /* concat([cos, sin]) */
+int ddpo_nchw_to_nhwc(const float* x, float* y, int B, int C, int HW, void* stream);
+int ddpo_nhwc_to_nchw(const float* x, float* y, int B, int C, int HW, void* stream);
+int ddpo_copy_cols(const float* src, int ld_src, float* dst, int ld_dst, int64_t rows, int cols, void* stream);
+int ddpo_softmax_rows(float* x, int64_t rows, int cols, float scale, void* stream);    /* in place */
+int ddpo_scale_shift_clip(const float* x, float* y, int64_t n, float scale, float shift, float lo, float hi, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,159 @@
+"""CPU checks of the oracle restatements: DDIM schedule anchors, log-prob identities, PPO closed form vs autograd,
+optax-AdamW restatement vs an independent float64 derivation, parameter-count anchors."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ppo, prng
+from oracle.ddim import DDIMOracle
+from oracle.optim import AdamWBf16Mu, AccumulatingState, bf16_round, global_norm
+from oracle import unet as OU
+
+
+def _gold(golden_dir):
+    with open(os.path.join(golden_dir, "ddim_schedule.json")) as f:
+        return json.load(f)
+
+
+def test_schedule_anchors(golden_dir):
+    g = _gold(golden_dir)
+    d = DDIMOracle()
+    s = d.create_state()
+    for k, v in g["alphas_cumprod"].items():
+        assert abs(float(s.alphas_cumprod[int(k)]) - v) <= 2e-7 * max(1.0, abs(v)) + 5e-9, k
+    assert float(s.final_alpha_cumprod) == float(s.alphas_cumprod[0])
+    s50 = d.set_timesteps(s, 50)
+    assert s50.timesteps[:3].tolist() == g["timesteps_T50_head"] and s50.timesteps[-3:].tolist() == g["timesteps_T50_tail"]
+    assert d.set_timesteps(s, 4).timesteps.tolist() == g["timesteps_T4"]
+    for c in g["coeffs_eta1"]:
+        st = d.set_timesteps(s, c["T"])
+        a_t, a_p, b_t, std = d.coefficients(st, c["t"], 1.0)
+        dmu = np.sqrt(1 - a_p - std ** 2) - np.sqrt(a_p) * np.sqrt(1 - a_t) / np.sqrt(a_t)
+        assert abs(float(std) - c["sigma"]) < 2e-6 and abs(float(dmu) - c["dmu_deps"]) < 5e-6
+
+
+def test_param_count_anchors(golden_dir):
+    g = _gold(golden_dir)["param_counts"]
+    assert OU.count_params(OU.unet_param_shapes(OU.SD15)) == g["unet_sd15"]
+    assert OU.count_params(OU.unet_param_shapes(OU.SD21)) == g["unet_sd21"]
+    assert OU.count_params(OU.vae_decoder_param_shapes(OU.VAE_SD)) == g["vae_decoder_with_post_quant"]
+
+
+@pytest.mark.parametrize("pred", ["epsilon", "v_prediction"])
+def test_sampling_logprob_identity(pred):
+    """In sampling mode x' - mu = sigma z, so log_prob = mean(-z^2/2) - log sigma - log sqrt(2 pi)."""
+    d = DDIMOracle(prediction_type=pred)
+    st = d.set_timesteps(d.create_state(), 50)
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((3, 4, 8, 8), dtype=np.float32)
+    e = rng.standard_normal((3, 4, 8, 8), dtype=np.float32)
+    z = rng.standard_normal((3, 4, 8, 8), dtype=np.float32)
+    t = 481
+    xn, lp = d.step(st, e, t, x, noise=z, eta=1.0)
+    _, _, _, std = d.coefficients(st, t, 1.0)
+    want = (-(z.astype(np.float64) ** 2) / 2).reshape(3, -1).mean(1) - math.log(float(std)) - 0.5 * math.log(2 * math.pi)
+    np.testing.assert_allclose(lp, want, rtol=0, atol=2e-4)
+    # scoring mode on the produced sample reproduces the same log-prob
+    _, lp2 = d.step(st, e, t, x, prev_sample=xn, eta=1.0)
+    np.testing.assert_allclose(lp2, lp, rtol=0, atol=1e-6)
+    with pytest.raises(ValueError):
+        d.step(st, e, t, x, noise=z, prev_sample=xn, eta=1.0)
+
+
+@pytest.mark.parametrize("pred", ["epsilon", "v_prediction"])
+@pytest.mark.parametrize("train_cfg", [True, False])
+def test_ppo_closed_form_matches_autograd(pred, train_cfg):
+    d = DDIMOracle(prediction_type=pred)
+    st = d.set_timesteps(d.create_state(), 50)
+    g = torch.Generator().manual_seed(1)
+    B = 6
+    shp = (B, 4, 8, 8)
+    eps_c = torch.randn(shp, generator=g, dtype=torch.float64)
+    eps_u = torch.randn(shp, generator=g, dtype=torch.float64)
+    lat = torch.randn(shp, generator=g, dtype=torch.float64)
+    ts = torch.tensor([981, 481, 1, 21, 701, 241])
+    # build next_latents near the posterior mean so that ratios straddle the clip range
+    with torch.no_grad():
+        guided = eps_u + 5.0 * (eps_c - eps_u) if train_cfg else eps_c
+        nxt, _ = d.step(st, guided.numpy().astype(np.float32), ts.numpy(), lat.numpy().astype(np.float32),
+                        noise=torch.randn(shp, generator=g).numpy(), eta=1.0)
+    nxt = torch.from_numpy(nxt).double()
+    batch = {"latents": lat, "next_latents": nxt, "ts": ts.numpy(),
+             "advantages": torch.tensor([1.5, -0.7, 12.0, -20.0, 0.3, -0.2], dtype=torch.float64)}
+    ec = eps_c.clone().requires_grad_(True)
+    eu = eps_u.clone().requires_grad_(True)
+    with torch.no_grad():
+        lp0 = ppo.log_prob_torch(d, st, (eu + 5.0 * (ec - eu)) if train_cfg else ec, batch["ts"], lat, nxt, 1.0, torch.float64)
+    # old log-probs: inside, above and below the clip range
+    batch["log_probs"] = lp0 + torch.tensor([0.0, 5e-5, -3e-4, 3e-4, 3e-4, -3e-4], dtype=torch.float64)
+    loss, info, lp = ppo.loss_and_info_torch(d, st, ec, eu, batch, 5.0, 1.0, 1e-4, train_cfg, torch.float64)
+    loss.backward()
+    l2, info2, lp2, dc, du = ppo.closed_form_numpy(d, st, eps_c.numpy().astype(np.float32), eps_u.numpy().astype(np.float32),
+                                                   lat.numpy().astype(np.float32), nxt.numpy().astype(np.float32), ts.numpy(),
+                                                   batch["log_probs"].numpy().astype(np.float32), batch["advantages"].numpy(),
+                                                   5.0, 1.0, 1e-4, train_cfg)
+    np.testing.assert_allclose(lp2, lp.detach().numpy(), rtol=2e-5, atol=2e-5)
+    assert abs(float(l2) - float(loss)) < 1e-4 * max(1, abs(float(loss)))
+    assert float(info2["clipfrac"]) == pytest.approx(float(info["clipfrac"]))
+    scale = float(ec.grad.abs().max())
+    np.testing.assert_allclose(dc, ec.grad.numpy(), rtol=2e-3, atol=2e-4 * scale)
+    if train_cfg:
+        np.testing.assert_allclose(du, eu.grad.numpy(), rtol=2e-3, atol=2e-4 * scale)
+    # clipped samples carry exactly zero gradient
+    clipped_rows = (ec.grad.flatten(1).abs().sum(1) == 0).numpy()
+    assert clipped_rows.any() and (np.abs(dc).reshape(B, -1).sum(1)[clipped_rows] == 0).all()
+
+
+def test_bf16_round_matches_torch():
+    x = np.random.default_rng(0).standard_normal(10000).astype(np.float32) * 10
+    want = torch.from_numpy(x).to(torch.bfloat16).to(torch.float32).numpy()
+    np.testing.assert_array_equal(bf16_round(x), want)
+
+
+def test_adamw_against_float64_rederivation():
+    rng = np.random.default_rng(0)
+    p = [rng.standard_normal((37, 5)).astype(np.float32), rng.standard_normal(11).astype(np.float32)]
+    opt = AdamWBf16Mu(mu_decay_in_bf16=False)
+    st = AccumulatingState(p, opt)
+    m64 = [np.zeros_like(x, dtype=np.float64) for x in p]
+    v64 = [np.zeros_like(x, dtype=np.float64) for x in p]
+    p64 = [x.astype(np.float64) for x in p]
+    for t in range(1, 4):
+        g1 = [rng.standard_normal(x.shape).astype(np.float32) * 3 for x in p]
+        g2 = [rng.standard_normal(x.shape).astype(np.float32) * 3 for x in p]
+        st.apply_gradients(g1, do_update=False)
+        assert st.n_acc == 1
+        st.apply_gradients(g2, do_update=True)
+        assert st.n_acc == 0 and all((ga == 0).all() for ga in st.grad_acc) and st.step == t
+        g = [(a.astype(np.float64) + b) / 2 for a, b in zip(g1, g2)]
+        n = math.sqrt(sum((x ** 2).sum() for x in g))
+        assert abs(float(st.last_grad_norm) - n) < 1e-5 * n
+        if n >= 1.0:
+            g = [x / n for x in g]
+        for i in range(len(p)):
+            m64[i] = 0.9 * bf16_round(m64[i].astype(np.float32)).astype(np.float64) + 0.1 * g[i]
+            v64[i] = 0.999 * v64[i] + 0.001 * g[i] ** 2
+            u = (m64[i] / (1 - 0.9 ** t)) / (np.sqrt(v64[i] / (1 - 0.999 ** t)) + 1e-8) + 1e-4 * p64[i]
+            p64[i] = p64[i] - 1e-5 * u
+            np.testing.assert_allclose(st.params[i], p64[i], rtol=1e-6, atol=1e-7)
+
+
+def test_accumulate_then_reduce_equals_reduce_then_accumulate():
+    """mean-over-ranks and sum-over-steps commute (justifies one all-reduce per optimizer update)."""
+    rng = np.random.default_rng(1)
+    g = rng.standard_normal((2, 3, 50))          # (rank, micro-step, param)
+    a = g.mean(0).sum(0)
+    b = g.sum(1).mean(0)
+    np.testing.assert_allclose(a, b, rtol=1e-12)
+    assert float(global_norm([a.astype(np.float32)])) == pytest.approx(float(np.sqrt((a ** 2).sum())), rel=1e-6)
+
+
+def test_key_tree_shapes():
+    keys = prng.sample_key_tree(0, n_devices=8, n_batches=2)
+    assert len(keys) == 2 and keys[0].shape == (8, 2) and keys[0].dtype == np.uint32
+    init, zs = prng.device_noise_stream(keys[0][3], (2, 4, 8, 8), 4)
+    assert init.shape == (2, 4, 8, 8) and len(zs) == 4 and not np.array_equal(zs[0], zs[1])
