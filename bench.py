@@ -1,0 +1,197 @@
+#!/usr/bin/env python
+"""Headline benchmark: sampled images/sec (512x512, 50 DDIM steps, CFG 5.0, eta 1.0, VAE decode included) on N MI355X.
+
+A "step" = one pass of the sampling hot path over one per-GPU batch of `sample_batch_size` (8) prompts:
+50 x [U-Net on 2B latents -> CFG -> Threefry noise -> DDIM step + log-prob] + VAE decode — BASELINE.json configs[1]
+(compressed-animals geometry, SD-1.5 architecture, 512^2, 50 steps) with synthetic embeddings and random-init
+weights (no checkpoints are reachable offline).  Weak scaling: every rank samples its own batch, no data-path
+collective; value = all images of all ranks / max-over-ranks wall time.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     — dominant kernel (fp32-MFMA implicit-GEMM conv/GEMM): algorithmic FLOPs / event-timed duration
+  cpu_baseline — the CPU oracle (oracle/, torch-CPU) timed on a bounded sample of the same workload (rank 0, N=1)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+UNET_FWD_TFLOP = {"sd15": 0.8033, "tiny": None}      # per sample at 64x64 latents
+VAE_TFLOP = {"sd15": 2.5145}
+FP32_MFMA_PEAK_TFLOPS = 157.3                          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--model", default="sd15", choices=["sd15", "tiny"])
+    ap.add_argument("--resolution", type=int, default=512)
+    ap.add_argument("--n-inference-steps", type=int, default=50)
+    ap.add_argument("--sample-batch-size", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(args):
+    """Times the oracle restatement (torch CPU, all host cores) on ONE CFG denoising step of ONE image
+    (U-Net batch 2 at the benchmark resolution), then scales by the analytic FLOP count of a full image."""
+    from oracle import unet as OU
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = OU.SD15 if args.model == "sd15" else OU.TINY
+    g = torch.Generator().manual_seed(0)
+    params = {}
+    for name, shp in OU.unet_param_shapes(cfg).items():
+        fan = int(np.prod(shp[:-1])) if name.endswith(".kernel") else 1
+        params[name] = torch.randn(shp, generator=g) / (fan ** 0.5) if name.endswith(".kernel") else \
+            (torch.ones(shp) if name.endswith(".scale") else torch.zeros(shp))
+    hw = args.resolution // 8
+    x = torch.randn(2, 4, hw, hw, generator=g)
+    ctx = torch.randn(2, 77, cfg.cross_attention_dim, generator=g)
+    t = torch.full((2,), 481, dtype=torch.int32)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        OU.unet_forward(params, cfg, x, t, ctx)
+    dt = time.perf_counter() - t0
+    T = args.n_inference_steps
+    if args.model == "sd15" and hw == 64:
+        per_image = dt * T * (1.0 + VAE_TFLOP["sd15"] / (T * 2 * UNET_FWD_TFLOP["sd15"]))
+        gflops = 2 * UNET_FWD_TFLOP["sd15"] * 1e3 / dt
+    else:
+        per_image = dt * T
+        gflops = None
+    return {"value": 1.0 / per_image, "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"one CFG denoising step of one image (oracle U-Net fwd, batch 2, {hw}x{hw} latents) = {dt:.2f} s on "
+                      f"{cores} torch-CPU threads; x{T} steps + VAE decode scaled by analytic FLOPs",
+            "seconds_per_cfg_step": dt, "cpu_gflops": gflops}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the DDPO engine has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        dist.init_process_group("nccl", device_id=dev)
+
+    from ddpo_amd import lib as L
+    from ddpo_amd.models.unet import UNet2DCondition, UNetConfig
+    from ddpo_amd.models.vae import VAEDecoder, VAEConfig
+    from ddpo_amd.diffusers_patch.scheduling_ddim import DDIMScheduler
+    from ddpo_amd.diffusers_patch.pipeline_stable_diffusion import StableDiffusionPipeline
+    from ddpo_amd.utils import prng
+
+    L.load()
+    ucfg = UNetConfig.named(args.model)
+    unet = UNet2DCondition(ucfg, dev)
+    unet.params.init_synthetic(seed=0)
+    vae = VAEDecoder(VAEConfig.named("sd" if args.model == "sd15" else "tiny"), dev)
+    vae.params.init_synthetic(seed=1)
+    sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", set_alpha_to_one=False, steps_offset=1)
+    state = sched.create_state(device=dev)
+    pipe = StableDiffusionPipeline(unet, vae, sched)
+    B = args.sample_batch_size
+    g = torch.Generator().manual_seed(1 + rank)
+    emb = torch.randn(B, 77, ucfg.cross_attention_dim, generator=g).to(dev)
+    neg = torch.randn(1, 77, ucfg.cross_attention_dim, generator=torch.Generator().manual_seed(2)).expand(B, -1, -1).contiguous().to(dev)
+    # reference key tree (pipeline/policy_gradient.py:51,201,244-245): rank r uses row r of split(sample_seed, n_devices)
+    rng = prng.PRNGKey(0)
+    _, sample_rng = prng.split(rng)
+
+    def one_step():
+        nonlocal sample_rng
+        sample_rng, sample_seed = prng.split(sample_rng)
+        key = prng.split(sample_seed, world)[rank]
+        final, lat, nxt, lps, ts = pipe(emb, neg, {"unet": unet.params, "scheduler": state}, key, args.n_inference_steps,
+                                        height=args.resolution, width=args.resolution, guidance_scale=5.0, eta=1.0)
+        img = vae.decode(final)
+        return img, lps
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        img, lps = one_step()
+    sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert torch.isfinite(img).all() and torch.isfinite(lps).all()
+    images = world * B * args.steps
+    value = images / dt
+
+    roofline = None
+    if not args.no_roofline:
+        # event-timed pass over the dominant kernel family (every ddpo_gemm_conv_fwd launch of one U-Net forward
+        # on 2B latents); events are recorded on the stream the kernels are launched on.
+        lat2 = torch.randn(2 * B, 4, args.resolution // 8, args.resolution // 8, device=dev)
+        ts2 = torch.full((2 * B,), 481, dtype=torch.int32, device=dev)
+        ctx2 = torch.cat([neg, emb])
+        unet(lat2, ts2, ctx2)
+        torch.cuda.synchronize()
+        L.PROFILE = []
+        unet(lat2, ts2, ctx2)
+        torch.cuda.synchronize()
+        recs, L.PROFILE = L.PROFILE, None
+        flops = sum(r[2] for r in recs)
+        ms = sum(r[0].elapsed_time(r[1]) for r in recs)
+        achieved = flops / (ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": "gemm_conv_kernel (v_mfma_f32_32x32x2_f32)", "achieved": achieved,
+                    "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                    "launches": len(recs), "avg_launch_ms": ms / max(len(recs), 1),
+                    "algorithmic_gflop_per_launch": flops / max(len(recs), 1) / 1e9}
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args)
+    tflop_per_image = None
+    if args.model == "sd15" and args.resolution == 512:
+        tflop_per_image = args.n_inference_steps * 2 * UNET_FWD_TFLOP["sd15"] + VAE_TFLOP["sd15"]
+    out = {
+        "metric": "sampled images/sec (512^2, 50 DDIM steps)", "value": value, "unit": "images/sec", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[1]: compressed-animals geometry, {args.model} U-Net+VAE (random init), "
+                               f"{args.resolution}x{args.resolution}, {args.n_inference_steps} DDIM steps, CFG 5.0, eta 1.0, "
+                               f"sample_batch_size {B}/GPU, VAE decode included",
+                   "datapath": "exact-fp32 MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4_f32)", "parallelism": f"dp{world}",
+                   "global_batch": world * B},
+        "end_to_end_tflops": None if tflop_per_image is None else value * tflop_per_image,
+        "roofline": roofline, "cpu_baseline": cpu,
+    }
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

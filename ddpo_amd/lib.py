@@ -68,6 +68,9 @@ _SIGS = {
 
 EXPORTED_SYMBOLS = tuple(_SIGS)
 _lib = None
+# When set to a list, every ddpo_gemm_conv_fwd launch appends (start_event, end_event, algorithmic_flops);
+# used by bench.py for the live roofline measurement of the dominant kernel.
+PROFILE = None
 
 
 class DdpoHipError(RuntimeError):
@@ -240,6 +243,13 @@ def gemm_conv(src, w, *, M, N, K, bias=None, rowbias=None, rows_per_batch=0, res
     if conv:
         for k in ("ksize", "stride", "pad", "upsample", "B", "H", "W", "Cin", "OH", "OW"):
             setattr(d, k, int(conv[k]))
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _check(load().ddpo_gemm_conv_fwd(byref(d), _stream()), "ddpo_gemm_conv_fwd")
+        e1.record()
+        PROFILE.append((e0, e1, 2.0 * M * N * K))
+        return out
     _check(load().ddpo_gemm_conv_fwd(byref(d), _stream()), "ddpo_gemm_conv_fwd")
     return out
 
