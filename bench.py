@@ -47,7 +47,7 @@ def cpu_baseline(args):
     """Times the oracle restatement (torch CPU, all host cores) on ONE CFG denoising step of ONE image
     (U-Net batch 2 at the benchmark resolution), then scales by the analytic FLOP count of a full image."""
     from oracle import unet as OU
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 32)      # torch-CPU stops scaling (and oversubscribes) beyond a few dozen threads
     torch.set_num_threads(cores)
     cfg = OU.SD15 if args.model == "sd15" else OU.TINY
     g = torch.Generator().manual_seed(0)
@@ -57,13 +57,13 @@ def cpu_baseline(args):
         params[name] = torch.randn(shp, generator=g) / (fan ** 0.5) if name.endswith(".kernel") else \
             (torch.ones(shp) if name.endswith(".scale") else torch.zeros(shp))
     hw = args.resolution // 8
-    x = torch.randn(2, 4, hw, hw, generator=g)
-    ctx = torch.randn(2, 77, cfg.cross_attention_dim, generator=g)
-    t = torch.full((2,), 481, dtype=torch.int32)
+    x = torch.randn(1, 4, hw, hw, generator=g)
+    ctx = torch.randn(1, 77, cfg.cross_attention_dim, generator=g)
+    t = torch.full((1,), 481, dtype=torch.int32)
     t0 = time.perf_counter()
     with torch.no_grad():
         OU.unet_forward(params, cfg, x, t, ctx)
-    dt = time.perf_counter() - t0
+    dt = 2.0 * (time.perf_counter() - t0)       # a CFG step is two such forwards (uncond + cond)
     T = args.n_inference_steps
     if args.model == "sd15" and hw == 64:
         per_image = dt * T * (1.0 + VAE_TFLOP["sd15"] / (T * 2 * UNET_FWD_TFLOP["sd15"]))
@@ -72,7 +72,7 @@ def cpu_baseline(args):
         per_image = dt * T
         gflops = None
     return {"value": 1.0 / per_image, "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"one CFG denoising step of one image (oracle U-Net fwd, batch 2, {hw}x{hw} latents) = {dt:.2f} s on "
+            "sample": f"one oracle U-Net forward (batch 1, {hw}x{hw} latents) timed, x2 for a CFG step = {dt:.2f} s on "
                       f"{cores} torch-CPU threads; x{T} steps + VAE decode scaled by analytic FLOPs",
             "seconds_per_cfg_step": dt, "cpu_gflops": gflops}
 

@@ -5,18 +5,19 @@
 
 #define GN_THREADS 256
 #define GN_MAXCOL 4        // C <= 4*256*GN_MAXCOL = 4096
+#define GN_MAXC 4096
 #define GN_MAXG 64
+#define GN_PPB 32          // pixels per stats block (lower bound)
 
-// Pass 1: per-(b, group) sum / sum-of-squares.  grid = (pixel chunks, B).
+// Pass 1: per-(b, pixel-chunk, group) partial sum / sum-of-squares, reduced in a FIXED order (no atomics, so the
+// result is bit-reproducible run to run).  grid = (pixel chunks, B).
 __global__ void __launch_bounds__(GN_THREADS) gn_stats_kernel(const float* __restrict__ x, int ldx, int HW, int C, int G,
-                                                              int pix_per_block, double* __restrict__ ws) {
-  __shared__ float s_sum[GN_MAXG], s_sq[GN_MAXG];
+                                                              int pix_per_block, double* __restrict__ part) {
+  __shared__ float s_sum[GN_MAXC], s_sq[GN_MAXC];
   const int b = blockIdx.y;
   const int C4 = C >> 2;
   const int cpg = C / G;
   const int t = threadIdx.x;
-  if (t < G) { s_sum[t] = 0.f; s_sq[t] = 0.f; }
-  __syncthreads();
   const int p0 = blockIdx.x * pix_per_block;
   const int p1 = min(p0 + pix_per_block, HW);
   float sum[GN_MAXCOL][4], sq[GN_MAXCOL][4];
@@ -48,40 +49,49 @@ __global__ void __launch_bounds__(GN_THREADS) gn_stats_kernel(const float* __res
       }
     }
   }
+  // per-thread partials -> LDS as [slot][channel] (slot = pixel lane of the thread), then a serial per-group sum
 #pragma unroll
   for (int j = 0; j < GN_MAXCOL; ++j) {
     if (j < ncol) {
-      const int c = (col0 + j * GN_THREADS) << 2;
+      const int idx = poff * C + ((col0 + j * GN_THREADS) << 2);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int g = (c + e) / cpg;
-        atomicAdd(&s_sum[g], sum[j][e]);
-        atomicAdd(&s_sq[g], sq[j][e]);
-      }
+      for (int e = 0; e < 4; ++e) { s_sum[idx + e] = sum[j][e]; s_sq[idx + e] = sq[j][e]; }
     }
   }
   __syncthreads();
   if (t < G) {
-    atomicAdd(&ws[((int64_t)b * G + t) * 2 + 0], (double)s_sum[t]);
-    atomicAdd(&ws[((int64_t)b * G + t) * 2 + 1], (double)s_sq[t]);
+    double a = 0.0, q = 0.0;
+    for (int slot = 0; slot < ppi; ++slot)
+      for (int c = t * cpg; c < (t + 1) * cpg; ++c) { a += (double)s_sum[slot * C + c]; q += (double)s_sq[slot * C + c]; }
+    double* o = part + (((int64_t)b * gridDim.x + blockIdx.x) * G + t) * 2;
+    o[0] = a; o[1] = q;
   }
 }
 
-// Pass 2: per-(b, c) affine  a = rstd*gamma, s = beta - mean*a
-__global__ void gn_finalize_kernel(const double* __restrict__ ws, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   float* __restrict__ ab, int B, int C, int G, int HW, float eps) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= B * C) return;
-  const int b = i / C, c = i - b * C;
-  const int cpg = C / G, g = c / cpg;
+// Pass 2: one wave per (b, group): fixed-order reduction over the chunks, then the per-(b, c) affine
+//   a = rstd*gamma, s = beta - mean*a
+__global__ void __launch_bounds__(64) gn_finalize_kernel(const double* __restrict__ part, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float* __restrict__ ab, int chunks,
+                                                         int C, int G, int HW, float eps) {
+  const int b = blockIdx.x / G, g = blockIdx.x - b * G;
+  const int lane = threadIdx.x;
+  double a = 0.0, q = 0.0;
+  for (int ch = lane; ch < chunks; ch += 64) {
+    const double* o = part + (((int64_t)b * chunks + ch) * G + g) * 2;
+    a += o[0]; q += o[1];
+  }
+  a = wave_sum_d(a); q = wave_sum_d(q);
+  const int cpg = C / G;
   const double cnt = (double)cpg * (double)HW;
-  const double mean = ws[((int64_t)b * G + g) * 2] / cnt;
-  double var = ws[((int64_t)b * G + g) * 2 + 1] / cnt - mean * mean;
+  const double mean = a / cnt;
+  double var = q / cnt - mean * mean;
   if (var < 0.0) var = 0.0;
   const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-  const float a = rstd * gamma[c];
-  ab[2 * (int64_t)i] = a;
-  ab[2 * (int64_t)i + 1] = beta[c] - (float)mean * a;
+  for (int c = g * cpg + lane; c < (g + 1) * cpg; c += 64) {
+    const float k = rstd * gamma[c];
+    ab[2 * ((int64_t)b * C + c)] = k;
+    ab[2 * ((int64_t)b * C + c) + 1] = beta[c] - (float)mean * k;
+  }
 }
 
 // Pass 3: y = act(x*a + s)
@@ -104,28 +114,33 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__
   }
 }
 
-extern "C" size_t ddpo_groupnorm_ws_bytes(int B, int C, int G) {
-  return (size_t)B * G * 2 * sizeof(double) + (size_t)B * C * 2 * sizeof(float);
+static inline int gn_ppb(int C) {
+  const int C4 = C >> 2;
+  const int ppi = C4 <= GN_THREADS ? GN_THREADS / C4 : 1;
+  int ppb = GN_PPB < ppi ? ppi : GN_PPB;
+  return ((ppb + ppi - 1) / ppi) * ppi;
+}
+
+extern "C" size_t ddpo_groupnorm_ws_bytes(int B, int HW, int C, int G) {
+  if (B <= 0 || HW <= 0 || C <= 0 || G <= 0) return 0;
+  const int chunks = (HW + gn_ppb(C) - 1) / gn_ppb(C);
+  return (size_t)B * chunks * G * 2 * sizeof(double) + (size_t)B * C * 2 * sizeof(float);
 }
 
 extern "C" int ddpo_groupnorm_fwd(const float* x, int ldx, float* y, int ldy, const float* gamma, const float* beta, int B,
                                   int HW, int C, int G, float eps, int fuse_silu, void* ws, void* stream) {
   if (!x || !y || !gamma || !beta || !ws || B <= 0 || HW <= 0 || C <= 0 || G <= 0 || G > GN_MAXG) return DDPO_EINVAL;
-  if ((C & 3) || (C % G) || (ldx & 3) || (ldy & 3) || C > 4 * GN_THREADS * GN_MAXCOL) return DDPO_EINVAL;
+  if ((C & 3) || (C % G) || (ldx & 3) || (ldy & 3) || C > GN_MAXC || B > 65535) return DDPO_EINVAL;
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(ws)) & 15) return DDPO_EINVAL;
   hipStream_t st = as_stream(stream);
-  double* sums = reinterpret_cast<double*>(ws);
-  float* ab = reinterpret_cast<float*>(sums + (size_t)B * G * 2);
-  if (hipMemsetAsync(sums, 0, (size_t)B * G * 2 * sizeof(double), st) != hipSuccess) return DDPO_ELAUNCH;
   const int C4 = C >> 2;
-  const int ppi = C4 <= GN_THREADS ? GN_THREADS / C4 : 1;
-  int ppb = 32;
-  if (ppb < ppi) ppb = ppi;
-  ppb = ((ppb + ppi - 1) / ppi) * ppi;
+  const int ppb = gn_ppb(C);
   const int chunks = (HW + ppb - 1) / ppb;
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(chunks, B), dim3(GN_THREADS), 0, st, x, ldx, HW, C, G, ppb, sums);
+  double* part = reinterpret_cast<double*>(ws);
+  float* ab = reinterpret_cast<float*>(part + (size_t)B * chunks * G * 2);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(chunks, B), dim3(GN_THREADS), 0, st, x, ldx, HW, C, G, ppb, part);
   DDPO_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, sums, gamma, beta, ab, B, C, G, HW, eps);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * G), dim3(64), 0, st, part, gamma, beta, ab, chunks, C, G, HW, eps);
   DDPO_LAUNCH_CHECK();
   int64_t blocks = ((int64_t)B * HW * C4 + 255) / 256;
   if (blocks > 16384) blocks = 16384;

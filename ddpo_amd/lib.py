@@ -49,7 +49,7 @@ _SIGS = {
     "ddpo_grad_sqnorm": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_void_p]),
     "ddpo_adamw_bf16mu_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_double, c_double,
                                        c_double, c_double, c_double, c_double, c_double, c_int, c_int, c_int, c_void_p]),
-    "ddpo_groupnorm_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "ddpo_groupnorm_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "ddpo_groupnorm_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                    c_float, c_int, c_void_p, c_void_p]),
     "ddpo_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
@@ -195,8 +195,8 @@ def adamw_bf16mu_step(p, g, mu, nu, sqnorm, inv_n_acc, lr, b1, b2, eps, weight_d
 _gn_ws = {}
 
 
-def _groupnorm_ws(B, C, G, device):
-    need = load().ddpo_groupnorm_ws_bytes(B, C, G)
+def _groupnorm_ws(B, HW, C, G, device):
+    need = load().ddpo_groupnorm_ws_bytes(B, HW, C, G)
     key = (device, torch.cuda.current_stream().cuda_stream)
     ws = _gn_ws.get(key)
     if ws is None or ws.numel() < need:
@@ -210,7 +210,7 @@ def groupnorm(x, B, HW, gamma, beta, groups, eps, silu, out=None, ld_x=None, ld_
     C = gamma.numel()
     if out is None:
         out = torch.empty(B * HW, C, dtype=torch.float32, device=x.device)
-    ws = _groupnorm_ws(B, C, groups, x.device)
+    ws = _groupnorm_ws(B, HW, C, groups, x.device)
     _check(load().ddpo_groupnorm_fwd(_p(x), int(ld_x or C), _p(out), int(ld_out or C), _p(gamma), _p(beta), B, HW, C, groups,
                                      float(eps), int(bool(silu)), _p(ws), _stream()), "ddpo_groupnorm_fwd")
     return out

@@ -85,8 +85,9 @@ int ddpo_adamw_bf16mu_step(float* p, float* g, uint16_t* mu, float* nu, int64_t 
  *      pipeline/policy_gradient.py:174-182) --------------------------------------------------------- */
 
 /* GroupNorm(+SiLU) over NHWC x:(B,HW,C) with row stride ldx/ldy (floats).
- * ws: 16-byte aligned scratch of ddpo_groupnorm_ws_bytes(B,C,G) bytes (group sums + per-(b,c) affine). */
-size_t ddpo_groupnorm_ws_bytes(int B, int C, int G);
+ * ws: 16-byte aligned scratch of ddpo_groupnorm_ws_bytes(B,HW,C,G) bytes (per-chunk group sums + per-(b,c)
+ * affine).  Reductions run in a fixed order: results are bit-reproducible. */
+size_t ddpo_groupnorm_ws_bytes(int B, int HW, int C, int G);
 int ddpo_groupnorm_fwd(const float* x, int ldx, float* y, int ldy, const float* gamma, const float* beta,
                        int B, int HW, int C, int G, float eps, int fuse_silu, void* ws, void* stream);
 /* LayerNorm over the last dim: x,y:(rows,C) contiguous. */
