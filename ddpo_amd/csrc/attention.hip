@@ -19,7 +19,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int D, int DPV, int KT>
 __global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
                                                        const float* __restrict__ v, int ldv, float* __restrict__ o, int ldo,
-                                                       int heads, int Nq, int Nk, float scale_log2e) {
+                                                       float* __restrict__ lse, int heads, int Nq, int Nk, float scale_log2e) {
   constexpr int LDK = D + 2;
   constexpr int LDV = DPV + 4;
   constexpr int NS = D / 4;         // k-steps of the S^T product
@@ -129,6 +129,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__
   float l_tot = l_run + __shfl_xor(l_run, 16, 64);
   l_tot += __shfl_xor(l_tot, 32, 64);
   const float inv = 1.0f / l_tot;
+  if (lse && g == 0 && q0 + qi < Nq) lse[(int64_t)bh * Nq + q0 + qi] = m_run + log2f(l_tot);   // log2-domain logsumexp
   if (q0 + qi < Nq) {
     float* op = o + ((int64_t)b * Nq + q0 + qi) * ldo + h * D;
 #pragma unroll
@@ -140,17 +141,17 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__
 }
 
 template <int D, int DPV, int KT>
-static int launch_attn(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo, int B,
-                       int heads, int Nq, int Nk, float scale, hipStream_t st) {
+static int launch_attn(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo, float* lse,
+                       int B, int heads, int Nq, int Nk, float scale, hipStream_t st) {
   dim3 grid((Nq + 63) / 64, B * heads);
-  hipLaunchKernelGGL((attn_fwd_kernel<D, DPV, KT>), grid, dim3(256), 0, st, q, ldq, k, ldk, v, ldv, o, ldo, heads, Nq, Nk,
+  hipLaunchKernelGGL((attn_fwd_kernel<D, DPV, KT>), grid, dim3(256), 0, st, q, ldq, k, ldk, v, ldv, o, ldo, lse, heads, Nq, Nk,
                      scale * 1.4426950408889634f);
   DDPO_LAUNCH_CHECK();
   return DDPO_OK;
 }
 
 extern "C" int ddpo_attention_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
-                                  int B, int heads, int Nq, int Nk, int d, float scale, void* stream) {
+                                  float* lse, int B, int heads, int Nq, int Nk, int d, float scale, void* stream) {
   if (!q || !k || !v || !o || B <= 0 || heads <= 0 || Nq <= 0 || Nk <= 0) return DDPO_EINVAL;
   if ((ldq & 3) || (ldk & 3) || (ldv & 3) || (ldo & 3)) return DDPO_EINVAL;
   if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v) |
@@ -158,13 +159,13 @@ extern "C" int ddpo_attention_fwd(const float* q, int ldq, const float* k, int l
   if ((long)B * heads > 65535) return DDPO_EINVAL;
   hipStream_t st = as_stream(stream);
   switch (d) {
-    case 4:   return launch_attn<4, 16, 64>(q, ldq, k, ldk, v, ldv, o, ldo, B, heads, Nq, Nk, scale, st);
-    case 8:   return launch_attn<8, 16, 64>(q, ldq, k, ldk, v, ldv, o, ldo, B, heads, Nq, Nk, scale, st);
-    case 16:  return launch_attn<16, 16, 64>(q, ldq, k, ldk, v, ldv, o, ldo, B, heads, Nq, Nk, scale, st);
-    case 40:  return launch_attn<40, 48, 64>(q, ldq, k, ldk, v, ldv, o, ldo, B, heads, Nq, Nk, scale, st);
-    case 64:  return launch_attn<64, 64, 64>(q, ldq, k, ldk, v, ldv, o, ldo, B, heads, Nq, Nk, scale, st);
-    case 80:  return launch_attn<80, 80, 64>(q, ldq, k, ldk, v, ldv, o, ldo, B, heads, Nq, Nk, scale, st);
-    case 160: return launch_attn<160, 160, 32>(q, ldq, k, ldk, v, ldv, o, ldo, B, heads, Nq, Nk, scale, st);
+    case 4:   return launch_attn<4, 16, 64>(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, heads, Nq, Nk, scale, st);
+    case 8:   return launch_attn<8, 16, 64>(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, heads, Nq, Nk, scale, st);
+    case 16:  return launch_attn<16, 16, 64>(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, heads, Nq, Nk, scale, st);
+    case 40:  return launch_attn<40, 48, 64>(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, heads, Nq, Nk, scale, st);
+    case 64:  return launch_attn<64, 64, 64>(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, heads, Nq, Nk, scale, st);
+    case 80:  return launch_attn<80, 80, 64>(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, heads, Nq, Nk, scale, st);
+    case 160: return launch_attn<160, 160, 32>(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, heads, Nq, Nk, scale, st);
     default:  return DDPO_EINVAL;
   }
 }

@@ -51,6 +51,7 @@ __global__ void __launch_bounds__(GEMM_THREADS) gemm_conv_kernel(const ddpo_gemm
 
   const bool conv = d.ksize > 0;
   const int VH = d.upsample ? d.H * 2 : d.H, VW = d.upsample ? d.W * 2 : d.W;
+  const bool zins = d.upsample == 2;     // zero-insert source (transposed conv = dgrad of a stride-2 conv)
 
   // ---- A loader state: thread owns k-quad kq and rows (t>>2) + 64*i
   const int kq = t & 3;
@@ -94,7 +95,7 @@ __global__ void __launch_bounds__(GEMM_THREADS) gemm_conv_kernel(const ddpo_gemm
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (conv) {
         const int iy = ri[i].iy0 + ky, ix = ri[i].ix0 + kx;
-        if (ri[i].valid && kval && iy >= 0 && iy < VH && ix >= 0 && ix < VW) {
+        if (ri[i].valid && kval && iy >= 0 && iy < VH && ix >= 0 && ix < VW && !(zins && ((iy | ix) & 1))) {
           const int sy = d.upsample ? (iy >> 1) : iy, sx = d.upsample ? (ix >> 1) : ix;
           v = *reinterpret_cast<const float4*>(d.src + (ri[i].base + (int64_t)sy * d.W + sx) * d.ld_src + ci);
         }
@@ -108,7 +109,14 @@ __global__ void __launch_bounds__(GEMM_THREADS) gemm_conv_kernel(const ddpo_gemm
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (WTRANS) {
         const int n = n0 + (t >> 2) + 64 * i;
-        if (n < d.N && kval) v = *reinterpret_cast<const float4*>(d.w + (int64_t)n * d.K + kg);
+        if (n < d.N && kval) {
+          if (d.w_dgrad) {   // W is the forward HWIO kernel (taps, N=Cin_fwd, Cin=Cout_fwd): flipped tap, (ci,co) swapped
+            const int tapf = d.ksize * d.ksize - 1 - (ky * d.ksize + kx);
+            v = *reinterpret_cast<const float4*>(d.w + ((int64_t)tapf * d.N + n) * d.Cin + ci);
+          } else {
+            v = *reinterpret_cast<const float4*>(d.w + (int64_t)n * d.K + kg);
+          }
+        }
       } else {
         const int k = kt * BK + bk0 + BKSTEP * i;
         const int n = n0 + bn4 * 4;
@@ -195,6 +203,182 @@ __global__ void __launch_bounds__(GEMM_THREADS) gemm_conv_kernel(const ddpo_gemm
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient:  dW[k][n] (+)= sum_m A(m,k) * dY[m][n]   (k = (ky,kx,ci) for convs, reduction over the
+// B*OH*OW output pixels).  The A tile is gathered transposed — float4 along ci (the OUTPUT row dimension here),
+// one reduction index (pixel) per LDS row — and dY streams in directly; the long reduction is split across
+// gridDim.y and combined with fp32 atomic adds, which also implements the gradient accumulation
+// (AccumulatingTrainState: grad_acc += g) in place.
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN>
+__global__ void __launch_bounds__(GEMM_THREADS) gemm_wgrad_kernel(const ddpo_gemm_desc d, int tiles_n, int m_per_split) {
+  constexpr int BK = GEMM_BK;
+  constexpr int LDA = BM + 4;
+  constexpr int LDB = BN + 4;
+  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int APASS = (BK * BM / 4) / GEMM_THREADS;     // float4 chunks per thread (A tile)
+  constexpr int BPASS = (BK * BN / 4) / GEMM_THREADS;
+  constexpr int ARSTEP = GEMM_THREADS / (BM / 4);
+  constexpr int BRSTEP = GEMM_THREADS / (BN / 4);
+  __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
+
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
+  const int k0 = tile_m * BM, n0 = tile_n * BN;          // output rows are k (K = taps*Cin), columns n
+  const int m_begin = blockIdx.y * m_per_split;
+  const int m_end = min(m_begin + m_per_split, d.M);
+  if (m_begin >= m_end) return;
+
+  const bool conv = d.ksize > 0;
+  const int VH = d.upsample ? d.H * 2 : d.H, VW = d.upsample ? d.W * 2 : d.W;
+  const int ohw = conv ? d.OH * d.OW : 1;
+
+  // A loader: fixed output-row quad per thread
+  const int arow4 = t % (BM / 4), ar0 = t / (BM / 4);
+  const int kg = k0 + arow4 * 4;
+  const bool kvalid = kg < d.K;
+  int ky = 0, kx = 0, ci = kg;
+  if (conv) {
+    const int tap = kg / d.Cin;
+    ci = kg - tap * d.Cin;
+    ky = tap / d.ksize;
+    kx = tap - ky * d.ksize;
+  }
+  const int bn4 = t % (BN / 4), br0 = t / (BN / 4);
+
+  float4 ra[APASS], rb[BPASS];
+  auto load_tile = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < APASS; ++i) {
+      const int m = m_begin + kt * BK + ar0 + ARSTEP * i;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (kvalid && m < m_end) {
+        if (conv) {
+          const int b = m / ohw, rem = m - b * ohw;
+          const int oy = rem / d.OW, ox = rem - oy * d.OW;
+          const int iy = oy * d.stride - d.pad + ky, ix = ox * d.stride - d.pad + kx;
+          if (iy >= 0 && iy < VH && ix >= 0 && ix < VW) {
+            const int sy = d.upsample ? (iy >> 1) : iy, sx = d.upsample ? (ix >> 1) : ix;
+            v = *reinterpret_cast<const float4*>(d.src + (((int64_t)b * d.H + sy) * d.W + sx) * d.ld_src + ci);
+          }
+        } else {
+          v = *reinterpret_cast<const float4*>(d.src + (int64_t)m * d.ld_src + kg);
+        }
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < BPASS; ++i) {
+      const int m = m_begin + kt * BK + br0 + BRSTEP * i;
+      const int n = n0 + bn4 * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < m_end && n < d.N) v = *reinterpret_cast<const float4*>(d.w + (int64_t)m * d.ld_w + n);
+      rb[i] = v;
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < APASS; ++i) *reinterpret_cast<float4*>(&As[buf][(ar0 + ARSTEP * i) * LDA + arow4 * 4]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < BPASS; ++i) *reinterpret_cast<float4*>(&Bs[buf][(br0 + BRSTEP * i) * LDB + bn4 * 4]) = rb[i];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = (m_end - m_begin + BK - 1) / BK;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  const int a_off = wm * (BM / 2) + (lane & 31);
+  const int b_off = wn * (BN / 2) + (lane & 31);
+  const int khalf = lane >> 5;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) load_tile(kt + 1);
+    const float* as = As[cur];
+    const float* bs = Bs[cur];
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      const int k = kk * 2 + khalf;
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = as[k * LDA + a_off + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = bs[k * LDB + b_off + j * 32];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+      if (col >= d.N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = k0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+        if (row >= d.K) continue;
+        float* o = d.out + (int64_t)row * d.ld_out + col;
+        if (d.accumulate) atomicAdd(o, d.alpha * acc[i][j][r]);
+        else *o = d.alpha * acc[i][j][r];
+      }
+    }
+  }
+}
+
+template <int BM, int BN>
+static int launch_wgrad(const ddpo_gemm_desc& d0, hipStream_t st) {
+  ddpo_gemm_desc d = d0;
+  const int tiles_m = (d.K + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;
+  const int tiles = tiles_m * tiles_n;
+  int splits = d.splits;
+  if (splits <= 0) {
+    splits = (1024 + tiles - 1) / tiles;
+    const int max_splits = (d.M + 255) / 256;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+  }
+  if (splits > 1) d.accumulate = 1;      // caller must have zero-initialised (or be accumulating into) out
+  int mps = (d.M + splits - 1) / splits;
+  mps = (mps + GEMM_BK - 1) / GEMM_BK * GEMM_BK;
+  splits = (d.M + mps - 1) / mps;
+  hipLaunchKernelGGL((gemm_wgrad_kernel<BM, BN>), dim3(tiles, splits), dim3(GEMM_THREADS), 0, st, d, tiles_n, mps);
+  DDPO_LAUNCH_CHECK();
+  return DDPO_OK;
+}
+
+extern "C" int ddpo_gemm_conv_wgrad(const ddpo_gemm_desc* dp, void* stream) {
+  if (!dp) return DDPO_EINVAL;
+  const ddpo_gemm_desc& d = *dp;
+  if (!d.src || !d.w || !d.out || d.M <= 0 || d.N <= 0 || d.K <= 0) return DDPO_EINVAL;
+  if ((d.ld_src & 3) || (d.ld_w & 3) || (d.N & 3) || (d.K & 3)) return DDPO_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(d.src) | reinterpret_cast<uintptr_t>(d.w)) & 15) return DDPO_EINVAL;
+  if (d.ksize > 0) {
+    if (d.ksize != 1 && d.ksize != 3) return DDPO_EINVAL;
+    if ((d.Cin & 3) || d.K != d.ksize * d.ksize * d.Cin || d.M != d.B * d.OH * d.OW || d.upsample > 1) return DDPO_EINVAL;
+  }
+  if (d.splits != 1 && !d.accumulate && d.splits != 0) return DDPO_EINVAL;
+  hipStream_t st = as_stream(stream);
+  const long t128 = (long)((d.K + 127) / 128) * ((d.N + 127) / 128);
+  if (d.N % 128 == 0 && d.K >= 128 && t128 >= 16) return launch_wgrad<128, 128>(d, st);
+  if (d.N > 32 && d.K >= 128) return launch_wgrad<128, 64>(d, st);
+  return launch_wgrad<64, 64>(d, st);
+}
+
 template <int BM, int BN>
 static int launch_cfg(const ddpo_gemm_desc& d, hipStream_t st) {
   const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;
@@ -220,6 +404,8 @@ extern "C" int ddpo_gemm_conv_fwd(const ddpo_gemm_desc* dp, void* stream) {
     return DDPO_EINVAL;
   }
   if (d.w_trans ? (d.K & 3) : (d.N & 3)) return DDPO_EINVAL;
+  if (d.w_dgrad && (!d.w_trans || d.ksize <= 0)) return DDPO_EINVAL;
+  if (d.upsample < 0 || d.upsample > 2) return DDPO_EINVAL;
   if (d.rowbias && d.rows_per_batch <= 0) return DDPO_EINVAL;
   hipStream_t st = as_stream(stream);
   // tile choice: big tiles when they still fill the chip (256 CUs), smaller ones for small problems

@@ -71,8 +71,8 @@ __global__ void __launch_bounds__(GN_THREADS) gn_stats_kernel(const float* __res
 // Pass 2: one wave per (b, group): fixed-order reduction over the chunks, then the per-(b, c) affine
 //   a = rstd*gamma, s = beta - mean*a
 __global__ void __launch_bounds__(64) gn_finalize_kernel(const double* __restrict__ part, const float* __restrict__ gamma,
-                                                         const float* __restrict__ beta, float* __restrict__ ab, int chunks,
-                                                         int C, int G, int HW, float eps) {
+                                                         const float* __restrict__ beta, float* __restrict__ ab,
+                                                         float* __restrict__ mr, int chunks, int C, int G, int HW, float eps) {
   const int b = blockIdx.x / G, g = blockIdx.x - b * G;
   const int lane = threadIdx.x;
   double a = 0.0, q = 0.0;
@@ -87,6 +87,7 @@ __global__ void __launch_bounds__(64) gn_finalize_kernel(const double* __restric
   double var = q / cnt - mean * mean;
   if (var < 0.0) var = 0.0;
   const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  if (lane == 0) { mr[2 * blockIdx.x] = (float)mean; mr[2 * blockIdx.x + 1] = rstd; }
   for (int c = g * cpg + lane; c < (g + 1) * cpg; c += 64) {
     const float k = rstd * gamma[c];
     ab[2 * ((int64_t)b * C + c)] = k;
@@ -124,23 +125,26 @@ static inline int gn_ppb(int C) {
 extern "C" size_t ddpo_groupnorm_ws_bytes(int B, int HW, int C, int G) {
   if (B <= 0 || HW <= 0 || C <= 0 || G <= 0) return 0;
   const int chunks = (HW + gn_ppb(C) - 1) / gn_ppb(C);
-  return (size_t)B * chunks * G * 2 * sizeof(double) + (size_t)B * C * 2 * sizeof(float);
+  return (size_t)B * chunks * G * 2 * sizeof(double);
 }
+extern "C" size_t ddpo_groupnorm_stats_floats(int B, int C, int G) { return (size_t)B * C * 2 + (size_t)B * G * 2; }
 
 extern "C" int ddpo_groupnorm_fwd(const float* x, int ldx, float* y, int ldy, const float* gamma, const float* beta, int B,
-                                  int HW, int C, int G, float eps, int fuse_silu, void* ws, void* stream) {
-  if (!x || !y || !gamma || !beta || !ws || B <= 0 || HW <= 0 || C <= 0 || G <= 0 || G > GN_MAXG) return DDPO_EINVAL;
+                                  int HW, int C, int G, float eps, int fuse_silu, void* ws, float* stats, void* stream) {
+  if (!x || !y || !gamma || !beta || !ws || !stats || B <= 0 || HW <= 0 || C <= 0 || G <= 0 || G > GN_MAXG) return DDPO_EINVAL;
   if ((C & 3) || (C % G) || (ldx & 3) || (ldy & 3) || C > GN_MAXC || B > 65535) return DDPO_EINVAL;
-  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(ws)) & 15) return DDPO_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(ws) |
+       reinterpret_cast<uintptr_t>(stats)) & 15) return DDPO_EINVAL;
   hipStream_t st = as_stream(stream);
   const int C4 = C >> 2;
   const int ppb = gn_ppb(C);
   const int chunks = (HW + ppb - 1) / ppb;
   double* part = reinterpret_cast<double*>(ws);
-  float* ab = reinterpret_cast<float*>(part + (size_t)B * chunks * G * 2);
+  float* ab = stats;                                  // (B, C, 2): a = rstd*gamma, s = beta - mean*a
+  float* mr = stats + (size_t)B * C * 2;              // (B, G, 2): mean, rstd
   hipLaunchKernelGGL(gn_stats_kernel, dim3(chunks, B), dim3(GN_THREADS), 0, st, x, ldx, HW, C, G, ppb, part);
   DDPO_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * G), dim3(64), 0, st, part, gamma, beta, ab, chunks, C, G, HW, eps);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * G), dim3(64), 0, st, part, gamma, beta, ab, mr, chunks, C, G, HW, eps);
   DDPO_LAUNCH_CHECK();
   int64_t blocks = ((int64_t)B * HW * C4 + 255) / 256;
   if (blocks > 16384) blocks = 16384;

@@ -32,7 +32,8 @@ class GemmDesc(ctypes.Structure):
                 ("M", c_int), ("N", c_int), ("K", c_int),
                 ("ksize", c_int), ("stride", c_int), ("pad", c_int), ("upsample", c_int),
                 ("B", c_int), ("H", c_int), ("W", c_int), ("Cin", c_int),
-                ("OH", c_int), ("OW", c_int)]
+                ("OH", c_int), ("OW", c_int),
+                ("w_dgrad", c_int), ("ld_w", c_int), ("splits", c_int), ("accumulate", c_int)]
 
 
 _SIGS = {
@@ -51,11 +52,24 @@ _SIGS = {
                                        c_double, c_double, c_double, c_double, c_double, c_int, c_int, c_int, c_void_p]),
     "ddpo_groupnorm_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "ddpo_groupnorm_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
-                                   c_float, c_int, c_void_p, c_void_p]),
+                                   c_float, c_int, c_void_p, c_void_p, c_void_p]),
     "ddpo_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "ddpo_gemm_conv_fwd": (c_int, [POINTER(GemmDesc), c_void_p]),
-    "ddpo_attention_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
+    "ddpo_gemm_conv_wgrad": (c_int, [POINTER(GemmDesc), c_void_p]),
+    "ddpo_attention_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int,
                                    c_int, c_int, c_int, c_float, c_void_p]),
+    "ddpo_attention_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "ddpo_groupnorm_stats_floats": (c_size_t, [c_int, c_int, c_int]),
+    "ddpo_groupnorm_bwd_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "ddpo_groupnorm_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                   c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ddpo_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ddpo_geglu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "ddpo_silu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "ddpo_colsum_accum": (c_int, [c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "ddpo_sumpool2x2": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "ddpo_add": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "ddpo_geglu_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "ddpo_silu_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "ddpo_timestep_embedding": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
@@ -192,28 +206,38 @@ def adamw_bf16mu_step(p, g, mu, nu, sqnorm, inv_n_acc, lr, b1, b2, eps, weight_d
 
 
 # ------------------------------------------------------------------------------------------------ U-Net blocks
-_gn_ws = {}
+_ws_cache = {}
 
 
-def _groupnorm_ws(B, HW, C, G, device):
-    need = load().ddpo_groupnorm_ws_bytes(B, HW, C, G)
-    key = (device, torch.cuda.current_stream().cuda_stream)
-    ws = _gn_ws.get(key)
-    if ws is None or ws.numel() < need:
-        ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=device)
-        _gn_ws[key] = ws
+def _scratch(nbytes, device, tag):
+    key = (tag, str(device), torch.cuda.current_stream().cuda_stream)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
     return ws
 
 
-def groupnorm(x, B, HW, gamma, beta, groups, eps, silu, out=None, ld_x=None, ld_out=None):
-    """x: (B*HW, C) NHWC rows (row stride ld_x).  Returns (B*HW, C)."""
+def groupnorm(x, B, HW, gamma, beta, groups, eps, silu, out=None, ld_x=None, ld_out=None, return_stats=False):
+    """x: (B*HW, C) NHWC rows (row stride ld_x).  Returns (B*HW, C) [and the saved statistics for the backward]."""
     C = gamma.numel()
     if out is None:
         out = torch.empty(B * HW, C, dtype=torch.float32, device=x.device)
-    ws = _groupnorm_ws(B, HW, C, groups, x.device)
+    ws = _scratch(load().ddpo_groupnorm_ws_bytes(B, HW, C, groups), x.device, "gn")
+    stats = torch.empty(load().ddpo_groupnorm_stats_floats(B, C, groups), dtype=torch.float32, device=x.device)
     _check(load().ddpo_groupnorm_fwd(_p(x), int(ld_x or C), _p(out), int(ld_out or C), _p(gamma), _p(beta), B, HW, C, groups,
-                                     float(eps), int(bool(silu)), _p(ws), _stream()), "ddpo_groupnorm_fwd")
-    return out
+                                     float(eps), int(bool(silu)), _p(ws), _p(stats), _stream()), "ddpo_groupnorm_fwd")
+    return (out, stats) if return_stats else out
+
+
+def groupnorm_bwd(x, dy, stats, gamma, B, HW, groups, silu, dgamma, dbeta, dx_add=None, ld_x=None, ld_dy=None):
+    C = gamma.numel()
+    dx = torch.empty(B * HW, C, dtype=torch.float32, device=x.device)
+    ws = _scratch(load().ddpo_groupnorm_bwd_ws_bytes(B, HW, C, groups), x.device, "gnb")
+    _check(load().ddpo_groupnorm_bwd(_p(x), int(ld_x or C), _p(dy), int(ld_dy or C), _p(stats), _p(gamma), B, HW, C, groups,
+                                     int(bool(silu)), _p(dx_add), C, _p(dx), C, _p(dgamma), _p(dbeta), _p(ws), _stream()),
+           "ddpo_groupnorm_bwd")
+    return dx
 
 
 def layernorm(x, gamma, beta, eps=1e-5, out=None):
@@ -273,13 +297,137 @@ def linear(x, w, bias=None, **kw):
     return gemm_conv(x, w, M=M, N=N, K=K, bias=bias, **kw)
 
 
-def attention(q, k, v, B, heads, Nq, Nk, d, scale=None, out=None, ldq=None, ldk=None, ldv=None, ldo=None):
+def attention(q, k, v, B, heads, Nq, Nk, d, scale=None, out=None, ldq=None, ldk=None, ldv=None, ldo=None, return_lse=False):
     C = heads * d
     if out is None:
         out = torch.empty(B * Nq, C, dtype=torch.float32, device=q.device)
+    lse = torch.empty(B * heads * Nq, dtype=torch.float32, device=q.device) if return_lse else None
     _check(load().ddpo_attention_fwd(_p(q), int(ldq or C), _p(k), int(ldk or C), _p(v), int(ldv or C), _p(out), int(ldo or C),
-                                     B, heads, Nq, Nk, d, float(scale if scale is not None else d ** -0.5), _stream()),
+                                     _p(lse), B, heads, Nq, Nk, d, float(scale if scale is not None else d ** -0.5), _stream()),
            "ddpo_attention_fwd")
+    return (out, lse) if return_lse else out
+
+
+def attention_bwd(q, k, v, o, d_o, lse, B, heads, Nq, Nk, d, scale=None):
+    """Returns (dq, dk, dv), contiguous (rows, heads*d)."""
+    C = heads * d
+    dq = torch.empty(B * Nq, C, dtype=torch.float32, device=q.device)
+    dk = torch.empty(B * Nk, C, dtype=torch.float32, device=q.device)
+    dv = torch.empty(B * Nk, C, dtype=torch.float32, device=q.device)
+    dvec = torch.empty(B * heads * Nq, dtype=torch.float32, device=q.device)
+    _check(load().ddpo_attention_bwd(_p(q), C, _p(k), C, _p(v), C, _p(o), _p(d_o), _p(lse), _p(dvec), _p(dq), _p(dk), _p(dv),
+                                     B, heads, Nq, Nk, d, float(scale if scale is not None else d ** -0.5), _stream()),
+           "ddpo_attention_bwd")
+    return dq, dk, dv
+
+
+def layernorm_bwd(x, dy, gamma, dgamma, dbeta, eps=1e-5, dx_add=None):
+    rows, C = x.shape
+    dx = torch.empty_like(x)
+    _check(load().ddpo_layernorm_bwd(_p(x), _p(dy), _p(gamma), rows, C, float(eps), _p(dx_add), _p(dx), _p(dgamma), _p(dbeta), _stream()),
+           "ddpo_layernorm_bwd")
+    return dx
+
+
+def geglu_bwd(x, dy):
+    rows, F2 = x.shape
+    dx = torch.empty_like(x)
+    _check(load().ddpo_geglu_bwd(_p(x), _p(dy), _p(dx), rows, F2 // 2, _stream()), "ddpo_geglu_bwd")
+    return dx
+
+
+def silu_bwd(x, dy):
+    dx = torch.empty_like(x)
+    _check(load().ddpo_silu_bwd(_p(x), _p(dy), _p(dx), x.numel(), _stream()), "ddpo_silu_bwd")
+    return dx
+
+
+def colsum_accum(x, out, rows_per_seg=0, ld_x=None):
+    """out[seg, :] += column sums of x over each segment of rows_per_seg rows (0: all rows -> out is (cols,))."""
+    rows, cols = x.shape
+    _check(load().ddpo_colsum_accum(_p(x), int(ld_x or cols), rows, cols, int(rows_per_seg), _p(out), _stream()), "ddpo_colsum_accum")
+    return out
+
+
+def sumpool2x2(x, B, H, W, C):
+    """x: (B*2H*2W, C) -> (B*H*W, C)."""
+    out = torch.empty(B * H * W, C, dtype=torch.float32, device=x.device)
+    _check(load().ddpo_sumpool2x2(_p(x), _p(out), B, H, W, C, _stream()), "ddpo_sumpool2x2")
+    return out
+
+
+def add(a, b, out=None):
+    if out is None:
+        out = torch.empty_like(a)
+    _check(load().ddpo_add(_p(a), _p(b), _p(out), a.numel(), _stream()), "ddpo_add")
+    return out
+
+
+def linear_dgrad(dy, w, residual=None):
+    """dx = dy @ w^T for the forward y = x @ w, w: (K, N) Flax layout."""
+    M, N = dy.shape
+    K = w.shape[0]
+    return gemm_conv(dy, w, M=M, N=K, K=N, w_trans=True, residual=residual)
+
+
+def linear_wgrad(x, dy, dw):
+    """dw (K,N) += x^T @ dy."""
+    M, K = x.shape
+    N = dy.shape[1]
+    return gemm_wgrad(x, dy, dw, M=M, N=N, K=K)
+
+
+def gemm_wgrad(src, dy, dw, *, M, N, K, conv=None, ld_src=None, ld_dy=None, accumulate=True, splits=0, alpha=1.0):
+    d = GemmDesc()
+    d.src = src.data_ptr(); d.ld_src = int(ld_src if ld_src is not None else (conv["Cin"] if conv else K))
+    d.w = dy.data_ptr(); d.ld_w = int(ld_dy if ld_dy is not None else N)
+    d.out = dw.data_ptr(); d.ld_out = int(N)
+    d.alpha = float(alpha)
+    d.M, d.N, d.K = int(M), int(N), int(K)
+    d.accumulate = int(bool(accumulate)); d.splits = int(splits)
+    if conv:
+        for k in ("ksize", "stride", "pad", "upsample", "B", "H", "W", "Cin", "OH", "OW"):
+            setattr(d, k, int(conv[k]))
+    _check(load().ddpo_gemm_conv_wgrad(byref(d), _stream()), "ddpo_gemm_conv_wgrad")
+    return dw
+
+
+def _conv_geom(B, H, W, Cin, ksize, stride, pad, upsample):
+    if pad is None:
+        pad = ksize // 2
+    VH, VW = (2 * H, 2 * W) if upsample else (H, W)
+    OH = (VH + 2 * pad - ksize) // stride + 1
+    OW = (VW + 2 * pad - ksize) // stride + 1
+    return dict(ksize=ksize, stride=stride, pad=pad, upsample=int(bool(upsample)), B=B, H=H, W=W, Cin=Cin, OH=OH, OW=OW)
+
+
+def conv2d_wgrad(x, dy, dw, B, H, W, Cin, Cout, ksize, stride=1, pad=None, upsample=False, ld_src=None):
+    """dw (ksize,ksize,Cin,Cout) += im2col(x)^T @ dy, x: forward input (B*H*W, Cin), dy: (B*OH*OW, Cout)."""
+    conv = _conv_geom(B, H, W, Cin, ksize, stride, pad, upsample)
+    return gemm_wgrad(x, dy, dw, M=B * conv["OH"] * conv["OW"], N=Cout, K=ksize * ksize * Cin, conv=conv, ld_src=ld_src)
+
+
+def conv2d_dgrad(dy, w, B, H, W, Cin, Cout, ksize, stride=1, residual=None):
+    """Gradient w.r.t. the input of y = conv(x, w) (pad = ksize//2, no upsample): x was (B*H*W, Cin), dy is (B*OH*OW, Cout).
+    Returns (B*H*W, Cin).  stride 2 uses the zero-insert gather (transposed convolution)."""
+    pad = ksize // 2
+    OH = (H + 2 * pad - ksize) // stride + 1
+    OW = (W + 2 * pad - ksize) // stride + 1
+    if stride == 2 and (H != 2 * OH or W != 2 * OW):
+        raise DdpoHipError("stride-2 dgrad expects even input sizes")
+    conv = dict(ksize=ksize, stride=1, pad=pad, upsample=2 if stride == 2 else 0, B=B, H=OH, W=OW, Cin=Cout, OH=H, OW=W)
+    d = GemmDesc()
+    d.src = dy.data_ptr(); d.ld_src = int(Cout)
+    d.w = w.data_ptr(); d.w_trans = 1; d.w_dgrad = 1
+    out = torch.empty(B * H * W, Cin, dtype=torch.float32, device=dy.device)
+    if residual is not None:
+        d.residual = residual.data_ptr(); d.ld_res = int(Cin)
+    d.out = out.data_ptr(); d.ld_out = int(Cin)
+    d.alpha = 1.0
+    d.M, d.N, d.K = B * H * W, int(Cin), ksize * ksize * int(Cout)
+    for k, v in conv.items():
+        setattr(d, k, int(v))
+    _check(load().ddpo_gemm_conv_fwd(byref(d), _stream()), "ddpo_gemm_conv_fwd(dgrad)")
     return out
 
 

@@ -177,22 +177,61 @@ class Act:
     def HW(self):
         return self.H * self.W
 
+    @property
+    def M(self):
+        return self.B * self.H * self.W
 
-def resnet_forward(P, name, x: Act, temb_act, groups, eps):
+
+def resnet_forward(P, name, x: Act, temb_act, groups, eps, tape=None):
     """FlaxResnetBlock2D: GN-SiLU-conv3x3 (+time proj) - GN-SiLU-conv3x3 (+ shortcut)."""
     cout = P[name + ".conv1.bias"].numel()
-    h = L.groupnorm(x.t, x.B, x.HW, P[name + ".norm1.scale"], P[name + ".norm1.bias"], groups, eps, True)
+    h1, st1 = L.groupnorm(x.t, x.B, x.HW, P[name + ".norm1.scale"], P[name + ".norm1.bias"], groups, eps, True, return_stats=True)
     rowbias = None
     if temb_act is not None:
         rowbias = L.linear(temb_act, P[name + ".time_emb_proj.kernel"], P[name + ".time_emb_proj.bias"])
-    h, _, _ = L.conv2d(h, P[name + ".conv1.kernel"], P[name + ".conv1.bias"], x.B, x.H, x.W, x.C, cout, 3,
-                       rowbias=rowbias, rows_per_batch=x.HW)
-    h = L.groupnorm(h, x.B, x.HW, P[name + ".norm2.scale"], P[name + ".norm2.bias"], groups, eps, True)
+    c1, _, _ = L.conv2d(h1, P[name + ".conv1.kernel"], P[name + ".conv1.bias"], x.B, x.H, x.W, x.C, cout, 3,
+                        rowbias=rowbias, rows_per_batch=x.HW)
+    h2, st2 = L.groupnorm(c1, x.B, x.HW, P[name + ".norm2.scale"], P[name + ".norm2.bias"], groups, eps, True, return_stats=True)
     res = x.t
-    if (name + ".conv_shortcut.kernel") in P:
+    shortcut = (name + ".conv_shortcut.kernel") in P
+    if shortcut:
         res, _, _ = L.conv2d(x.t, P[name + ".conv_shortcut.kernel"], P[name + ".conv_shortcut.bias"], x.B, x.H, x.W, x.C, cout, 1)
-    out, _, _ = L.conv2d(h, P[name + ".conv2.kernel"], P[name + ".conv2.bias"], x.B, x.H, x.W, cout, cout, 3, residual=res)
+    out, _, _ = L.conv2d(h2, P[name + ".conv2.kernel"], P[name + ".conv2.bias"], x.B, x.H, x.W, cout, cout, 3, residual=res)
+    if tape is not None:
+        tape.append(("resnet", dict(name=name, x=x, st1=st1, h1=h1, c1=c1, st2=st2, h2=h2, cout=cout, shortcut=shortcut,
+                                    temb=temb_act is not None, groups=groups)))
     return Act(out, x.B, x.H, x.W, cout)
+
+
+def resnet_backward(P, G, r, d_out, tctx):
+    """Returns d_x (rows of x).  Parameter grads are accumulated into G; the time-embedding grad into tctx."""
+    name, x, cout = r["name"], r["x"], r["cout"]
+    B, H, W, HW = x.B, x.H, x.W, x.HW
+    # out = conv2(h2) + res
+    L.conv2d_wgrad(r["h2"], d_out, G[name + ".conv2.kernel"], B, H, W, cout, cout, 3)
+    L.colsum_accum(d_out, G[name + ".conv2.bias"])
+    d_h2 = L.conv2d_dgrad(d_out, P[name + ".conv2.kernel"], B, H, W, cout, cout, 3)
+    if r["shortcut"]:
+        L.conv2d_wgrad(x.t, d_out, G[name + ".conv_shortcut.kernel"], B, H, W, x.C, cout, 1)
+        L.colsum_accum(d_out, G[name + ".conv_shortcut.bias"])
+        d_res = L.conv2d_dgrad(d_out, P[name + ".conv_shortcut.kernel"], B, H, W, x.C, cout, 1)
+    else:
+        d_res = d_out
+    d_c1 = L.groupnorm_bwd(r["c1"], d_h2, r["st2"], P[name + ".norm2.scale"], B, HW, r["groups"], True,
+                           G[name + ".norm2.scale"], G[name + ".norm2.bias"])
+    L.conv2d_wgrad(r["h1"], d_c1, G[name + ".conv1.kernel"], B, H, W, x.C, cout, 3)
+    if r["temb"]:
+        d_tproj = torch.zeros(B, cout, dtype=torch.float32, device=d_c1.device)
+        L.colsum_accum(d_c1, d_tproj, rows_per_seg=HW)                      # d(time_emb_proj output)[b] = sum over pixels of b
+        L.colsum_accum(d_tproj, G[name + ".conv1.bias"])                    # conv1 bias sees the same sums
+        L.linear_wgrad(tctx["temb_act"], d_tproj, G[name + ".time_emb_proj.kernel"])
+        L.colsum_accum(d_tproj, G[name + ".time_emb_proj.bias"])
+        tctx["d_temb_act"] = L.linear_dgrad(d_tproj, P[name + ".time_emb_proj.kernel"], residual=tctx["d_temb_act"])
+    else:
+        L.colsum_accum(d_c1, G[name + ".conv1.bias"])
+    d_h1 = L.conv2d_dgrad(d_c1, P[name + ".conv1.kernel"], B, H, W, x.C, cout, 3)
+    return L.groupnorm_bwd(x.t, d_h1, r["st1"], P[name + ".norm1.scale"], B, HW, r["groups"], True,
+                           G[name + ".norm1.scale"], G[name + ".norm1.bias"], dx_add=d_res)
 
 
 class UNet2DCondition:
@@ -200,42 +239,123 @@ class UNet2DCondition:
         self.cfg = cfg
         self.device = torch.device(device)
         self.params = ParamStore(unet_param_shapes(cfg), self.device)
+        self.grads = None
 
-    # -------------------------------------------------------------------------------- sub-blocks
-    def _attention(self, name, x, B, N, C, heads, ctx, ctx_len):
+    def ensure_grads(self):
+        """Flat fp32 gradient-accumulation buffer with the parameter layout (AccumulatingTrainState.grad_acc)."""
+        if self.grads is None:
+            self.grads = ParamStore(self.params.shapes, self.device)
+        return self.grads
+
+    # -------------------------------------------------------------------------------- attention
+    def _attention(self, name, x, B, N, C, heads, ctx, ctx_len, rec=None):
         P = self.params
         q = L.linear(x, P[name + ".to_q.kernel"])
         kv_src = x if ctx is None else ctx
         k = L.linear(kv_src, P[name + ".to_k.kernel"])
         v = L.linear(kv_src, P[name + ".to_v.kernel"])
-        return L.attention(q, k, v, B, heads, N, N if ctx is None else ctx_len, C // heads)
+        Nk = N if ctx is None else ctx_len
+        if rec is None:
+            return L.attention(q, k, v, B, heads, N, Nk, C // heads)
+        o, lse = L.attention(q, k, v, B, heads, N, Nk, C // heads, return_lse=True)
+        rec.update(q=q, k=k, v=v, o=o, lse=lse, Nk=Nk)
+        return o
 
-    def _transformer(self, name, x: Act, ctx, ctx_len, heads):
+    def _attention_backward(self, name, rec, x_in, kv_in, d_o, B, N, C, heads, self_attn):
+        """d_o: grad of the attention output (before to_out).  Returns the grad w.r.t. the (normed) attention input."""
+        P, G = self.params, self.grads
+        dq, dk, dv = L.attention_bwd(rec["q"], rec["k"], rec["v"], rec["o"], d_o, rec["lse"], B, heads, N, rec["Nk"], C // heads)
+        L.linear_wgrad(x_in, dq, G[name + ".to_q.kernel"])
+        L.linear_wgrad(kv_in, dk, G[name + ".to_k.kernel"])
+        L.linear_wgrad(kv_in, dv, G[name + ".to_v.kernel"])
+        d_x = L.linear_dgrad(dq, P[name + ".to_q.kernel"])
+        if self_attn:
+            d_x = L.linear_dgrad(dk, P[name + ".to_k.kernel"], residual=d_x)
+            d_x = L.linear_dgrad(dv, P[name + ".to_v.kernel"], residual=d_x)
+        return d_x
+
+    def _transformer(self, name, x: Act, ctx, ctx_len, heads, tape=None):
         P, cfg = self.params, self.cfg
         C, B, N = x.C, x.B, x.HW
-        h = L.groupnorm(x.t, B, N, P[name + ".norm.scale"], P[name + ".norm.bias"], cfg.norm_groups, 1e-5, False)
+        rec = None if tape is None else dict(name=name, x=x, heads=heads, ctx=ctx, ctx_len=ctx_len)
+        hn, st = L.groupnorm(x.t, B, N, P[name + ".norm.scale"], P[name + ".norm.bias"], cfg.norm_groups, 1e-5, False, return_stats=True)
         if cfg.use_linear_projection:
-            h = L.linear(h, P[name + ".proj_in.kernel"], P[name + ".proj_in.bias"])
+            h0 = L.linear(hn, P[name + ".proj_in.kernel"], P[name + ".proj_in.bias"])
         else:
-            h, _, _ = L.conv2d(h, P[name + ".proj_in.kernel"], P[name + ".proj_in.bias"], B, x.H, x.W, C, C, 1)
+            h0, _, _ = L.conv2d(hn, P[name + ".proj_in.kernel"], P[name + ".proj_in.bias"], B, x.H, x.W, C, C, 1)
         tb = name + ".transformer_blocks_0"
         ln = lambda n, t: L.layernorm(t, P[f"{tb}.{n}.scale"], P[f"{tb}.{n}.bias"], 1e-5)
-        a = self._attention(tb + ".attn1", ln("norm1", h), B, N, C, heads, None, 0)
-        h = L.linear(a, P[tb + ".attn1.to_out_0.kernel"], P[tb + ".attn1.to_out_0.bias"], residual=h)
-        a = self._attention(tb + ".attn2", ln("norm2", h), B, N, C, heads, ctx, ctx_len)
-        h = L.linear(a, P[tb + ".attn2.to_out_0.kernel"], P[tb + ".attn2.to_out_0.bias"], residual=h)
-        f = L.linear(ln("norm3", h), P[tb + ".ff.net_0.proj.kernel"], P[tb + ".ff.net_0.proj.bias"])
-        f = L.geglu(f)
-        h = L.linear(f, P[tb + ".ff.net_2.kernel"], P[tb + ".ff.net_2.bias"], residual=h)
+        a1r = None if rec is None else {}
+        a2r = None if rec is None else {}
+        l1 = ln("norm1", h0)
+        a1 = self._attention(tb + ".attn1", l1, B, N, C, heads, None, 0, a1r)
+        h1 = L.linear(a1, P[tb + ".attn1.to_out_0.kernel"], P[tb + ".attn1.to_out_0.bias"], residual=h0)
+        l2 = ln("norm2", h1)
+        a2 = self._attention(tb + ".attn2", l2, B, N, C, heads, ctx, ctx_len, a2r)
+        h2 = L.linear(a2, P[tb + ".attn2.to_out_0.kernel"], P[tb + ".attn2.to_out_0.bias"], residual=h1)
+        l3 = ln("norm3", h2)
+        f = L.linear(l3, P[tb + ".ff.net_0.proj.kernel"], P[tb + ".ff.net_0.proj.bias"])
+        gg = L.geglu(f)
+        h3 = L.linear(gg, P[tb + ".ff.net_2.kernel"], P[tb + ".ff.net_2.bias"], residual=h2)
         if cfg.use_linear_projection:
-            out = L.linear(h, P[name + ".proj_out.kernel"], P[name + ".proj_out.bias"], residual=x.t)
+            out = L.linear(h3, P[name + ".proj_out.kernel"], P[name + ".proj_out.bias"], residual=x.t)
         else:
-            out, _, _ = L.conv2d(h, P[name + ".proj_out.kernel"], P[name + ".proj_out.bias"], B, x.H, x.W, C, C, 1, residual=x.t)
+            out, _, _ = L.conv2d(h3, P[name + ".proj_out.kernel"], P[name + ".proj_out.bias"], B, x.H, x.W, C, C, 1, residual=x.t)
+        if rec is not None:
+            rec.update(st=st, hn=hn, h0=h0, l1=l1, a1r=a1r, h1=h1, l2=l2, a2r=a2r, h2=h2, l3=l3, f=f, gg=gg, h3=h3)
+            tape.append(("transformer", rec))
         return Act(out, B, x.H, x.W, C)
 
+    def _transformer_backward(self, r, d_out):
+        P, G, cfg = self.params, self.grads, self.cfg
+        name, x, heads = r["name"], r["x"], r["heads"]
+        C, B, N, H, W = x.C, x.B, x.HW, x.H, x.W
+        tb = name + ".transformer_blocks_0"
+        gw = lambda n: G[n + ".kernel"]
+        # out = proj_out(h3) + x
+        L.colsum_accum(d_out, G[name + ".proj_out.bias"])
+        if cfg.use_linear_projection:
+            L.linear_wgrad(r["h3"], d_out, gw(name + ".proj_out"))
+            d_h3 = L.linear_dgrad(d_out, P[name + ".proj_out.kernel"])
+        else:
+            L.conv2d_wgrad(r["h3"], d_out, gw(name + ".proj_out"), B, H, W, C, C, 1)
+            d_h3 = L.conv2d_dgrad(d_out, P[name + ".proj_out.kernel"], B, H, W, C, C, 1)
+        # h3 = ff2(geglu(ff1(LN3(h2)))) + h2
+        L.linear_wgrad(r["gg"], d_h3, gw(tb + ".ff.net_2"))
+        L.colsum_accum(d_h3, G[tb + ".ff.net_2.bias"])
+        d_gg = L.linear_dgrad(d_h3, P[tb + ".ff.net_2.kernel"])
+        d_f = L.geglu_bwd(r["f"], d_gg)
+        L.linear_wgrad(r["l3"], d_f, gw(tb + ".ff.net_0.proj"))
+        L.colsum_accum(d_f, G[tb + ".ff.net_0.proj.bias"])
+        d_l3 = L.linear_dgrad(d_f, P[tb + ".ff.net_0.proj.kernel"])
+        d_h2 = L.layernorm_bwd(r["h2"], d_l3, P[tb + ".norm3.scale"], G[tb + ".norm3.scale"], G[tb + ".norm3.bias"], 1e-5, dx_add=d_h3)
+        # h2 = to_out(attn2(LN2(h1), ctx)) + h1
+        L.linear_wgrad(r["a2r"]["o"], d_h2, gw(tb + ".attn2.to_out_0"))
+        L.colsum_accum(d_h2, G[tb + ".attn2.to_out_0.bias"])
+        d_a2 = L.linear_dgrad(d_h2, P[tb + ".attn2.to_out_0.kernel"])
+        d_l2 = self._attention_backward(tb + ".attn2", r["a2r"], r["l2"], r["ctx"], d_a2, B, N, C, heads, False)
+        d_h1 = L.layernorm_bwd(r["h1"], d_l2, P[tb + ".norm2.scale"], G[tb + ".norm2.scale"], G[tb + ".norm2.bias"], 1e-5, dx_add=d_h2)
+        # h1 = to_out(attn1(LN1(h0))) + h0
+        L.linear_wgrad(r["a1r"]["o"], d_h1, gw(tb + ".attn1.to_out_0"))
+        L.colsum_accum(d_h1, G[tb + ".attn1.to_out_0.bias"])
+        d_a1 = L.linear_dgrad(d_h1, P[tb + ".attn1.to_out_0.kernel"])
+        d_l1 = self._attention_backward(tb + ".attn1", r["a1r"], r["l1"], r["l1"], d_a1, B, N, C, heads, True)
+        d_h0 = L.layernorm_bwd(r["h0"], d_l1, P[tb + ".norm1.scale"], G[tb + ".norm1.scale"], G[tb + ".norm1.bias"], 1e-5, dx_add=d_h1)
+        # h0 = proj_in(GN(x))
+        L.colsum_accum(d_h0, G[name + ".proj_in.bias"])
+        if cfg.use_linear_projection:
+            L.linear_wgrad(r["hn"], d_h0, gw(name + ".proj_in"))
+            d_hn = L.linear_dgrad(d_h0, P[name + ".proj_in.kernel"])
+        else:
+            L.conv2d_wgrad(r["hn"], d_h0, gw(name + ".proj_in"), B, H, W, C, C, 1)
+            d_hn = L.conv2d_dgrad(d_h0, P[name + ".proj_in.kernel"], B, H, W, C, C, 1)
+        return L.groupnorm_bwd(x.t, d_hn, r["st"], P[name + ".norm.scale"], B, N, cfg.norm_groups, False,
+                               G[name + ".norm.scale"], G[name + ".norm.bias"], dx_add=d_out)
+
     # -------------------------------------------------------------------------------- forward
-    def forward(self, sample, timesteps, context):
-        """sample (B,C,H,W) fp32 NCHW; timesteps (B,) int32; context (B,L,D) fp32 -> (B,C_out,H,W)."""
+    def forward(self, sample, timesteps, context, tape=None):
+        """sample (B,C,H,W) fp32 NCHW; timesteps (B,) int32; context (B,L,D) fp32 -> (B,C_out,H,W).
+        With `tape` (a list) every layer records what `backward` needs."""
         P, cfg = self.params, self.cfg
         B, Cin, H, W = sample.shape
         boc = cfg.block_out_channels
@@ -245,29 +365,37 @@ class UNet2DCondition:
         ctx = context.reshape(B * Lc, context.shape[2]).contiguous()
         timesteps = timesteps.to(torch.int32)
 
-        temb = L.timestep_embedding(timesteps, boc[0])
-        temb = L.linear(temb, P["time_embedding.linear_1.kernel"], P["time_embedding.linear_1.bias"])
-        temb = L.linear(L.silu(temb), P["time_embedding.linear_2.kernel"], P["time_embedding.linear_2.bias"])
+        emb = L.timestep_embedding(timesteps, boc[0])
+        t1 = L.linear(emb, P["time_embedding.linear_1.kernel"], P["time_embedding.linear_1.bias"])
+        s1 = L.silu(t1)
+        temb = L.linear(s1, P["time_embedding.linear_2.kernel"], P["time_embedding.linear_2.bias"])
         temb_act = L.silu(temb)          # every ResBlock applies SiLU before its time_emb_proj
 
         x = L.nchw_to_nhwc(sample.contiguous())
         t, _, _ = L.conv2d(x, P["conv_in.kernel"], P["conv_in.bias"], B, H, W, Cin, boc[0], 3)
+        if tape is not None:
+            tape.append(("head", dict(emb=emb, t1=t1, s1=s1, temb=temb, temb_act=temb_act, x=Act(x, B, H, W, Cin))))
         h = Act(t, B, H, W, boc[0])
         skips = [h]
         for i in range(nlev):
             for j in range(cfg.layers_per_block):
-                h = resnet_forward(P, f"down_blocks_{i}.resnets_{j}", h, temb_act, G, 1e-5)
+                h = resnet_forward(P, f"down_blocks_{i}.resnets_{j}", h, temb_act, G, 1e-5, tape)
                 if cfg.cross_attn_down[i]:
-                    h = self._transformer(f"down_blocks_{i}.attentions_{j}", h, ctx, Lc, cfg.num_heads[i])
+                    h = self._transformer(f"down_blocks_{i}.attentions_{j}", h, ctx, Lc, cfg.num_heads[i], tape)
                 skips.append(h)
+                if tape is not None:
+                    tape.append(("skip_push", None))
             if i < nlev - 1:
-                t, OH, OW = L.conv2d(h.t, P[f"down_blocks_{i}.downsamplers_0.conv.kernel"],
-                                     P[f"down_blocks_{i}.downsamplers_0.conv.bias"], B, h.H, h.W, h.C, h.C, 3, stride=2, pad=1)
+                name = f"down_blocks_{i}.downsamplers_0.conv"
+                t, OH, OW = L.conv2d(h.t, P[name + ".kernel"], P[name + ".bias"], B, h.H, h.W, h.C, h.C, 3, stride=2, pad=1)
+                if tape is not None:
+                    tape.append(("down", dict(name=name, x=h)))
+                    tape.append(("skip_push", None))
                 h = Act(t, B, OH, OW, h.C)
                 skips.append(h)
-        h = resnet_forward(P, "mid_block.resnets_0", h, temb_act, G, 1e-5)
-        h = self._transformer("mid_block.attentions_0", h, ctx, Lc, cfg.num_heads[-1])
-        h = resnet_forward(P, "mid_block.resnets_1", h, temb_act, G, 1e-5)
+        h = resnet_forward(P, "mid_block.resnets_0", h, temb_act, G, 1e-5, tape)
+        h = self._transformer("mid_block.attentions_0", h, ctx, Lc, cfg.num_heads[-1], tape)
+        h = resnet_forward(P, "mid_block.resnets_1", h, temb_act, G, 1e-5, tape)
         for i in range(nlev):
             lvl = nlev - 1 - i
             for j in range(cfg.layers_per_block + 1):
@@ -275,15 +403,85 @@ class UNet2DCondition:
                 cat = torch.empty(B * h.HW, h.C + s.C, dtype=torch.float32, device=self.device)
                 L.copy_cols(h.t, cat, 0, B * h.HW, h.C)
                 L.copy_cols(s.t, cat, h.C, B * h.HW, s.C)
-                h = resnet_forward(P, f"up_blocks_{i}.resnets_{j}", Act(cat, B, h.H, h.W, h.C + s.C), temb_act, G, 1e-5)
+                if tape is not None:
+                    tape.append(("concat", dict(c0=h.C, c1=s.C)))
+                h = resnet_forward(P, f"up_blocks_{i}.resnets_{j}", Act(cat, B, h.H, h.W, h.C + s.C), temb_act, G, 1e-5, tape)
                 if cfg.cross_attn_down[lvl]:
-                    h = self._transformer(f"up_blocks_{i}.attentions_{j}", h, ctx, Lc, cfg.num_heads[lvl])
+                    h = self._transformer(f"up_blocks_{i}.attentions_{j}", h, ctx, Lc, cfg.num_heads[lvl], tape)
             if i < nlev - 1:
-                t, OH, OW = L.conv2d(h.t, P[f"up_blocks_{i}.upsamplers_0.conv.kernel"], P[f"up_blocks_{i}.upsamplers_0.conv.bias"],
-                                     B, h.H, h.W, h.C, h.C, 3, upsample=True)
+                name = f"up_blocks_{i}.upsamplers_0.conv"
+                t, OH, OW = L.conv2d(h.t, P[name + ".kernel"], P[name + ".bias"], B, h.H, h.W, h.C, h.C, 3, upsample=True)
+                if tape is not None:
+                    tape.append(("up", dict(name=name, x=h)))
                 h = Act(t, B, OH, OW, h.C)
-        t = L.groupnorm(h.t, B, h.HW, P["conv_norm_out.scale"], P["conv_norm_out.bias"], G, 1e-5, True)
-        t, _, _ = L.conv2d(t, P["conv_out.kernel"], P["conv_out.bias"], B, h.H, h.W, h.C, cfg.out_channels, 3)
+        hn, st = L.groupnorm(h.t, B, h.HW, P["conv_norm_out.scale"], P["conv_norm_out.bias"], G, 1e-5, True, return_stats=True)
+        t, _, _ = L.conv2d(hn, P["conv_out.kernel"], P["conv_out.bias"], B, h.H, h.W, h.C, cfg.out_channels, 3)
+        if tape is not None:
+            tape.append(("tail", dict(x=h, hn=hn, st=st)))
         return L.nhwc_to_nchw(t, B, cfg.out_channels, h.H, h.W)
 
     __call__ = forward
+
+    # -------------------------------------------------------------------------------- backward
+    def backward(self, tape, d_out):
+        """Accumulates d loss / d params into self.grads given d loss / d output (B,C_out,H,W) and the tape of `forward`.
+        (The latents and the text context are not differentiated: DDPO only needs parameter gradients.)"""
+        P, cfg = self.params, self.cfg
+        G = self.ensure_grads()
+        kind, head = tape[0]
+        assert kind == "head"
+        tctx = dict(temb_act=head["temb_act"], d_temb_act=None)
+        kind, tail = tape[-1]
+        assert kind == "tail"
+        x = tail["x"]
+        B, H, W = x.B, x.H, x.W
+        d = L.nchw_to_nhwc(d_out.contiguous())                                 # (B*H*W, C_out)
+        L.conv2d_wgrad(tail["hn"], d, G["conv_out.kernel"], B, H, W, x.C, cfg.out_channels, 3)
+        L.colsum_accum(d, G["conv_out.bias"])
+        d = L.conv2d_dgrad(d, P["conv_out.kernel"], B, H, W, x.C, cfg.out_channels, 3)
+        d = L.groupnorm_bwd(x.t, d, tail["st"], P["conv_norm_out.scale"], B, x.HW, cfg.norm_groups, True,
+                            G["conv_norm_out.scale"], G["conv_norm_out.bias"])
+        skip_grads = []          # filled by the (reversed) up path: ends up in forward production order, consumed from the end
+        for kind, r in reversed(tape[1:-1]):
+            if kind == "resnet":
+                d = resnet_backward(P, G, r, d, tctx)
+            elif kind == "transformer":
+                d = self._transformer_backward(r, d)
+            elif kind == "concat":
+                rows = d.shape[0]
+                d_h = torch.empty(rows, r["c0"], dtype=torch.float32, device=self.device)
+                d_s = torch.empty(rows, r["c1"], dtype=torch.float32, device=self.device)
+                L.copy_cols(d, d_h, 0, rows, r["c0"], ld_src=r["c0"] + r["c1"])
+                L.copy_cols(d[:, r["c0"]:], d_s, 0, rows, r["c1"], ld_src=r["c0"] + r["c1"])
+                skip_grads.append(d_s)
+                d = d_h
+            elif kind == "up":
+                xx, name = r["x"], r["name"]
+                L.conv2d_wgrad(xx.t, d, G[name + ".kernel"], xx.B, xx.H, xx.W, xx.C, xx.C, 3, upsample=True)
+                L.colsum_accum(d, G[name + ".bias"])
+                d_up = L.conv2d_dgrad(d, P[name + ".kernel"], xx.B, 2 * xx.H, 2 * xx.W, xx.C, xx.C, 3)
+                d = L.sumpool2x2(d_up, xx.B, xx.H, xx.W, xx.C)
+            elif kind == "down":
+                xx, name = r["x"], r["name"]
+                L.conv2d_wgrad(xx.t, d, G[name + ".kernel"], xx.B, xx.H, xx.W, xx.C, xx.C, 3, stride=2, pad=1)
+                L.colsum_accum(d, G[name + ".bias"])
+                d = L.conv2d_dgrad(d, P[name + ".kernel"], xx.B, xx.H, xx.W, xx.C, xx.C, 3, stride=2)
+            elif kind == "skip_push":
+                # the activation produced just before this marker was also a skip connection: add its up-path grad.
+                d = L.add(d, skip_grads.pop())
+            else:
+                raise RuntimeError(kind)
+        # conv_in output was the first skip
+        d = L.add(d, skip_grads.pop())
+        assert not skip_grads
+        xin = head["x"]
+        L.conv2d_wgrad(xin.t, d, G["conv_in.kernel"], xin.B, xin.H, xin.W, xin.C, cfg.block_out_channels[0], 3)
+        L.colsum_accum(d, G["conv_in.bias"])
+        # time embedding MLP
+        d_temb = L.silu_bwd(head["temb"], tctx["d_temb_act"])
+        L.linear_wgrad(head["s1"], d_temb, G["time_embedding.linear_2.kernel"])
+        L.colsum_accum(d_temb, G["time_embedding.linear_2.bias"])
+        d_s1 = L.linear_dgrad(d_temb, P["time_embedding.linear_2.kernel"])
+        d_t1 = L.silu_bwd(head["t1"], d_s1)
+        L.linear_wgrad(head["emb"], d_t1, G["time_embedding.linear_1.kernel"])
+        L.colsum_accum(d_t1, G["time_embedding.linear_1.bias"])

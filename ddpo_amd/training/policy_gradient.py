@@ -1,0 +1,115 @@
+"""PPO-clip policy-gradient step on stored DDIM log-probs + gradient-accumulating train state.
+
+Host-side mirror of /root/reference/ddpo/training/policy_gradient.py:
+  AccumulatingTrainState :13-57, ADV_CLIP_MAX :60, train_step :63-146
+and of the optimizer the entrypoint builds (/root/reference/pipeline/policy_gradient.py:130-150):
+  optax.chain(clip_by_global_norm(max_grad_norm), adamw(lr, b1, b2, eps, weight_decay, mu_dtype=bf16)).
+
+MI355X design notes
+  * cond and uncond U-Net passes of `train_cfg` are run as ONE batch-2b pass ([uncond; cond] contexts, the same
+    latents twice) — identical arithmetic per sample, half the launches, twice the rows per GEMM.
+  * gradients are accumulated in place in one flat fp32 buffer by the wgrad kernels (grad_acc += g is free);
+    `lax.pmean(grad)` of the reference (:141, every micro-step) becomes ONE RCCL all-reduce of that buffer per
+    optimizer update — mean-over-ranks and sum-over-steps commute.
+  * the update itself is one fused kernel: 1/(n_acc+1) scaling, global-norm clip, AdamW with bf16 first moment.
+"""
+import numpy as np
+import torch
+
+from .. import lib as L
+
+ADV_CLIP_MAX = 10.0
+
+
+class AdamWConfig:
+    """Hyper-parameters of pipeline/policy_gradient.py:130-150 (defaults = config/base.py `pg`)."""
+
+    def __init__(self, learning_rate=1e-5, b1=0.9, b2=0.999, eps=1e-8, weight_decay=1e-4, max_grad_norm=1.0,
+                 mu_decay_in_bf16=True):
+        self.learning_rate, self.b1, self.b2, self.eps = learning_rate, b1, b2, eps
+        self.weight_decay, self.max_grad_norm = weight_decay, max_grad_norm
+        self.mu_decay_in_bf16 = mu_decay_in_bf16
+
+
+class AccumulatingTrainState:
+    """TrainState that accumulates gradients over several steps before applying them (reference :13-57).
+
+    fields: step, params (the U-Net's flat ParamStore), opt_state {count, mu (bf16), nu (fp32)}, grad_acc (flat), n_acc.
+    """
+
+    def __init__(self, unet, tx: AdamWConfig, process_group=None):
+        self.unet = unet
+        self.apply_fn = unet.forward
+        self.params = unet.params
+        self.tx = tx
+        self.step = 0
+        self.n_acc = 0
+        self.grad_acc = unet.ensure_grads()
+        n = self.params.flat.numel()
+        dev = self.params.flat.device
+        self.opt_state = {"count": 0, "mu": torch.zeros(n, dtype=torch.bfloat16, device=dev),
+                          "nu": torch.zeros(n, dtype=torch.float32, device=dev)}
+        self._sqnorm = torch.zeros(1, dtype=torch.float64, device=dev)
+        self.process_group = process_group
+        self.last_grad_norm = None
+
+    @classmethod
+    def create(cls, *, unet, tx, **kw):
+        return cls(unet, tx, **kw)
+
+    def apply_gradients(self, *, grads=None, do_update):
+        """`grads` were already accumulated into grad_acc by the backward kernels (grads is accepted for signature
+        parity and must be None or grad_acc itself)."""
+        assert grads is None or grads is self.grad_acc
+        if not do_update:
+            self.n_acc += 1
+            return self
+        g = self.grad_acc.flat
+        world = 1
+        if self.process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            world = torch.distributed.get_world_size(self.process_group)
+            if world > 1:
+                # lax.pmean(grad, "batch"): one all-reduce(sum) of the flat buffer, the mean is folded into inv_n below
+                torch.distributed.all_reduce(g, op=torch.distributed.ReduceOp.SUM, group=self.process_group)
+        inv = 1.0 / ((self.n_acc + 1) * world)
+        L.grad_sqnorm(g, self._sqnorm)
+        t = self.opt_state["count"] + 1
+        tx = self.tx
+        L.adamw_bf16mu_step(self.params.flat, g, self.opt_state["mu"], self.opt_state["nu"], self._sqnorm, inv,
+                            tx.learning_rate, tx.b1, tx.b2, tx.eps, tx.weight_decay, tx.max_grad_norm, t,
+                            mu_decay_in_bf16=tx.mu_decay_in_bf16, zero_grad=True)
+        self.last_grad_norm = torch.sqrt(self._sqnorm.clone()) * inv       # device scalar, no host sync
+        self.opt_state["count"] = t
+        self.step += 1
+        self.n_acc = 0
+        return self
+
+
+def train_step(state: AccumulatingTrainState, batch, noise_scheduler_state, noise_scheduler, train_cfg, guidance_scale,
+               eta, clip_range, do_opt_update):
+    """One PPO micro-step (reference :63-146).  batch: latents, next_latents (b,4,h,w), ts (b,) int32, log_probs,
+    advantages (b,), prompt_embeds, uncond_embeds (b,77,D) — device tensors.  Returns (state, info) with info a dict
+    of device scalars {approx_kl, clipfrac, loss}."""
+    assert isinstance(state, AccumulatingTrainState)
+    lat = batch["latents"]
+    b = lat.shape[0]
+    assert b == batch["ts"].shape[0] == batch["next_latents"].shape[0] == batch["log_probs"].shape[0]
+    unet = state.unet
+    ts = batch["ts"].to(torch.int32)
+    tape = []
+    if train_cfg:
+        lat2 = torch.cat([lat, lat])
+        ctx2 = torch.cat([batch["uncond_embeds"], batch["prompt_embeds"]])
+        out = unet.forward(lat2, torch.cat([ts, ts]), ctx2, tape=tape)
+        eps_u, eps_c = out[:b], out[b:]
+    else:
+        out = unet.forward(lat, ts, batch["prompt_embeds"], tape=tape)
+        eps_u, eps_c = None, out
+    consts = noise_scheduler.kernel_consts(noise_scheduler_state, eta)
+    d_c, d_u, per_sample, info = L.ddim_logprob_ppo_fwd_bwd(eps_c, eps_u, lat.contiguous(), batch["next_latents"].contiguous(), ts,
+                                                            batch["log_probs"].contiguous(), batch["advantages"].contiguous(),
+                                                            guidance_scale, clip_range, train_cfg, consts)
+    d_out = torch.cat([d_u, d_c]) if train_cfg else d_c
+    unet.backward(tape, d_out)
+    state = state.apply_gradients(do_update=do_opt_update)
+    return state, {"approx_kl": info[0], "clipfrac": info[1], "loss": info[2], "log_prob": per_sample[:, 0]}

@@ -85,19 +85,31 @@ int ddpo_adamw_bf16mu_step(float* p, float* g, uint16_t* mu, float* nu, int64_t 
  *      pipeline/policy_gradient.py:174-182) --------------------------------------------------------- */
 
 /* GroupNorm(+SiLU) over NHWC x:(B,HW,C) with row stride ldx/ldy (floats).
- * ws: 16-byte aligned scratch of ddpo_groupnorm_ws_bytes(B,HW,C,G) bytes (per-chunk group sums + per-(b,c)
- * affine).  Reductions run in a fixed order: results are bit-reproducible. */
+ * ws: 16-byte aligned scratch of ddpo_groupnorm_ws_bytes(B,HW,C,G) bytes (per-chunk group sums).
+ * stats: 16-byte aligned OUTPUT of ddpo_groupnorm_stats_floats(B,C,G) floats = per-(b,c) affine {rstd*gamma,
+ * beta-mean*rstd*gamma} followed by per-(b,g) {mean, rstd}; the backward pass reads it.
+ * Reductions run in a fixed order: results are bit-reproducible. */
 size_t ddpo_groupnorm_ws_bytes(int B, int HW, int C, int G);
+size_t ddpo_groupnorm_stats_floats(int B, int C, int G);
 int ddpo_groupnorm_fwd(const float* x, int ldx, float* y, int ldy, const float* gamma, const float* beta,
-                       int B, int HW, int C, int G, float eps, int fuse_silu, void* ws, void* stream);
+                       int B, int HW, int C, int G, float eps, int fuse_silu, void* ws, float* stats, void* stream);
+/* Backward of y = act(GroupNorm(x)): dx (+= dx_add if given), dgamma/dbeta accumulated atomically (they live in the
+ * flat gradient buffer).  ws: ddpo_groupnorm_bwd_ws_bytes(B,HW,C,G) bytes. */
+size_t ddpo_groupnorm_bwd_ws_bytes(int B, int HW, int C, int G);
+int ddpo_groupnorm_bwd(const float* x, int ldx, const float* dy, int lddy, const float* stats, const float* gamma,
+                       int B, int HW, int C, int G, int fuse_silu, const float* dx_add, int ld_add, float* dx, int lddx,
+                       float* dgamma, float* dbeta, void* ws, void* stream);
 /* LayerNorm over the last dim: x,y:(rows,C) contiguous. */
 int ddpo_layernorm_fwd(const float* x, float* y, const float* gamma, const float* beta, int rows, int C,
                        float eps, void* stream);
+/* dx = LayerNorm backward (+ dx_add if given; statistics recomputed from x); dgamma/dbeta accumulated atomically. */
+int ddpo_layernorm_bwd(const float* x, const float* dy, const float* gamma, int rows, int C, float eps,
+                       const float* dx_add, float* dx, float* dgamma, float* dbeta, void* stream);
 
 /* Implicit-GEMM convolution / dense GEMM on the exact-fp32 MFMA datapath (v_mfma_f32_32x32x2_f32).
  *   out[m][n] = alpha * sum_k A(m,k) * W[k][n] (+ bias[n]) (+ rowbias[m / rows_per_batch][n]) (+ residual[m][n])
  * conv mode: m = (b, oy, ox), k = (ky, kx, ci); src is NHWC with pixel stride ld_src; optional nearest-2x
- * upsampling of the source folded into the gather (FlaxUpsample2D), stride 1|2, pad 0|1, ksize 1|3.
+ * upsampling (upsample=1) of the source folded into the gather (FlaxUpsample2D), stride 1|2, pad 0|1, ksize 1|3.
  * dense mode (ksize==0): A = src (M,K) with row stride ld_src.
  * W is (K, N) row-major (Flax HWIO / (in,out) layout) unless w_trans, then (N, K). */
 typedef struct {
@@ -113,14 +125,32 @@ typedef struct {
   int ksize, stride, pad, upsample;
   int B, H, W, Cin;               /* source dims (before upsample) */
   int OH, OW;
+  /* backward-only fields (zero for the forward pass) */
+  int w_dgrad;                    /* with w_trans: w is the FORWARD HWIO kernel (taps, N, Cin); taps are flipped -> data gradient */
+  int ld_w;                       /* wgrad: row stride of dY (the `w` operand) */
+  int splits;                     /* wgrad: split of the reduction over M (0 = auto) */
+  int accumulate;                 /* wgrad: atomically add into out instead of storing */
 } ddpo_gemm_desc;
 int ddpo_gemm_conv_fwd(const ddpo_gemm_desc* d, void* stream);
+/* Data gradients reuse ddpo_gemm_conv_fwd: src = dY, w = forward kernel with w_trans=1, w_dgrad=1, and for the
+ * gradient of a stride-2 convolution upsample=2 ("zero-insert" source: only even virtual coordinates exist).
+ * Weight gradient (jax.grad w.r.t. conv / dense kernels, ddpo/training/policy_gradient.py:138-139):
+ *   out[k][n] (+)= alpha * sum_m A(m,k) * dY[m][n],  A as in the forward pass (src = forward input),
+ *   w = dY (M,N) with row stride ld_w, out = dW (K,N) with row stride ld_out.  With splits != 1 the partial sums
+ *   are combined with fp32 atomic adds (out must hold zeros or the running gradient accumulation). */
+int ddpo_gemm_conv_wgrad(const ddpo_gemm_desc* d, void* stream);
 
 /* Fused multi-head attention, softmax(q k^T * scale) v, flash-style on fp32 MFMA (16x16x4).
- * q:(B,Nq,·) k,v:(B,Nk,·) o:(B,Nq,·): head h occupies columns [h*d,(h+1)*d) of each row; ld* = row strides. */
+ * q:(B,Nq,·) k,v:(B,Nk,·) o:(B,Nq,·): head h occupies columns [h*d,(h+1)*d) of each row; ld* = row strides.
+ * lse (optional, (B,heads,Nq)): log2-domain logsumexp of the scaled scores, consumed by the backward pass. */
 int ddpo_attention_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
-                       float* o, int ldo, int B, int heads, int Nq, int Nk, int d, float scale,
+                       float* o, int ldo, float* lse, int B, int heads, int Nq, int Nk, int d, float scale,
                        void* stream);
+/* Attention backward with probability recomputation (no N x N tensor is ever materialised):
+ * dvec (B,heads,Nq) scratch = rowsum(dO * O); dq/dk/dv have the layout of q/k/v with contiguous rows of heads*d. */
+int ddpo_attention_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o,
+                       const float* d_o, const float* lse, float* dvec, float* dq, float* dk, float* dv,
+                       int B, int heads, int Nq, int Nk, int d, float scale, void* stream);
 
 /* Small element-wise pieces. */
 int ddpo_geglu_fwd(const float* x, float* y, int64_t rows, int F, void* stream);      /* y = x[:, :F] * gelu_tanh(x[:, F:]) */
@@ -130,6 +160,14 @@ int ddpo_nchw_to_nhwc(const float* x, float* y, int B, int C, int HW, void* stre
 int ddpo_nhwc_to_nchw(const float* x, float* y, int B, int C, int HW, void* stream);
 int ddpo_copy_cols(const float* src, int ld_src, float* dst, int ld_dst, int64_t rows, int cols, void* stream);
 int ddpo_softmax_rows(float* x, int64_t rows, int cols, float scale, void* stream);    /* in place */
+/* backward element-wise pieces */
+int ddpo_geglu_bwd(const float* x, const float* dy, float* dx, int64_t rows, int F, void* stream);
+int ddpo_silu_bwd(const float* x, const float* dy, float* dx, int64_t n, void* stream);
+/* out[seg][n] += sum over the rows of segment seg (rows_per_seg consecutive rows; 0 = one segment) of x[m][n] */
+int ddpo_colsum_accum(const float* x, int ldx, int64_t rows, int cols, int rows_per_seg, float* out, void* stream);
+/* nearest-2x upsampling backward: y[b,h,w,:] = sum of the 2x2 block of x:(B,2H,2W,C) */
+int ddpo_sumpool2x2(const float* x, float* y, int B, int H, int W, int C, void* stream);
+int ddpo_add(const float* a, const float* b, float* out, int64_t n, void* stream);
 int ddpo_scale_shift_clip(const float* x, float* y, int64_t n, float scale, float shift, float lo, float hi, void* stream);
 
 #ifdef __cplusplus

@@ -1,0 +1,244 @@
+"""GPU parity tests of the backward / training half of the hot path against torch-CPU float64 autograd and the oracle."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as TF
+
+pytestmark = pytest.mark.gpu
+
+from ddpo_amd import lib as L
+
+DEV = "cuda"
+
+
+def _rel(a, b):
+    a = np.asarray(a.detach().cpu() if torch.is_tensor(a) else a, dtype=np.float64)
+    b = np.asarray(b.detach().cpu() if torch.is_tensor(b) else b, dtype=np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+# ------------------------------------------------------------------------------------------------ GEMM / conv grads
+@pytest.mark.parametrize("M,K,N", [(64, 32, 64), (300, 320, 640), (4, 1280, 320), (4096, 64, 128), (2048, 640, 5120)])
+def test_linear_grads(M, K, N):
+    g = torch.Generator().manual_seed(M + K)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(K, N, generator=g) / math.sqrt(K)
+    dy = torch.randn(M, N, generator=g)
+    dx = L.linear_dgrad(dy.to(DEV), w.to(DEV))
+    assert _rel(dx, dy.double() @ w.double().t()) < 2e-6 * math.sqrt(N) + 1e-6
+    dw = torch.zeros(K, N, device=DEV)
+    L.linear_wgrad(x.to(DEV), dy.to(DEV), dw)
+    ref = x.double().t() @ dy.double()
+    assert _rel(dw, ref) < 2e-6 * math.sqrt(M) + 1e-6
+    L.linear_wgrad(x.to(DEV), dy.to(DEV), dw)            # accumulates in place
+    assert _rel(dw, 2 * ref) < 2e-6 * math.sqrt(M) + 1e-6
+    res = torch.randn(M, K, generator=g)
+    dx2 = L.linear_dgrad(dy.to(DEV), w.to(DEV), residual=res.to(DEV))
+    assert _rel(dx2, dy.double() @ w.double().t() + res.double()) < 2e-6 * math.sqrt(N) + 1e-6
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,ks,stride,ups", [
+    (2, 8, 8, 32, 64, 3, 1, False), (2, 8, 8, 96, 32, 3, 1, False), (2, 8, 8, 64, 64, 3, 2, False), (2, 4, 4, 64, 64, 3, 1, True),
+    (2, 8, 8, 64, 128, 1, 1, False), (2, 8, 8, 32, 4, 3, 1, False), (2, 8, 8, 4, 32, 3, 1, False), (1, 32, 32, 320, 320, 3, 1, False),
+    (2, 16, 16, 640, 640, 3, 2, False), (1, 8, 8, 1280, 1280, 3, 1, True), (3, 6, 10, 32, 64, 3, 1, False)])
+def test_conv_grads(B, H, W, Cin, Cout, ks, stride, ups):
+    g = torch.Generator().manual_seed(H + Cin + Cout + ks)
+    x = torch.randn(B, H, W, Cin, generator=g)
+    w = torch.randn(ks, ks, Cin, Cout, generator=g) / math.sqrt(ks * ks * Cin)
+    xd = x.permute(0, 3, 1, 2).double().requires_grad_(True)
+    wd = w.permute(3, 2, 0, 1).double().requires_grad_(True)
+    xin = TF.interpolate(xd, scale_factor=2, mode="nearest") if ups else xd
+    y = TF.conv2d(xin, wd, None, stride=stride, padding=ks // 2)
+    OH, OW = y.shape[2], y.shape[3]
+    dy = torch.randn(B, OH, OW, Cout, generator=g)
+    y.backward(dy.permute(0, 3, 1, 2).double())
+    dw_ref = wd.grad.permute(2, 3, 1, 0)                    # OIHW -> HWIO
+    dx_ref = xd.grad.permute(0, 2, 3, 1).reshape(B * H * W, Cin)
+    dyf = dy.reshape(B * OH * OW, Cout).to(DEV)
+    dw = torch.zeros(ks, ks, Cin, Cout, device=DEV)
+    L.conv2d_wgrad(x.reshape(-1, Cin).to(DEV), dyf, dw, B, H, W, Cin, Cout, ks, stride=stride, upsample=ups)
+    assert _rel(dw, dw_ref) < 2e-6 * math.sqrt(B * OH * OW) + 1e-6
+    if Cin > 4:        # (the latents feeding conv_in are never differentiated)
+        if ups:
+            d_up = L.conv2d_dgrad(dyf, w.to(DEV), B, 2 * H, 2 * W, Cin, Cout, ks)
+            dx = L.sumpool2x2(d_up, B, H, W, Cin)
+        else:
+            dx = L.conv2d_dgrad(dyf, w.to(DEV), B, H, W, Cin, Cout, ks, stride=stride)
+        assert _rel(dx, dx_ref) < 2e-6 * math.sqrt(ks * ks * Cout) + 1e-6
+
+
+# ------------------------------------------------------------------------------------------------ norms / elementwise
+@pytest.mark.parametrize("B,HW,C", [(2, 64, 32), (2, 64, 96), (2, 256, 320), (2, 64, 1280), (1, 64, 2560), (2, 1024, 128)])
+@pytest.mark.parametrize("silu", [True, False])
+def test_groupnorm_bwd(B, HW, C, silu):
+    g = torch.Generator().manual_seed(C + HW)
+    x = torch.randn(B * HW, C, generator=g) * 2 + 0.3
+    gamma, beta = 1 + 0.3 * torch.randn(C, generator=g), 0.2 * torch.randn(C, generator=g)
+    dy = torch.randn(B * HW, C, generator=g)
+    add = torch.randn(B * HW, C, generator=g)
+    xd = x.double().requires_grad_(True)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    y = TF.group_norm(xd.view(B, HW, C).permute(0, 2, 1), 32, gd, bd, 1e-5)
+    if silu:
+        y = TF.silu(y)
+    y.backward(dy.view(B, HW, C).permute(0, 2, 1).double())
+    yk, stats = L.groupnorm(x.to(DEV), B, HW, gamma.to(DEV), beta.to(DEV), 32, 1e-5, silu, return_stats=True)
+    assert _rel(yk, y.detach().permute(0, 2, 1).reshape(B * HW, C)) < 2e-5
+    dgam, dbet = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    dx = L.groupnorm_bwd(x.to(DEV), dy.to(DEV), stats, gamma.to(DEV), B, HW, 32, silu, dgam, dbet, dx_add=add.to(DEV))
+    assert _rel(dx, xd.grad + add.double()) < 5e-5
+    assert _rel(dgam, gd.grad) < 5e-5 and _rel(dbet, bd.grad) < 5e-5
+
+
+@pytest.mark.parametrize("rows,C", [(64, 32), (77, 64), (300, 320), (100, 640), (64, 1280)])
+def test_layernorm_bwd(rows, C):
+    g = torch.Generator().manual_seed(rows + C)
+    x = torch.randn(rows, C, generator=g) * 2 + 1
+    gamma = 1 + 0.3 * torch.randn(C, generator=g)
+    dy = torch.randn(rows, C, generator=g)
+    add = torch.randn(rows, C, generator=g)
+    xd, gd, bd = x.double().requires_grad_(True), gamma.double().requires_grad_(True), torch.zeros(C, dtype=torch.float64, requires_grad=True)
+    TF.layer_norm(xd, (C,), gd, bd, 1e-5).backward(dy.double())
+    dgam, dbet = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    dx = L.layernorm_bwd(x.to(DEV), dy.to(DEV), gamma.to(DEV), dgam, dbet, 1e-5, dx_add=add.to(DEV))
+    assert _rel(dx, xd.grad + add.double()) < 2e-5
+    assert _rel(dgam, gd.grad) < 2e-5 and _rel(dbet, bd.grad) < 2e-5
+
+
+def test_elementwise_bwd():
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(70, 2 * 128, generator=g) * 2
+    dy = torch.randn(70, 128, generator=g)
+    xd = x.double().requires_grad_(True)
+    (xd[:, :128] * TF.gelu(xd[:, 128:], approximate="tanh")).backward(dy.double())
+    assert _rel(L.geglu_bwd(x.to(DEV), dy.to(DEV)), xd.grad) < 1e-5
+    xs = torch.randn(1000, generator=g) * 3
+    ds = torch.randn(1000, generator=g)
+    xsd = xs.double().requires_grad_(True)
+    TF.silu(xsd).backward(ds.double())
+    assert _rel(L.silu_bwd(xs.to(DEV), ds.to(DEV)), xsd.grad) < 1e-5
+    m = torch.randn(3 * 500, 96, generator=g)
+    out = torch.zeros(96, device=DEV)
+    L.colsum_accum(m.to(DEV), out)
+    assert _rel(out, m.double().sum(0)) < 1e-5
+    out3 = torch.zeros(3, 96, device=DEV)
+    L.colsum_accum(m.to(DEV), out3, rows_per_seg=500)
+    assert _rel(out3, m.double().view(3, 500, 96).sum(1)) < 1e-5
+    a, b = torch.randn(999, generator=g), torch.randn(999, generator=g)
+    assert torch.equal(L.add(a.to(DEV), b.to(DEV)).cpu(), a + b)
+    u = torch.randn(2, 6, 8, 16, generator=g)       # (B, 2H, 2W, C)
+    sp = L.sumpool2x2(u.reshape(-1, 16).to(DEV), 2, 3, 4, 16).cpu().view(2, 3, 4, 16)
+    ref = u.view(2, 3, 2, 4, 2, 16).sum((2, 4))
+    assert torch.allclose(sp, ref, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------ attention
+@pytest.mark.parametrize("B,heads,Nq,Nk,d", [(2, 8, 64, 64, 4), (2, 8, 64, 77, 8), (1, 8, 256, 256, 16), (2, 8, 256, 256, 40),
+                                             (2, 8, 1024, 77, 40), (1, 8, 256, 256, 80), (2, 8, 64, 64, 160), (2, 8, 64, 77, 160),
+                                             (1, 5, 100, 150, 64), (1, 8, 1024, 1024, 40)])
+def test_attention_bwd(B, heads, Nq, Nk, d):
+    g = torch.Generator().manual_seed(Nq + Nk + d)
+    C = heads * d
+    q, k, v = torch.randn(B * Nq, C, generator=g), torch.randn(B * Nk, C, generator=g), torch.randn(B * Nk, C, generator=g)
+    do = torch.randn(B * Nq, C, generator=g)
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
+    sp = lambda t, n: t.view(B, n, heads, d).permute(0, 2, 1, 3)
+    s = sp(qd, Nq) @ sp(kd, Nk).transpose(-1, -2) * d ** -0.5
+    o_ref = (torch.softmax(s, -1) @ sp(vd, Nk)).permute(0, 2, 1, 3).reshape(B * Nq, C)
+    o_ref.backward(do.double())
+    o, lse = L.attention(q.to(DEV), k.to(DEV), v.to(DEV), B, heads, Nq, Nk, d, return_lse=True)
+    assert _rel(o, o_ref.detach()) < 1e-5
+    lse_ref = torch.logsumexp(s.detach(), -1) / math.log(2.0)               # (B, heads, Nq), log2 domain
+    assert _rel(lse.view(B, heads, Nq), lse_ref) < 1e-5
+    dq, dk, dv = L.attention_bwd(q.to(DEV), k.to(DEV), v.to(DEV), o, do.to(DEV), lse, B, heads, Nq, Nk, d)
+    assert _rel(dq, qd.grad) < 2e-5 and _rel(dk, kd.grad) < 2e-5 and _rel(dv, vd.grad) < 2e-5
+
+
+# ------------------------------------------------------------------------------------------------ the whole train step
+def _tiny_setup(train_bs, hw, seed=0):
+    from ddpo_amd.models.unet import UNet2DCondition, UNetConfig
+    from ddpo_amd.diffusers_patch.scheduling_ddim import DDIMScheduler
+    from oracle import unet as OU
+    from oracle.ddim import DDIMOracle
+    op = OU.init_params(OU.unet_param_shapes(OU.TINY), seed=seed)
+    unet = UNet2DCondition(UNetConfig.named("tiny"), DEV)
+    unet.params.load_dict(op)
+    sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", set_alpha_to_one=False, steps_offset=1)
+    st = sched.set_timesteps(sched.create_state(device=DEV), 50)
+    dd = DDIMOracle()
+    ost = dd.set_timesteps(dd.create_state(), 50)
+    g = torch.Generator().manual_seed(5)
+    shp = (train_bs, 4, hw, hw)
+    lat = torch.randn(shp, generator=g)
+    ts = torch.tensor([481, 21, 981, 241][:train_bs], dtype=torch.int32)
+    emb = torch.randn(train_bs, 77, 64, generator=g)
+    unc = torch.randn(1, 77, 64, generator=g).expand(train_bs, -1, -1).contiguous()
+    return op, unet, sched, st, dd, ost, lat, ts, emb, unc, g
+
+
+@pytest.mark.parametrize("train_cfg", [True, False])
+def test_train_step_grads_match_oracle(train_cfg):
+    """ddpo/training/policy_gradient.py:63-146 end to end: U-Net fwd (cond+uncond), log-prob, PPO-clip, jax.grad."""
+    from ddpo_amd.training.policy_gradient import AccumulatingTrainState, AdamWConfig, train_step
+    from oracle import unet as OU
+    from oracle.sampler import train_step_grads
+    b, hw = 2, 8
+    op, unet, sched, st, dd, ost, lat, ts, emb, unc, g = _tiny_setup(b, hw)
+    # build next_latents with the oracle forward so ratios are near 1; perturb old log-probs around the clip range
+    with torch.no_grad():
+        ec = OU.unet_forward(op, OU.TINY, lat, ts, emb)
+        eu = OU.unet_forward(op, OU.TINY, lat, ts, unc)
+    guided = (eu + 5.0 * (ec - eu)) if train_cfg else ec
+    nxt, lp0 = dd.step(ost, guided.numpy(), ts.numpy(), lat.numpy(), noise=torch.randn(lat.shape, generator=g).numpy(), eta=1.0)
+    old = torch.from_numpy(lp0) + torch.tensor([2e-5, -6e-5])
+    adv = torch.tensor([1.3, -0.8])
+    batch = {"latents": lat, "next_latents": torch.from_numpy(nxt), "ts": ts, "log_probs": old, "advantages": adv,
+             "prompt_embeds": emb, "uncond_embeds": unc}
+    ograds, oinfo, _ = train_step_grads(op, OU.TINY, dd, ost, {k: (v if k == "ts" else v.double()) for k, v in batch.items()},
+                                        5.0, 1.0, 1e-4, train_cfg, dtype=torch.float64)
+    state = AccumulatingTrainState(unet, AdamWConfig())
+    dbatch = {k: v.to(DEV) for k, v in batch.items()}
+    state, info = train_step(state, dbatch, st, sched, train_cfg, 5.0, 1.0, 1e-4, do_opt_update=False)
+    assert state.n_acc == 1 and state.step == 0
+    assert float(info["loss"]) == pytest.approx(oinfo["loss"], rel=1e-3, abs=1e-6)
+    assert float(info["clipfrac"]) == pytest.approx(oinfo["clipfrac"], abs=1e-6)
+    G = unet.grads
+    gn_o = math.sqrt(sum(float((v.double() ** 2).sum()) for v in ograds.values()))
+    gn = math.sqrt(float((G.flat.double() ** 2).sum()))
+    assert gn == pytest.approx(gn_o, rel=1e-3)                    # north-star tolerance on grad norms
+    worst = max((_rel(G[n], ograds[n]), n) for n in ograds if float(ograds[n].abs().max()) > 1e-6 * gn_o)
+    assert worst[0] < 2e-3, worst
+    # parameters that receive no gradient stay exactly zero in both
+    for n in ograds:
+        if float(ograds[n].abs().max()) == 0.0:
+            assert float(G[n].abs().max()) == 0.0, n
+
+
+def test_accumulate_and_adamw_update_match_oracle():
+    """Two micro-steps (accumulate, then update) against oracle autograd grads + the optax restatement."""
+    from ddpo_amd.training.policy_gradient import AccumulatingTrainState, AdamWConfig, train_step
+    from oracle import unet as OU
+    from oracle.optim import AdamWBf16Mu, AccumulatingState
+    from oracle.sampler import train_step_grads
+    b, hw = 2, 8
+    op, unet, sched, st, dd, ost, lat, ts, emb, unc, g = _tiny_setup(b, hw, seed=2)
+    names = list(op.keys())
+    ostate = AccumulatingState([op[n].numpy() for n in names], AdamWBf16Mu())
+    state = AccumulatingTrainState(unet, AdamWConfig())
+    for micro in range(2):
+        lat_m = torch.randn(lat.shape, generator=g)
+        nxt = lat_m * 0.9 + 0.1 * torch.randn(lat.shape, generator=g)
+        batch = {"latents": lat_m, "next_latents": nxt, "ts": ts, "log_probs": torch.tensor([-1.2, -0.9]),
+                 "advantages": torch.tensor([0.7, -1.1]), "prompt_embeds": emb, "uncond_embeds": unc}
+        ograds, _, _ = train_step_grads(op, OU.TINY, dd, ost, batch, 5.0, 1.0, 10.0, True, dtype=torch.float32)
+        ostate.apply_gradients([ograds[n].numpy() for n in names], do_update=(micro == 1))
+        state, info = train_step(state, {k: v.to(DEV) for k, v in batch.items()}, st, sched, True, 5.0, 1.0, 10.0,
+                                 do_opt_update=(micro == 1))
+    assert state.step == 1 and state.n_acc == 0 and float(unet.grads.flat.abs().max()) == 0.0
+    assert float(state.last_grad_norm) == pytest.approx(float(ostate.last_grad_norm), rel=1e-3)
+    for n, ref in zip(names, ostate.params):
+        upd = np.abs(ref - op[n].numpy()).max()
+        err = np.abs(unet.params[n].cpu().numpy() - ref).max()
+        assert err <= 2e-2 * upd + 1e-9, (n, err, upd)      # compare the applied UPDATE, not the (dominant) old weights
