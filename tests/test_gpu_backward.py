@@ -210,10 +210,11 @@ def test_train_step_grads_match_oracle(train_cfg):
     assert gn == pytest.approx(gn_o, rel=1e-3)                    # north-star tolerance on grad norms
     worst = max((_rel(G[n], ograds[n]), n) for n in ograds if float(ograds[n].abs().max()) > 1e-6 * gn_o)
     assert worst[0] < 2e-3, worst
-    # parameters that receive no gradient stay exactly zero in both
+    # parameters whose exact gradient is zero (e.g. q/k of a softmax over a single key at the 1x1 level) only carry
+    # fp32 round-off here
     for n in ograds:
         if float(ograds[n].abs().max()) == 0.0:
-            assert float(G[n].abs().max()) == 0.0, n
+            assert float(G[n].abs().max()) < 1e-6 * gn_o, n
 
 
 def test_accumulate_and_adamw_update_match_oracle():
@@ -227,18 +228,31 @@ def test_accumulate_and_adamw_update_match_oracle():
     names = list(op.keys())
     ostate = AccumulatingState([op[n].numpy() for n in names], AdamWBf16Mu())
     state = AccumulatingTrainState(unet, AdamWConfig())
+    gsum = {n: 0.0 for n in names}
     for micro in range(2):
         lat_m = torch.randn(lat.shape, generator=g)
         nxt = lat_m * 0.9 + 0.1 * torch.randn(lat.shape, generator=g)
         batch = {"latents": lat_m, "next_latents": nxt, "ts": ts, "log_probs": torch.tensor([-1.2, -0.9]),
                  "advantages": torch.tensor([0.7, -1.1]), "prompt_embeds": emb, "uncond_embeds": unc}
         ograds, _, _ = train_step_grads(op, OU.TINY, dd, ost, batch, 5.0, 1.0, 10.0, True, dtype=torch.float32)
+        for n in names:
+            gsum[n] = gsum[n] + ograds[n].double()
         ostate.apply_gradients([ograds[n].numpy() for n in names], do_update=(micro == 1))
         state, info = train_step(state, {k: v.to(DEV) for k, v in batch.items()}, st, sched, True, 5.0, 1.0, 10.0,
                                  do_opt_update=(micro == 1))
     assert state.step == 1 and state.n_acc == 0 and float(unet.grads.flat.abs().max()) == 0.0
     assert float(state.last_grad_norm) == pytest.approx(float(ostate.last_grad_norm), rel=1e-3)
+    gmax = max(float(v.abs().max()) for v in gsum.values())
+    checked = 0
     for n, ref in zip(names, ostate.params):
-        upd = np.abs(ref - op[n].numpy()).max()
-        err = np.abs(unet.params[n].cpu().numpy() - ref).max()
+        # Adam normalises every gradient to an O(lr) step, so parameters whose true gradient is ~0 (TINY has one-channel
+        # GroupNorm groups that cancel the preceding conv bias exactly) would compare round-off noise: restrict the
+        # element-wise check to entries with a well-resolved gradient.
+        mask = (gsum[n].abs() > 1e-3 * gmax).numpy()
+        if not mask.any():
+            continue
+        checked += 1
+        upd = np.abs(ref - op[n].numpy())[mask].max()
+        err = np.abs(unet.params[n].cpu().numpy() - ref)[mask].max()
         assert err <= 2e-2 * upd + 1e-9, (n, err, upd)      # compare the applied UPDATE, not the (dominant) old weights
+    assert checked > 50
