@@ -1,0 +1,50 @@
+"""Hyper-parameters for `pipeline/policy_gradient.py` — the `pg` experiment of the reference's flag surface.
+
+Same keys, defaults and precedence as /root/reference/config/base.py:61-102 (`base["pg"]`) and its per-dataset
+`common` / `pg` overrides (:106-148, :222-314); the RWR-only `sample` / `train` / `sizes` experiments are out of
+scope for this engine.  Values are declarative data; the tables are assembled by helpers so
+that adding a dataset is one line.
+"""
+from . import user
+
+_PG_DEFAULTS = (
+    # misc
+    ("loadpath", ""), ("load_epoch", "latest"), ("modelpath", "models/pg"), ("savepath", "f:models/pg"),
+    ("pretrained_model", "duongna/stable-diffusion-v1-4-flax"), ("resolution", 512), ("filter_field", None),
+    ("guidance_scale", 5.0), ("dtype", "float32"), ("cache", "cache"), ("verbose", False), ("seed", 0), ("iteration", 0),
+    # sampling (batch sizes are per device)
+    ("sample_batch_size", 8), ("num_sample_batches_per_epoch", 1), ("n_inference_steps", 50), ("identical_batch", False),
+    ("evaluate", False), ("eta", 1.0),
+    # training
+    ("train_batch_size", 2), ("train_accumulation_steps", 1), ("num_train_epochs", 200), ("num_inner_epochs", 1),
+    ("ppo_clip_range", 1e-4), ("train_cfg", True), ("learning_rate", 1e-5), ("beta1", 0.9), ("beta2", 0.999),
+    ("weight_decay", 1e-4), ("epsilon", 1e-8), ("max_grad_norm", 1.0), ("save_freq", 10), ("optimizer", "adamw"),
+    ("train_timestep_ratio", 1.0), ("prompt_kwargs", {}), ("per_prompt_stats_bufsize", 32), ("per_prompt_stats_min_count", 16),
+)
+
+base = {"pg": dict(_PG_DEFAULTS)}
+
+
+def _dataset(logdir, prompt_fn, filter_field, prompt_kwargs=None, **pg):
+    common = {"logbase": f"{user.bucket}/logs/{logdir}", "prompt_fn": prompt_fn, "filter_field": filter_field}
+    if prompt_kwargs is not None:
+        common["prompt_kwargs"] = prompt_kwargs
+    return {"common": common, "pg": pg}
+
+
+_ANIMALS = {"loadpath": "assets/common_animals.txt"}
+_NOUNS_ACTIVITIES = {"nouns_path": "assets/common_animals.txt", "activities_path": "assets/activities_v0.txt"}
+
+compressed_animals = _dataset("identical-compressed-animals-s1024-p90", "imagenet_animals", "jpeg")
+neg_compressed_animals = _dataset("identical-neg-compressed-animals-s1024-p90", "imagenet_animals", "neg_jpeg")
+llava_vqa = _dataset("llava-vqa-v2", "vqa_dataset", "llava_vqa", {"loadpath": "assets/vqa_v2.txt"},
+                     per_prompt_stats_bufsize=128, per_prompt_stats_min_count=32, num_train_epochs=120)
+llava_counting = _dataset("llava-counting-v0-8", "counting", "llava_vqa",
+                          {"nouns_path": "assets/very_simple_animals.txt", "number_range": (2, 8)})
+llava_bertscore = _dataset("llava-bertscore-2-simple-animals", "nouns_activities", "llava_bertscore", _NOUNS_ACTIVITIES)
+a_dog_1 = _dataset("aesthetic_dogs_sweep/one", "manual", "aesthetic", {"prompts": ["a dog"]}, per_prompt_stats_bufsize=None,
+                   per_prompt_stats_min_count=None, train_batch_size=1, train_accumulation_steps=2)
+a_dog_2 = _dataset("aesthetic_dogs_sweep/imagenet", "imagenet_dogs", "aesthetic", {}, train_batch_size=1,
+                   train_accumulation_steps=2)
+a_animals = _dataset("aesthetic_simple_animals", "from_file", "aesthetic", _ANIMALS, train_batch_size=1,
+                     train_accumulation_steps=2)

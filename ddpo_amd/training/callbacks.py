@@ -1,0 +1,161 @@
+"""`filter_field` plugin surface: reward callbacks.
+
+Behavioural mirror of the registry / calling convention of /root/reference/ddpo/training/callbacks.py:
+  callback_fns[name](**factory_kwargs) -> fn(images, prompts, metadata) -> (scores, info)       (:549-564)
+  evaluate_callbacks(fns, images, prompts, metadata) -> {name: (scores, info)}                  (:540-546)
+images: float32 (N,H,W,3) in [0,1]; scores: (N,) or (N,1) numpy; info: dict of numpy arrays.
+Callbacks run in a worker thread of the entrypoint (ThreadPoolExecutor, max_workers=2) next to the sampling of the
+following batch, so they must not touch the sampler's HIP stream: the host ones below are pure CPU code and the
+on-device one (aesthetic) uses its own stream.
+
+In scope (BASELINE.json configs): jpeg, neg_jpeg, aesthetic, llava_bertscore (+ its sibling llava_vqa wire format).
+The other reward ideas of the reference (rotational / mirror symmetry, thumbnail, BLIP-2 vqa, ...) are not part of
+any benchmark config; add them as plugins with `register`.
+"""
+import io
+import pickle
+import random
+
+import numpy as np
+from PIL import Image
+
+
+def register(name):
+    def deco(factory):
+        callback_fns[name] = factory
+        return factory
+    return deco
+
+
+# ------------------------------------------------------------------------------------------------ jpeg compressibility
+def encode_jpeg(x, quality=95):
+    """float [0,1] or uint8 HxWx3 -> JPEG bytes as a uint8 array (reference ddpo/utils/hdf5.py:25-37: floats are
+    TRUNCATED to uint8 via (x*255).astype(uint8), PIL quality 95)."""
+    x = np.asarray(x)
+    if np.issubdtype(x.dtype, np.floating):
+        assert np.abs(x).max() <= 1.0
+        x = (x * 255).astype(np.uint8)
+    buf = io.BytesIO()
+    Image.fromarray(x).save(buf, "JPEG", quality=quality)
+    return np.frombuffer(buf.getvalue(), dtype=np.uint8)
+
+
+def jpeg_fn(devices=None, jit=False):
+    """reward = -(JPEG size in kB): compressibility (reference :143-153).  Returns (N,1) float64."""
+    assert not jit
+
+    def _fn(images, prompts, metadata):
+        del prompts, metadata
+        kb = [len(encode_jpeg(im)) / 1000.0 for im in images]
+        return -np.array(kb)[:, None], {}
+
+    return _fn
+
+
+def neg_jpeg_fn(*a, **kw):
+    """reward = +(JPEG size in kB): incompressibility (reference :156-163)."""
+    inner = jpeg_fn(*a, **kw)
+
+    def _fn(*args, **kwargs):
+        scores, info = inner(*args, **kwargs)
+        return -scores, info
+
+    return _fn
+
+
+# ------------------------------------------------------------------------------------------------ LAION aesthetic
+def aesthetic_fn(devices=None, rng=0, cache="cache", jit=True, weights_dir=None):
+    """CLIP ViT-L/14 image features -> L2-normalise -> LAION aesthetic MLP (reference :60-95, ddpo/models/laion.py).
+    Runs on the GPU in torch on a private stream.  Without network access neither the CLIP checkpoint nor the MLP
+    weights can be fetched: pass `weights_dir` with `clip/` (HF format) and `sac+logos+ava1-l14-linearMSE.pth`;
+    otherwise deterministic random-init weights are used and the info dict says so."""
+    import torch
+    from ..models.laion import AestheticScorer
+    scorer = AestheticScorer(weights_dir=weights_dir, seed=rng)
+
+    def _wrapper(images, prompts, metadata):
+        del prompts, metadata
+        scores = scorer(np.asarray(images, dtype=np.float32))
+        return scores[:, None], {"synthetic_weights": np.array(scorer.synthetic)}
+
+    return _wrapper
+
+
+# ------------------------------------------------------------------------------------------------ LLaVA over HTTP
+def _to_jpeg_bytes(image_u8, quality=80):
+    buf = io.BytesIO()
+    Image.fromarray(image_u8).save(buf, format="JPEG", quality=quality)
+    return buf.getvalue()
+
+
+def _llava_session():
+    import requests
+    from requests.adapters import HTTPAdapter, Retry
+    sess = requests.Session()
+    sess.mount("http://", HTTPAdapter(max_retries=Retry(total=1000, backoff_factor=1, status_forcelist=[500], allowed_methods=False)))
+    return sess
+
+
+def llava_bertscore(devices=None, jit=False, url="http://127.0.0.1:8085", batch_size=16, timeout=120):
+    """Alignment reward served by a LLaVA + BERTScore server (reference :465-537).  Wire format: POST of
+    pickle.dumps({"images": [jpeg bytes, q=80], "queries": [[str]], "answers": [[str]]}); the reply is a pickled dict
+    with "recall" (the reward), "precision", "f1", "outputs".  Batches of 16; 1000 retries on HTTP 500."""
+    sess = _llava_session()
+
+    def _fn(images, prompts, metadata):
+        del metadata
+        images = (np.asarray(images) * 255).astype(np.uint8)
+        nb = int(np.ceil(len(images) / batch_size))
+        scores, info = [], {"precision": [], "f1": [], "outputs": []}
+        for img_b, prm_b in zip(np.array_split(images, nb), np.array_split(np.asarray(prompts), nb)):
+            payload = {"images": [_to_jpeg_bytes(im) for im in img_b],
+                       "queries": [["Answer concisely: what is going on in this image?"]] * len(img_b),
+                       "answers": [[f"The image contains {p}"] for p in prm_b]}
+            reply = pickle.loads(sess.post(url, data=pickle.dumps(payload), timeout=timeout).content)
+            scores += np.array(reply["recall"]).squeeze().reshape(-1).tolist()
+            for k in info:
+                info[k] += np.array(reply[k]).squeeze().reshape(-1).tolist()
+        return np.array(scores), {k: np.array(v) for k, v in info.items()}
+
+    return _fn
+
+
+def llava_vqa_satisfaction(devices=None, jit=False, url="http://127.0.0.1:8085", batch_size=4, timeout=120):
+    """VQA reward (reference :402-462): request {"images", "queries"} (questions from the prompt metadata), reply
+    {"outputs"}; the score of an image is the fraction of answers that contain the expected answer string."""
+    sess = _llava_session()
+
+    def _fn(images, prompts, metadata):
+        del prompts
+        images = (np.asarray(images) * 255).astype(np.uint8)
+        nb = int(np.ceil(len(images) / batch_size))
+        metadata = list(metadata)
+        scores, outputs = [], []
+        for img_b, meta_b in zip(np.array_split(images, nb), np.array_split(np.arange(len(images)), nb)):
+            metas = [metadata[i] for i in meta_b]
+            payload = {"images": [_to_jpeg_bytes(im) for im in img_b], "queries": [m["questions"] for m in metas]}
+            reply = pickle.loads(sess.post(url, data=pickle.dumps(payload), timeout=timeout).content)
+            for m, outs in zip(metas, reply["outputs"]):
+                hits = [a.lower() in o.lower() for a, o in zip(m["answers"], outs)]
+                scores.append(float(np.mean(hits)))
+                outputs.append(list(outs))
+        return np.array(scores), {"outputs": np.array(outputs, dtype=object)}
+
+    return _fn
+
+
+# ------------------------------------------------------------------------------------------------ registry
+def evaluate_callbacks(fns, images, prompts, metadata):
+    if type(prompts[0]) == list:
+        prompts = [random.choice(p) for p in prompts]
+    images = np.asarray(images).astype(np.float32)
+    return {key: fn(images, prompts, metadata) for key, fn in fns.items()}
+
+
+callback_fns = {
+    "jpeg": jpeg_fn,
+    "neg_jpeg": neg_jpeg_fn,
+    "aesthetic": aesthetic_fn,
+    "llava_bertscore": llava_bertscore,
+    "llava_vqa": llava_vqa_satisfaction,
+}

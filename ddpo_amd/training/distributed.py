@@ -1,0 +1,92 @@
+"""Data-parallel plumbing: one process per GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI on the GPU box,
+"gloo" for the CPU tests).  Replaces the reference's pmap / multihost collectives:
+
+  lax.pmean(grad)                         -> ONE all-reduce(sum) of the flat gradient buffer per optimizer update
+                                             (ddpo_amd/training/policy_gradient.py), mean folded into the AdamW kernel
+  lax.pmean(info)                         -> all-reduce of 3 floats, once per logging point          (pmean_info)
+  multihost_utils.process_allgather(r)    -> all-gather of per-rank rewards, tiled                   (allgather_array)
+  process_allgather(prompt_ids) + decode  -> all_gather_object of the prompt strings                  (allgather_strings)
+  jax.process_index() / process_count()   -> rank / world size
+"""
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def init(backend=None):
+    """Initialise from torchrun-style env (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*); no-op for a single process."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = os.environ.get("DDPO_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        kw = {}
+        if backend == "nccl":
+            local = int(os.environ.get("LOCAL_RANK", "0"))
+            torch.cuda.set_device(local)
+            kw["device_id"] = torch.device("cuda", local)
+        dist.init_process_group(backend, **kw)
+    return process_index(), process_count()
+
+
+def process_index():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def process_count():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def _comm_device():
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+
+
+def allgather_array(x):
+    """process_allgather(x, tiled=True): concatenate equally-shaped per-rank numpy arrays along axis 0, on every rank."""
+    x = np.asarray(x)
+    if process_count() == 1:
+        return x
+    t = torch.from_numpy(np.ascontiguousarray(x)).to(_comm_device())
+    out = [torch.empty_like(t) for _ in range(process_count())]
+    dist.all_gather(out, t)
+    return torch.cat(out, 0).cpu().numpy()
+
+
+def allgather_strings(strings):
+    strings = list(strings)
+    if process_count() == 1:
+        return strings
+    out = [None] * process_count()
+    dist.all_gather_object(out, strings)
+    return [s for part in out for s in part]
+
+
+def pmean_info(info):
+    """Mean over ranks of a dict of scalars (device tensors or floats) with ONE small all-reduce."""
+    keys = sorted(info)
+    vals = torch.stack([torch.as_tensor(info[k], dtype=torch.float32).reshape(()).to(_comm_device() if process_count() > 1 else "cpu")
+                        for k in keys])
+    if process_count() > 1:
+        dist.all_reduce(vals, op=dist.ReduceOp.SUM)
+        vals = vals / process_count()
+    return {k: float(v) for k, v in zip(keys, vals.cpu())}
+
+
+def allreduce_sum_(flat, group=None):
+    """In-place sum over ranks of a flat buffer (the gradient all-reduce)."""
+    if process_count() > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    return flat
+
+
+def local_slice(global_array, rank=None, world=None):
+    """advantages.reshape(process_count, -1)[worker_id] (reference pipeline/policy_gradient.py:349)."""
+    rank = process_index() if rank is None else rank
+    world = process_count() if world is None else world
+    return np.asarray(global_array).reshape(world, -1)[rank]
+
+
+def barrier():
+    if process_count() > 1:
+        dist.barrier()

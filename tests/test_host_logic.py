@@ -1,0 +1,143 @@
+"""CPU tests of the host-side mirror of the reference's plugin / flag / advantage logic (no GPU, no oracle needed)."""
+import json
+import os
+import pickle
+import random
+import threading
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ------------------------------------------------------------------------------------------------ prompts
+def test_prompt_fns_follow_reference_rng_call_order():
+    from ddpo_amd.training import prompts as P
+    labels = [l.strip() for l in open(os.path.join(ROOT, "assets", "imagenet_labels.txt"))]
+    assert len(labels) == 1000 and labels[0] == "tench, Tinca tinca" and labels[397] == "puffer, pufferfish, blowfish, globefish"
+    random.seed(123)
+    got, training, meta = P.make_prompts("imagenet_animals", 5, False, evaluate=False)
+    random.seed(123)
+    want = []
+    for _ in range(5):                       # reference: randint(0, 397), then random.choice of the 1-element list
+        c = labels[random.randint(0, 397)]
+        want.append(random.choice([c]))
+    assert got == want and all(t == [g] for t, g in zip(training, got)) and meta == ({},) * 5
+    nouns = [l.strip() for l in open(os.path.join(ROOT, "assets", "common_animals.txt"))]
+    acts = [l.strip() for l in open(os.path.join(ROOT, "assets", "activities_v0.txt"))]
+    assert len(nouns) == 45 and acts == ["washing the dishes", "riding a bike", "playing chess"]
+    random.seed(7)
+    got = P.make_prompts("nouns_activities", 4, False, nouns_path="assets/common_animals.txt",
+                         activities_path="assets/activities_v0.txt", evaluate=False)[0]
+    random.seed(7)
+    want = []
+    for _ in range(4):
+        n = random.choice(nouns); a = random.choice(acts)
+        want.append(("an " if n[0] in "aeiou" else "a ") + n + " " + a)
+    assert got == want
+    random.seed(7)
+    same = P.make_prompts("from_file", 3, True, loadpath="assets/common_animals.txt", evaluate=False)
+    assert len(set(same[0])) == 1 and same[0][0] in nouns      # identical_batch: ONE draw replicated
+    with pytest.raises(KeyError):
+        P.make_prompts("no_such_prompt_fn", 1)
+
+    @P.register
+    def my_plugin(evaluate=False, word="x"):
+        return f"a {word}", [f"a {word}"], {"k": 1}
+    assert P.make_prompts("my_plugin", 2, False, word="cat", evaluate=False)[0] == ["a cat", "a cat"]
+
+
+# ------------------------------------------------------------------------------------------------ parser / config
+def test_parser_precedence_and_casting(tmp_path):
+    from ddpo_amd.utils.parser import Parser
+    a = Parser(["--dataset", "a-animals", "--logbase", str(tmp_path), "--sample_batch_size", "4", "--train_cfg", "False",
+                "--per_prompt_stats_bufsize", "None", "--eta", "0.25", "--seed", "5"]).parse_args("pg", process_index=2)
+    assert a.prompt_fn == "from_file" and a.filter_field == "aesthetic" and a.prompt_kwargs == {"loadpath": "assets/common_animals.txt"}
+    assert a.train_batch_size == 1 and a.train_accumulation_steps == 2          # dataset["pg"] over base["pg"]
+    assert a.sample_batch_size == 4 and a.train_cfg is False and a.per_prompt_stats_bufsize is None and a.eta == 0.25
+    assert a.seed == 7                                                            # seed + process index
+    assert a.savepath == os.path.join(str(tmp_path), "models/pg") and os.path.isdir(a.savepath)
+    assert a._dict["learning_rate"] == 1e-5 and a._dict["ppo_clip_range"] == 1e-4 and a._dict["n_inference_steps"] == 50
+    json.dumps(a._dict, default=str)
+    with pytest.raises(AssertionError):
+        Parser(["--dataset", "compressed_animals", "--not_a_flag", "1"]).parse_args("pg")
+    b = Parser(["--dataset", "compressed-animals", "--logbase", str(tmp_path)]).parse_args("pg")
+    assert b.filter_field == "jpeg" and b.prompt_fn == "imagenet_animals" and b.per_prompt_stats_bufsize == 32
+
+
+# ------------------------------------------------------------------------------------------------ advantages
+def test_per_prompt_stat_tracker_semantics():
+    from ddpo_amd.utils.stat_tracking import PerPromptStatTracker
+    tr = PerPromptStatTracker(buffer_size=4, min_count=3)
+    prompts = np.array(["a", "b", "a", "b"])
+    r = np.array([[1.0], [2.0], [3.0], [6.0]])
+    adv = tr.update(prompts, r)                       # fewer than min_count entries: batch-global statistics
+    np.testing.assert_allclose(adv, (r - r.mean()) / (r.std() + 1e-6))
+    adv2 = tr.update(prompts, r)                      # now 4 >= 3 per prompt: per-prompt buffers
+    for p in ("a", "b"):
+        buf = np.concatenate([r[prompts == p], r[prompts == p]])
+        np.testing.assert_allclose(adv2[prompts == p], (r[prompts == p] - buf.mean()) / (buf.std() + 1e-6))
+    tr.update(prompts, r)
+    assert tr.get_stats()["a"]["count"] == 4          # ring buffer capped at buffer_size
+    tr2 = PerPromptStatTracker(4, 3)
+    tr2.load_state_dict(tr.state_dict())
+    np.testing.assert_allclose(tr2.update(prompts, r), tr.update(prompts, r))
+
+
+def test_jpeg_reward_is_integer_exact_and_signed():
+    from ddpo_amd.training import callback_fns, evaluate_callbacks
+    from ddpo_amd.training.callbacks import encode_jpeg
+    import io
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    imgs = rng.random((3, 32, 32, 3)).astype(np.float32)
+    out = evaluate_callbacks({"jpeg": callback_fns["jpeg"](), "neg_jpeg": callback_fns["neg_jpeg"]()}, imgs, ["p"] * 3, ({},) * 3)
+    s, sneg = out["jpeg"][0], out["neg_jpeg"][0]
+    assert s.shape == (3, 1) and s.dtype == np.float64 and np.array_equal(s, -sneg)
+    for im, sc in zip(imgs, s[:, 0]):
+        buf = io.BytesIO()
+        Image.fromarray((im * 255).astype(np.uint8)).save(buf, "JPEG", quality=95)     # truncation, q=95
+        assert sc == -len(buf.getvalue()) / 1000.0 and len(encode_jpeg(im)) == len(buf.getvalue())
+    flat = np.full((1, 32, 32, 3), 0.5, dtype=np.float32)
+    assert callback_fns["jpeg"]()(flat, None, None)[0][0, 0] > s.max()                  # flat image compresses better
+
+
+def test_llava_bertscore_wire_format_against_stub():
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import llava_stub_server
+    from ddpo_amd.training.callbacks import llava_bertscore, llava_vqa_satisfaction
+    srv = llava_stub_server.serve(0)
+    port = srv.server_address[1]
+    th = threading.Thread(target=srv.serve_forever, daemon=True)
+    th.start()
+    try:
+        rng = np.random.default_rng(1)
+        imgs = rng.random((20, 16, 16, 3)).astype(np.float32)          # 2 chunks of <=16
+        fn = llava_bertscore(url=f"http://127.0.0.1:{port}")
+        scores, info = fn(imgs, [f"a cat {i}" for i in range(20)], None)
+        assert scores.shape == (20,) and set(info) == {"precision", "f1", "outputs"} and info["precision"].shape == (20,)
+        np.testing.assert_allclose(info["precision"], scores / 2)
+        vq = llava_vqa_satisfaction(url=f"http://127.0.0.1:{port}")
+        meta = tuple({"questions": ["is it?", "what?"], "answers": ["yes", "cat"]} for _ in range(5))
+        s2, i2 = vq(imgs[:5], None, meta)
+        np.testing.assert_allclose(s2, 0.5)
+    finally:
+        srv.shutdown()
+
+
+def test_global_advantage_normalisation_and_local_slice():
+    from ddpo_amd.training import distributed as D
+    r = np.arange(8, dtype=np.float64)[:, None]
+    adv = (r - r.mean()) / r.std()
+    assert np.array_equal(D.local_slice(adv, 1, 4), adv.reshape(4, -1)[1])
+    assert np.array_equal(D.allgather_array(r), r) and D.allgather_strings(["a"]) == ["a"]
+
+
+def test_byte_tokenizer_framing():
+    from ddpo_amd.models.text import ByteTokenizer, make_uncond_text
+    t = ByteTokenizer()
+    ids = t(["a cat", ""], padding="max_length", max_length=77, truncation=True, return_tensors="np").input_ids
+    assert ids.shape == (2, 77) and ids[0, 0] == 49406 and (ids[1, 1:] == 49407).all()
+    assert t.batch_decode(ids) == ["a cat", ""] and np.array_equal(make_uncond_text(t, 1)[0], ids[1])
