@@ -120,7 +120,19 @@ def _stream():
 
 
 def _p(t):
-    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+    """Device pointer of a CONTIGUOUS tensor (kernels index with explicit leading dimensions, never torch strides)."""
+    if t is None:
+        return c_void_p(0)
+    if not t.is_contiguous():
+        raise DdpoHipError(f"non-contiguous tensor of shape {tuple(t.shape)} / strides {t.stride()} passed to a HIP kernel")
+    return c_void_p(t.data_ptr())
+
+
+def _p_rows(t):
+    """Pointer of a 2-D row-strided view (column slice of a row-major matrix); the caller passes the row stride."""
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise DdpoHipError(f"expected a row-major 2-D view, got strides {t.stride()}")
+    return c_void_p(t.data_ptr())
 
 
 def _f32(t, name="tensor"):
@@ -468,7 +480,7 @@ def copy_cols(src, dst, col_off, rows, cols, ld_src=None):
     """dst[:, col_off:col_off+cols] = src[:, :cols] (dst/src are 2-D row-major)."""
     ld_dst = dst.shape[1]
     dptr = c_void_p(dst.data_ptr() + 4 * col_off)
-    _check(load().ddpo_copy_cols(_p(src), int(ld_src or src.shape[1]), dptr, ld_dst, rows, cols, _stream()), "ddpo_copy_cols")
+    _check(load().ddpo_copy_cols(_p_rows(src), int(ld_src or src.shape[1]), dptr, ld_dst, rows, cols, _stream()), "ddpo_copy_cols")
 
 
 def softmax_rows_(x, scale=1.0):

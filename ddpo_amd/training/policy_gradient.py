@@ -91,22 +91,22 @@ def train_step(state: AccumulatingTrainState, batch, noise_scheduler_state, nois
     advantages (b,), prompt_embeds, uncond_embeds (b,77,D) — device tensors.  Returns (state, info) with info a dict
     of device scalars {approx_kl, clipfrac, loss}."""
     assert isinstance(state, AccumulatingTrainState)
-    lat = batch["latents"]
+    lat = batch["latents"].contiguous()
     b = lat.shape[0]
     assert b == batch["ts"].shape[0] == batch["next_latents"].shape[0] == batch["log_probs"].shape[0]
     unet = state.unet
-    ts = batch["ts"].to(torch.int32)
+    ts = batch["ts"].to(torch.int32).contiguous()
     tape = []
     if train_cfg:
         lat2 = torch.cat([lat, lat])
-        ctx2 = torch.cat([batch["uncond_embeds"], batch["prompt_embeds"]])
+        ctx2 = torch.cat([batch["uncond_embeds"], batch["prompt_embeds"]]).contiguous()
         out = unet.forward(lat2, torch.cat([ts, ts]), ctx2, tape=tape)
-        eps_u, eps_c = out[:b], out[b:]
+        eps_u, eps_c = out[:b].contiguous(), out[b:].contiguous()
     else:
         out = unet.forward(lat, ts, batch["prompt_embeds"], tape=tape)
         eps_u, eps_c = None, out
     consts = noise_scheduler.kernel_consts(noise_scheduler_state, eta)
-    d_c, d_u, per_sample, info = L.ddim_logprob_ppo_fwd_bwd(eps_c, eps_u, lat.contiguous(), batch["next_latents"].contiguous(), ts,
+    d_c, d_u, per_sample, info = L.ddim_logprob_ppo_fwd_bwd(eps_c, eps_u, lat, batch["next_latents"].contiguous(), ts,
                                                             batch["log_probs"].contiguous(), batch["advantages"].contiguous(),
                                                             guidance_scale, clip_range, train_cfg, consts)
     d_out = torch.cat([d_u, d_c]) if train_cfg else d_c

@@ -236,7 +236,7 @@ def main(argv=None):
             except ImportError:
                 pass
     executor.shutdown()
-    return {"mean_rewards": mean_rewards, "localpath": localpath}
+    return {"mean_rewards": mean_rewards, "localpath": localpath, "state": state}
 
 
 if __name__ == "__main__":

@@ -34,7 +34,7 @@ def test_entrypoint_single_process(tmp_path, monkeypatch):
     assert set(info) == {"approx_kl", "clipfrac", "loss"} and info["loss"].shape == (4,)     # 1 minibatch x 4 timesteps
     assert np.isfinite(info["loss"]).all()
     # first PPO step of an epoch re-evaluates the sampled trajectory with unchanged weights: ratio == 1 up to fp32 noise
-    assert info["approx_kl"][0] < 1e-8
+    assert info["approx_kl"].max() < 1e-8 and info["clipfrac"].max() == 0.0
     ck = os.path.join(str(tmp_path / "run"), "models/pg/checkpoints")
     assert os.path.exists(os.path.join(ck, "checkpoint_1.safetensors")) and os.path.exists(os.path.join(ck, "resume_1.pt"))
     from safetensors.torch import load_file
@@ -51,7 +51,8 @@ def test_entrypoint_two_ranks_share_one_gpu(tmp_path):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", "29571", os.path.join(ROOT, "tests", "_dp_driver.py"), str(tmp_path)]
     p = subprocess.run(cmd, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=580)
-    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    errs = "".join(open(tmp_path / f).read() for f in os.listdir(tmp_path) if f.startswith("error_"))
+    assert p.returncode == 0, errs + p.stderr[-1500:]
     h0 = open(tmp_path / "hash_0.txt").read()
     h1 = open(tmp_path / "hash_1.txt").read()
     assert h0 == h1
