@@ -1,0 +1,320 @@
+// Implicit-GEMM convolution / dense GEMM on the bf16 MFMA datapath of gfx950 (v_mfma_f32_32x32x16_bf16, ~2.5 PFLOP/s
+// dense) with fp32 operands emulated by a bf16 split:   x = hi + lo,  hi = bf16(x),  lo = bf16(x - hi)
+//   NPASS = 3:  a*b ~= a_lo*b_hi + a_hi*b_lo + a_hi*b_hi   (XLA's "bf16_3x" / HIGH precision, ~2^-16 relative per product)
+//   NPASS = 1:  a*b ~= a_hi*b_hi                            (XLA's TPU DEFAULT precision, what the reference ran with)
+// accumulated in fp32.  Same contract as gemm_conv_kernel (gemm.hip):
+//   out[m][n] = alpha * sum_k A(m,k) W(k,n) + bias[n] + rowbias[m / rows_per_batch][n] + residual[m][n]
+// Activations stay fp32 in HBM and are split while they are staged into LDS (v_cvt_pk_bf16_f32); weights are
+// pre-split once per optimizer update into bf16 hi/lo planes, k-contiguous per output column ([N][Kp] for the forward
+// pass, the original [K][N] order for data gradients), so a B fragment is one 16-byte load.
+// LDS tiles are [row][32 k] bf16 (64 B per row) with the 16-byte chunk index XOR-swizzled by (row>>2)&3: every
+// ds_read_b128 / ds_write of a 16-lane group touches 16 distinct 16-byte slots (conflict-free).
+#include "common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define BF_BK 32
+#define BF_THREADS 256
+
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+
+// split 4 floats into 4 bf16 "hi" (2 dwords) and 4 bf16 "lo" (2 dwords)
+__device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo) {
+  hi.x = cvt_pk_bf16(v.x, v.y);
+  hi.y = cvt_pk_bf16(v.z, v.w);
+  const float r0 = v.x - __uint_as_float(hi.x << 16), r1 = v.y - __uint_as_float(hi.x & 0xFFFF0000u);
+  const float r2 = v.z - __uint_as_float(hi.y << 16), r3 = v.w - __uint_as_float(hi.y & 0xFFFF0000u);
+  lo.x = cvt_pk_bf16(r0, r1);
+  lo.y = cvt_pk_bf16(r2, r3);
+}
+
+__device__ __forceinline__ int swz_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }   // bytes
+
+template <int BM, int BN, int NPASS>
+__global__ void __launch_bounds__(BF_THREADS) gemm_conv_bf16_kernel(const ddpo_gemm_desc d, const uint16_t* __restrict__ w_hi,
+                                                                   const uint16_t* __restrict__ w_lo, int ldw, int tiles_n,
+                                                                   int nblk) {
+  constexpr int BK = BF_BK;
+  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int AROWS = BM / 32;                 // float4 chunks per thread (A tile)
+  constexpr int BCH = BN / 64;                   // 16-byte chunks per thread per plane (W tile)
+  constexpr int NPL = (NPASS == 3) ? 2 : 1;      // planes per operand
+  constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // layout per stage: A_hi | A_lo | B_hi | B_lo
+  constexpr int STAGE = NPL * (A_BYTES + B_BYTES);
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+
+  int bid = blockIdx.x;
+  {
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int q = nblk >> 3, r = nblk & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const bool conv = d.ksize > 0;
+  const int VH = d.upsample ? d.H * 2 : d.H, VW = d.upsample ? d.W * 2 : d.W;
+  const bool zins = d.upsample == 2;
+
+  // ---- A loader: thread owns float4 index kq (k = 4*kq..) of rows (t>>3) + 32*i
+  const int kq = t & 7;
+  int64_t abase[AROWS];
+  int aiy0[AROWS], aix0[AROWS];
+  bool avalid[AROWS];
+#pragma unroll
+  for (int i = 0; i < AROWS; ++i) {
+    const int m = m0 + (t >> 3) + 32 * i;
+    avalid[i] = m < d.M;
+    if (conv) {
+      const int ohw = d.OH * d.OW;
+      const int mm = avalid[i] ? m : 0;
+      const int b = mm / ohw, rem = mm - b * ohw;
+      const int oy = rem / d.OW, ox = rem - oy * d.OW;
+      abase[i] = (int64_t)b * d.H * d.W;
+      aiy0[i] = oy * d.stride - d.pad;
+      aix0[i] = ox * d.stride - d.pad;
+    } else {
+      abase[i] = (int64_t)m * d.ld_src;
+      aiy0[i] = aix0[i] = 0;
+    }
+  }
+  // ---- W loader: thread owns 16-byte chunk bc (8 bf16 of k) of rows (t>>2) + 64*i
+  const int bc = t & 3;
+
+  float4 ra[AROWS];
+  uint4 rbh[BCH], rbl[BCH];
+
+  auto load_tile = [&](int kt) {
+    const int kg = kt * BK + kq * 4;
+    int ky = 0, kx = 0, ci = kg;
+    if (conv) {
+      const int tap = kg / d.Cin;
+      ci = kg - tap * d.Cin;
+      ky = tap / d.ksize;
+      kx = tap - ky * d.ksize;
+    }
+    const bool kval = kg < d.K;
+#pragma unroll
+    for (int i = 0; i < AROWS; ++i) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (conv) {
+        const int iy = aiy0[i] + ky, ix = aix0[i] + kx;
+        if (avalid[i] && kval && iy >= 0 && iy < VH && ix >= 0 && ix < VW && !(zins && ((iy | ix) & 1))) {
+          const int sy = d.upsample ? (iy >> 1) : iy, sx = d.upsample ? (ix >> 1) : ix;
+          v = *reinterpret_cast<const float4*>(d.src + (abase[i] + (int64_t)sy * d.W + sx) * d.ld_src + ci);
+        }
+      } else if (avalid[i] && kval) {
+        v = *reinterpret_cast<const float4*>(d.src + abase[i] + kg);
+      }
+      ra[i] = v;
+    }
+    const int kb = kt * BK + bc * 8;             // first k of this thread's 8-wide W chunk
+#pragma unroll
+    for (int i = 0; i < BCH; ++i) {
+      const int n = n0 + (t >> 2) + 64 * i;
+      uint4 h = make_uint4(0u, 0u, 0u, 0u), l = h;
+      if (n < d.N && kb < d.K) {
+        int64_t off;
+        if (d.w_dgrad) {   // planes in the forward [K][N] order = [tap][ci_fwd = n][co_fwd]: flipped tap, co contiguous
+          const int tap = kb / d.Cin, co = kb - tap * d.Cin;
+          const int tapf = d.ksize * d.ksize - 1 - tap;
+          off = ((int64_t)tapf * d.N + n) * d.Cin + co;
+        } else {
+          off = (int64_t)n * ldw + kb;
+        }
+        h = *reinterpret_cast<const uint4*>(w_hi + off);
+        if (NPASS == 3) l = *reinterpret_cast<const uint4*>(w_lo + off);
+      }
+      rbh[i] = h;
+      rbl[i] = l;
+    }
+  };
+
+  auto store_tile = [&](int buf) {
+    char* st = smem + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < AROWS; ++i) {
+      const int row = (t >> 3) + 32 * i;
+      uint2 hi, lo;
+      split4(ra[i], hi, lo);
+      const int off = swz_off(row, kq >> 1) + (kq & 1) * 8;
+      *reinterpret_cast<uint2*>(st + off) = hi;
+      if (NPASS == 3) *reinterpret_cast<uint2*>(st + A_BYTES + off) = lo;
+    }
+    char* sb = st + NPL * A_BYTES;
+#pragma unroll
+    for (int i = 0; i < BCH; ++i) {
+      const int row = (t >> 2) + 64 * i;
+      const int off = swz_off(row, bc);
+      *reinterpret_cast<uint4*>(sb + off) = rbh[i];
+      if (NPASS == 3) *reinterpret_cast<uint4*>(sb + B_BYTES + off) = rbl[i];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = (d.K + BK - 1) / BK;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  const int arow = wm * (BM / 2) + (lane & 31);
+  const int brow = wn * (BN / 2) + (lane & 31);
+  const int khalf = lane >> 5;
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) load_tile(kt + 1);
+    const char* sa = smem + cur * STAGE;
+    const char* sb = sa + NPL * A_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      const int chunk = ks * 2 + khalf;
+      bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int off = swz_off(arow + i * 32, chunk);
+        ah[i] = *reinterpret_cast<const bf16x8*>(sa + off);
+        if (NPASS == 3) al[i] = *reinterpret_cast<const bf16x8*>(sa + A_BYTES + off);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int off = swz_off(brow + j * 32, chunk);
+        bh[j] = *reinterpret_cast<const bf16x8*>(sb + off);
+        if (NPASS == 3) bl[j] = *reinterpret_cast<const bf16x8*>(sb + B_BYTES + off);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          if (NPASS == 3) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    if (kt + 1 < nk) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+      if (col >= d.N) continue;
+      const float bv = d.bias ? d.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+        if (row >= d.M) continue;
+        float v = d.alpha * acc[i][j][r] + bv;
+        if (d.rowbias) v += d.rowbias[(int64_t)(row / d.rows_per_batch) * d.ld_rowbias + col];
+        if (d.residual) v += d.residual[(int64_t)row * d.ld_res + col];
+        d.out[(int64_t)row * d.ld_out + col] = v;
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int NPASS>
+static int launch_bf16(const ddpo_gemm_desc& d, const uint16_t* w_hi, const uint16_t* w_lo, int ldw, hipStream_t st) {
+  const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;
+  const int nblk = tiles_m * tiles_n;
+  constexpr int NPL = (NPASS == 3) ? 2 : 1;
+  const size_t lds = 2 * NPL * (size_t)(BM + BN) * 64;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_bf16_kernel<BM, BN, NPASS>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_conv_bf16_kernel<BM, BN, NPASS>), dim3(nblk), dim3(BF_THREADS), lds, st, d, w_hi, w_lo, ldw, tiles_n, nblk);
+  DDPO_LAUNCH_CHECK();
+  return DDPO_OK;
+}
+
+extern "C" int ddpo_gemm_conv_fwd_bf16(const ddpo_gemm_desc* dp, const uint16_t* w_hi, const uint16_t* w_lo, int ldw, int npass,
+                                       void* stream) {
+  if (!dp || !w_hi) return DDPO_EINVAL;
+  const ddpo_gemm_desc& d = *dp;
+  if (npass != 1 && npass != 3) return DDPO_EINVAL;
+  if (npass == 3 && !w_lo) return DDPO_EINVAL;
+  if (!d.src || !d.out || d.M <= 0 || d.N <= 0 || d.K <= 0 || (d.ld_src & 3) || (reinterpret_cast<uintptr_t>(d.src) & 15)) return DDPO_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(w_hi) & 15) || (w_lo && (reinterpret_cast<uintptr_t>(w_lo) & 15))) return DDPO_EINVAL;
+  if (d.ksize > 0) {
+    if (d.ksize != 1 && d.ksize != 3) return DDPO_EINVAL;
+    if ((d.Cin & 7) || d.K != d.ksize * d.ksize * d.Cin || d.M != d.B * d.OH * d.OW) return DDPO_EINVAL;
+    if (d.upsample < 0 || d.upsample > 2) return DDPO_EINVAL;
+  } else if (d.K & 7) {
+    return DDPO_EINVAL;
+  }
+  if (d.w_dgrad) {
+    if (d.ksize <= 0 || (d.Cin & 7)) return DDPO_EINVAL;       // W planes in forward [K][N] order; co chunks of 8 stay inside a tap
+  } else if (ldw < d.K || (ldw & 7)) {
+    return DDPO_EINVAL;
+  }
+  hipStream_t st = as_stream(stream);
+  const long t128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128);
+  const bool big = (d.N % 128 == 0) && t128 >= 256;
+  if (npass == 3) return big ? launch_bf16<128, 128, 3>(d, w_hi, w_lo, ldw, st) : launch_bf16<128, 64, 3>(d, w_hi, w_lo, ldw, st);
+  return big ? launch_bf16<128, 128, 1>(d, w_hi, w_lo, ldw, st) : launch_bf16<128, 64, 1>(d, w_hi, w_lo, ldw, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing: fp32 W[K][N] -> bf16 hi/lo planes, forward order [N][Kp] (k contiguous, Kp = K rounded up to 8,
+// pad zero) and backward order [K][N] (the original order).  32x32 LDS-tiled transpose.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) pack_weights_kernel(const float* __restrict__ w, int K, int N, int Kp,
+                                                           uint16_t* __restrict__ fwd_hi, uint16_t* __restrict__ fwd_lo,
+                                                           uint16_t* __restrict__ bwd_hi, uint16_t* __restrict__ bwd_lo) {
+  __shared__ uint32_t tile[32][33];      // hi | lo<<16
+  const int k0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    const int k = k0 + r, n = n0 + tx;
+    uint32_t packed = 0;
+    if (k < K && n < N) {
+      const float x = w[(int64_t)k * N + n];
+      const uint32_t h = cvt_pk_bf16(x, 0.f) & 0xFFFFu;
+      const float rem = x - __uint_as_float(h << 16);
+      const uint32_t l = cvt_pk_bf16(rem, 0.f) & 0xFFFFu;
+      packed = h | (l << 16);
+      if (bwd_hi) { bwd_hi[(int64_t)k * N + n] = (uint16_t)h; bwd_lo[(int64_t)k * N + n] = (uint16_t)l; }
+    }
+    tile[r][tx] = packed;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int n = n0 + r, k = k0 + tx;
+    if (n < N && k < Kp) {
+      const uint32_t p = tile[tx][r];
+      fwd_hi[(int64_t)n * Kp + k] = (uint16_t)(p & 0xFFFFu);
+      fwd_lo[(int64_t)n * Kp + k] = (uint16_t)(p >> 16);
+    }
+  }
+}
+
+extern "C" int ddpo_pack_weights_bf16(const float* w, int K, int N, int Kp, uint16_t* fwd_hi, uint16_t* fwd_lo, uint16_t* bwd_hi,
+                                      uint16_t* bwd_lo, void* stream) {
+  if (!w || !fwd_hi || !fwd_lo || K <= 0 || N <= 0 || Kp < K || (Kp & 7) || (bwd_hi && !bwd_lo)) return DDPO_EINVAL;
+  dim3 grid((N + 31) / 32, (Kp + 31) / 32);
+  hipLaunchKernelGGL(pack_weights_kernel, grid, dim3(256), 0, as_stream(stream), w, K, N, Kp, fwd_hi, fwd_lo, bwd_hi, bwd_lo);
+  DDPO_LAUNCH_CHECK();
+  return DDPO_OK;
+}

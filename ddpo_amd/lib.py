@@ -56,6 +56,8 @@ _SIGS = {
     "ddpo_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "ddpo_gemm_conv_fwd": (c_int, [POINTER(GemmDesc), c_void_p]),
     "ddpo_gemm_conv_wgrad": (c_int, [POINTER(GemmDesc), c_void_p]),
+    "ddpo_gemm_conv_fwd_bf16": (c_int, [POINTER(GemmDesc), c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "ddpo_pack_weights_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ddpo_attention_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int,
                                    c_int, c_int, c_int, c_float, c_void_p]),
     "ddpo_attention_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -82,6 +84,12 @@ _SIGS = {
 
 EXPORTED_SYMBOLS = tuple(_SIGS)
 _lib = None
+# Contraction datapath of the GEMM / conv kernels: "fp32" (exact v_mfma_f32_32x32x2_f32), "bf16x3" (bf16-split MFMA,
+# 3 passes, ~1e-5 relative) or "bf16" (single pass = XLA's TPU default precision).  The bf16 paths are used for
+# weights that have been registered with `pack_weights` (ParamStore.pack_bf16); everything else stays on fp32.
+DATAPATH = os.environ.get("DDPO_DATAPATH", "fp32")
+PACKED = {}          # data_ptr of an fp32 weight tensor -> dict(fwd=(hi, lo, Kp), bwd=(hi, lo) | None, K, N)
+
 # When set to a list, every ddpo_gemm_conv_fwd launch appends (start_event, end_event, algorithmic_flops);
 # used by bench.py for the live roofline measurement of the dominant kernel.
 PROFILE = None
@@ -260,6 +268,42 @@ def layernorm(x, gamma, beta, eps=1e-5, out=None):
     return out
 
 
+def pack_weights(w, bwd=True):
+    """Register bf16 hi/lo planes for an fp32 weight tensor w (…, N) viewed as (K, N); re-run after w changes."""
+    N = w.shape[-1]
+    K = w.numel() // N
+    Kp = (K + 7) // 8 * 8
+    ent = PACKED.get(w.data_ptr())
+    if ent is None or ent["K"] != K or ent["N"] != N:
+        mk = lambda *s: torch.zeros(*s, dtype=torch.int16, device=w.device)
+        ent = dict(K=K, N=N, fwd=(mk(N, Kp), mk(N, Kp), Kp), bwd=(mk(K, N), mk(K, N)) if bwd else None)
+        PACKED[w.data_ptr()] = ent
+    fh, fl, _ = ent["fwd"]
+    bh, bl = ent["bwd"] if ent["bwd"] is not None else (None, None)
+    _check(load().ddpo_pack_weights_bf16(_p(w), K, N, Kp, _p(fh), _p(fl), _p(bh), _p(bl), _stream()), "ddpo_pack_weights_bf16")
+    return ent
+
+
+def _bf16_route(w, K, N, conv, dgrad):
+    """Return (hi, lo, ldw, npass) if this contraction should run on the bf16 MFMA path, else None."""
+    if DATAPATH == "fp32":
+        return None
+    ent = PACKED.get(w.data_ptr())
+    if ent is None:
+        return None
+    cin = conv["Cin"] if conv else K
+    if cin % 8:
+        return None
+    npass = 3 if DATAPATH == "bf16x3" else 1
+    if dgrad:
+        if ent["bwd"] is None or not conv:
+            return None
+        return ent["bwd"][0], ent["bwd"][1], 0, npass
+    if ent["K"] != K or ent["N"] != N:
+        return None
+    return ent["fwd"][0], ent["fwd"][1], ent["fwd"][2], npass
+
+
 def gemm_conv(src, w, *, M, N, K, bias=None, rowbias=None, rows_per_batch=0, residual=None, out=None, alpha=1.0,
               w_trans=False, ld_src=None, ld_out=None, ld_res=None, conv=None):
     """Generic entry: conv = dict(ksize, stride, pad, upsample, B, H, W, Cin, OH, OW) or None for a dense GEMM."""
@@ -279,14 +323,18 @@ def gemm_conv(src, w, *, M, N, K, bias=None, rowbias=None, rows_per_batch=0, res
     if conv:
         for k in ("ksize", "stride", "pad", "upsample", "B", "H", "W", "Cin", "OH", "OW"):
             setattr(d, k, int(conv[k]))
+    route = None if w_trans else _bf16_route(w, K, N, conv, False)
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
+    if route is not None:
+        hi, lo, ldw, npass = route
+        _check(load().ddpo_gemm_conv_fwd_bf16(byref(d), _p(hi), _p(lo), ldw, npass, _stream()), "ddpo_gemm_conv_fwd_bf16")
+    else:
         _check(load().ddpo_gemm_conv_fwd(byref(d), _stream()), "ddpo_gemm_conv_fwd")
+    if PROFILE is not None:
         e1.record()
-        PROFILE.append((e0, e1, 2.0 * M * N * K))
-        return out
-    _check(load().ddpo_gemm_conv_fwd(byref(d), _stream()), "ddpo_gemm_conv_fwd")
+        PROFILE.append((e0, e1, 2.0 * M * N * K, "fp32" if route is None else DATAPATH))
     return out
 
 
@@ -379,6 +427,20 @@ def linear_dgrad(dy, w, residual=None):
     """dx = dy @ w^T for the forward y = x @ w, w: (K, N) Flax layout."""
     M, N = dy.shape
     K = w.shape[0]
+    ent = PACKED.get(w.data_ptr()) if DATAPATH != "fp32" else None
+    if ent is not None and ent["bwd"] is not None and N % 8 == 0:
+        # the original (K, N) order is exactly "output column k, reduction index n contiguous": forward-style planes with ldw = N
+        d = GemmDesc()
+        out = torch.empty(M, K, dtype=torch.float32, device=dy.device)
+        d.src = dy.data_ptr(); d.ld_src = int(N)
+        if residual is not None:
+            d.residual = residual.data_ptr(); d.ld_res = int(K)
+        d.out = out.data_ptr(); d.ld_out = int(K)
+        d.alpha = 1.0
+        d.M, d.N, d.K = int(M), int(K), int(N)
+        _check(load().ddpo_gemm_conv_fwd_bf16(byref(d), _p(ent["bwd"][0]), _p(ent["bwd"][1]), int(N), 3 if DATAPATH == "bf16x3" else 1,
+                                              _stream()), "ddpo_gemm_conv_fwd_bf16(dgrad)")
+        return out
     return gemm_conv(dy, w, M=M, N=K, K=N, w_trans=True, residual=residual)
 
 
@@ -439,7 +501,12 @@ def conv2d_dgrad(dy, w, B, H, W, Cin, Cout, ksize, stride=1, residual=None):
     d.M, d.N, d.K = B * H * W, int(Cin), ksize * ksize * int(Cout)
     for k, v in conv.items():
         setattr(d, k, int(v))
-    _check(load().ddpo_gemm_conv_fwd(byref(d), _stream()), "ddpo_gemm_conv_fwd(dgrad)")
+    route = _bf16_route(w, d.K, d.N, conv, True)
+    if route is not None:
+        hi, lo, _, npass = route
+        _check(load().ddpo_gemm_conv_fwd_bf16(byref(d), _p(hi), _p(lo), 0, npass, _stream()), "ddpo_gemm_conv_fwd_bf16(dgrad)")
+    else:
+        _check(load().ddpo_gemm_conv_fwd(byref(d), _stream()), "ddpo_gemm_conv_fwd(dgrad)")
     return out
 
 

@@ -74,6 +74,13 @@ class ParamStore:
                 raise ValueError(f"{n}: expected {self.shapes[n]}, got {tuple(t.shape)}")
             v.copy_(t)
 
+    def pack_bf16(self, bwd=True):
+        """(Re)build the bf16 hi/lo planes of every contraction weight for the bf16 MFMA datapaths (lib.DATAPATH).
+        Call after loading weights and after every optimizer update."""
+        for n, v in self.views.items():
+            if n.endswith(".kernel"):
+                L.pack_weights(v, bwd=bwd)
+
     def init_synthetic(self, seed=0):
         """Random-init weights of the right architecture (no checkpoints are reachable offline)."""
         g = torch.Generator(device=self.flat.device).manual_seed(seed)

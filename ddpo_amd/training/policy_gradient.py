@@ -79,6 +79,8 @@ class AccumulatingTrainState:
                             tx.learning_rate, tx.b1, tx.b2, tx.eps, tx.weight_decay, tx.max_grad_norm, t,
                             mu_decay_in_bf16=tx.mu_decay_in_bf16, zero_grad=True)
         self.last_grad_norm = torch.sqrt(self._sqnorm.clone()) * inv       # device scalar, no host sync
+        if L.DATAPATH != "fp32":
+            self.params.pack_bf16()                                        # refresh the bf16 hi/lo weight planes
         self.opt_state["count"] = t
         self.step += 1
         self.n_acc = 0

@@ -140,6 +140,19 @@ int ddpo_gemm_conv_fwd(const ddpo_gemm_desc* d, void* stream);
  *   are combined with fp32 atomic adds (out must hold zeros or the running gradient accumulation). */
 int ddpo_gemm_conv_wgrad(const ddpo_gemm_desc* d, void* stream);
 
+/* Same contraction on the bf16 MFMA datapath (v_mfma_f32_32x32x16_bf16) with fp32 operands emulated by a bf16 split
+ * (x = hi + lo): npass = 3 computes a_lo*b_hi + a_hi*b_lo + a_hi*b_hi (XLA "bf16_3x"/HIGH, ~1e-5 relative),
+ * npass = 1 computes a_hi*b_hi (XLA's TPU DEFAULT precision — what the reference ran with); fp32 accumulation.
+ * Activations (d->src) stay fp32 and are split on the fly; the weights are given as pre-split bf16 planes made by
+ * ddpo_pack_weights_bf16: forward order (N, ldw=Kp) for the forward pass, the original (K, N) order with
+ * d->w_dgrad = 1 for data gradients.  d->w / d->w_trans are ignored.  Requires Cin % 8 == 0 (K % 8 == 0 if dense). */
+int ddpo_gemm_conv_fwd_bf16(const ddpo_gemm_desc* d, const uint16_t* w_hi, const uint16_t* w_lo, int ldw, int npass,
+                            void* stream);
+/* fp32 W (K,N) -> bf16 hi/lo planes: fwd_* (N, Kp) k-contiguous (Kp = K rounded up to 8, zero padded) and, if
+ * bwd_hi != NULL, bwd_* (K, N).  Call after every optimizer update (weights only change there). */
+int ddpo_pack_weights_bf16(const float* w, int K, int N, int Kp, uint16_t* fwd_hi, uint16_t* fwd_lo,
+                           uint16_t* bwd_hi, uint16_t* bwd_lo, void* stream);
+
 /* Fused multi-head attention, softmax(q k^T * scale) v, flash-style on fp32 MFMA (16x16x4).
  * q:(B,Nq,·) k,v:(B,Nk,·) o:(B,Nq,·): head h occupies columns [h*d,(h+1)*d) of each row; ld* = row strides.
  * lse (optional, (B,heads,Nq)): log2-domain logsumexp of the scaled scores, consumed by the backward pass. */

@@ -1,0 +1,123 @@
+"""GPU tests of the bf16-split MFMA datapath (bf16x3 = 3-pass, ~1e-5 relative; bf16 = single pass) against float64."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as TF
+
+pytestmark = pytest.mark.gpu
+
+from ddpo_amd import lib as L
+
+DEV = "cuda"
+
+
+def _rel(a, b):
+    a = np.asarray(a.detach().cpu() if torch.is_tensor(a) else a, dtype=np.float64)
+    b = np.asarray(b.detach().cpu() if torch.is_tensor(b) else b, dtype=np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+@pytest.fixture
+def datapath():
+    old = L.DATAPATH
+    yield
+    L.DATAPATH = old
+    L.PACKED.clear()
+
+
+TOL = {"bf16x3": 5e-5, "bf16": 3e-2}
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("M,K,N", [(64, 32, 64), (154, 64, 128), (1000, 320, 320), (4096, 1280, 640), (16, 1280, 320), (2048, 320, 2560), (300, 768, 320)])
+def test_gemm_dense_bf16(datapath, mode, M, K, N):
+    L.DATAPATH = mode
+    g = torch.Generator().manual_seed(M + K + N)
+    a = torch.randn(M, K, generator=g)
+    w = (torch.randn(K, N, generator=g) / math.sqrt(K)).to(DEV)
+    bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    L.pack_weights(w)
+    out = L.linear(a.to(DEV), w, bias.to(DEV), residual=res.to(DEV))
+    ref = a.double() @ w.cpu().double() + bias.double() + res.double()
+    assert _rel(out, ref) < TOL[mode]
+    dy = torch.randn(M, N, generator=g)
+    dx = L.linear_dgrad(dy.to(DEV), w)
+    assert _rel(dx, dy.double() @ w.cpu().double().t()) < TOL[mode]
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("B,H,W,Cin,Cout,ks,stride,ups", [
+    (2, 8, 8, 32, 64, 3, 1, False), (2, 8, 8, 96, 64, 3, 1, False), (2, 8, 8, 64, 64, 3, 2, False), (2, 4, 4, 128, 128, 3, 1, True),
+    (2, 8, 8, 64, 128, 1, 1, False), (1, 32, 32, 320, 320, 3, 1, False), (2, 16, 16, 640, 640, 3, 2, False), (3, 5, 7, 32, 64, 3, 1, False),
+    (2, 8, 8, 32, 8, 3, 1, False)])
+def test_conv_bf16(datapath, mode, B, H, W, Cin, Cout, ks, stride, ups):
+    L.DATAPATH = mode
+    g = torch.Generator().manual_seed(H + Cin + Cout)
+    x = torch.randn(B, H, W, Cin, generator=g)
+    w = (torch.randn(ks, ks, Cin, Cout, generator=g) / math.sqrt(ks * ks * Cin)).to(DEV)
+    bias, temb = torch.randn(Cout, generator=g), torch.randn(B, Cout, generator=g)
+    L.pack_weights(w)
+    xd = x.permute(0, 3, 1, 2).double().requires_grad_(True)
+    xin = TF.interpolate(xd, scale_factor=2, mode="nearest") if ups else xd
+    y = TF.conv2d(xin, w.cpu().permute(3, 2, 0, 1).double(), bias.double(), stride=stride, padding=ks // 2)
+    OH, OW = y.shape[2], y.shape[3]
+    ref = (y + temb.double()[:, :, None, None]).permute(0, 2, 3, 1).reshape(B * OH * OW, Cout)
+    out, oh, ow = L.conv2d(x.reshape(-1, Cin).to(DEV), w, bias.to(DEV), B, H, W, Cin, Cout, ks, stride=stride, upsample=ups,
+                           rowbias=temb.to(DEV), rows_per_batch=OH * OW)
+    assert (oh, ow) == (OH, OW) and _rel(out, ref.detach()) < TOL[mode]
+    if not ups and Cout % 8 == 0:
+        dy = torch.randn(B, OH, OW, Cout, generator=g)
+        y.backward(dy.permute(0, 3, 1, 2).double())
+        dx = L.conv2d_dgrad(dy.reshape(-1, Cout).to(DEV), w, B, H, W, Cin, Cout, ks, stride=stride)
+        assert _rel(dx, xd.grad.permute(0, 2, 3, 1).reshape(B * H * W, Cin)) < TOL[mode]
+
+
+def test_unregistered_weights_stay_on_fp32(datapath):
+    L.DATAPATH = "bf16"
+    g = torch.Generator().manual_seed(0)
+    a, w = torch.randn(64, 64, generator=g), torch.randn(64, 64, generator=g)
+    out = L.linear(a.to(DEV), w.to(DEV))           # never packed -> exact fp32 MFMA path
+    assert _rel(out, a.double() @ w.double()) < 1e-5
+
+
+@pytest.mark.parametrize("mode,tol", [("bf16x3", 1e-3), ("bf16", 1e-1)])
+def test_unet_and_train_step_bf16(datapath, mode, tol):
+    """Whole U-Net forward + one PPO train step on the bf16 datapaths against the fp32/float64 oracle.  bf16x3 must
+    meet the north-star tolerance (1e-3 on outputs, loss and grad norm)."""
+    from ddpo_amd.models.unet import UNet2DCondition, UNetConfig
+    from ddpo_amd.diffusers_patch.scheduling_ddim import DDIMScheduler
+    from ddpo_amd.training.policy_gradient import AccumulatingTrainState, AdamWConfig, train_step
+    from oracle import unet as OU
+    from oracle.ddim import DDIMOracle
+    from oracle.sampler import train_step_grads
+    L.DATAPATH = mode
+    op = OU.init_params(OU.unet_param_shapes(OU.TINY), seed=0)
+    unet = UNet2DCondition(UNetConfig.named("tiny"), DEV)
+    unet.params.load_dict(op)
+    unet.params.pack_bf16()
+    g = torch.Generator().manual_seed(5)
+    b, hw = 2, 8
+    lat = torch.randn(b, 4, hw, hw, generator=g)
+    ts = torch.tensor([481, 21], dtype=torch.int32)
+    emb = torch.randn(b, 77, 64, generator=g)
+    unc = torch.randn(1, 77, 64, generator=g).expand(b, -1, -1).contiguous()
+    ref = OU.unet_forward({k: v.double() for k, v in op.items()}, OU.TINY, lat.double(), ts, emb.double())
+    out = unet(lat.to(DEV), ts.to(DEV), emb.to(DEV))
+    assert _rel(out, ref) < tol
+    sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", set_alpha_to_one=False, steps_offset=1)
+    st = sched.set_timesteps(sched.create_state(device=DEV), 50)
+    dd = DDIMOracle()
+    ost = dd.set_timesteps(dd.create_state(), 50)
+    nxt = lat * 0.95 + 0.05 * torch.randn(lat.shape, generator=g)
+    batch = {"latents": lat, "next_latents": nxt, "ts": ts, "log_probs": torch.tensor([-1.2, -0.9]),
+             "advantages": torch.tensor([0.7, -1.1]), "prompt_embeds": emb, "uncond_embeds": unc}
+    ograds, oinfo, _ = train_step_grads(op, OU.TINY, dd, ost, {k: (v if k == "ts" else v.double()) for k, v in batch.items()},
+                                        5.0, 1.0, 10.0, True, dtype=torch.float64)
+    state = AccumulatingTrainState(unet, AdamWConfig())
+    state, info = train_step(state, {k: v.to(DEV) for k, v in batch.items()}, st, sched, True, 5.0, 1.0, 10.0, do_opt_update=False)
+    gn_o = math.sqrt(sum(float((v.double() ** 2).sum()) for v in ograds.values()))
+    gn = math.sqrt(float((unet.grads.flat.double() ** 2).sum()))
+    assert gn == pytest.approx(gn_o, rel=tol)
+    assert float(info["loss"]) == pytest.approx(oinfo["loss"], rel=tol, abs=1e-6)
