@@ -27,6 +27,7 @@ import torch
 UNET_FWD_TFLOP = {"sd15": 0.8033, "tiny": None}      # per sample at 64x64 latents
 VAE_TFLOP = {"sd15": 2.5145}
 FP32_MFMA_PEAK_TFLOPS = 157.3                          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0                         # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16 dense peak
 
 
 def parse():
@@ -38,6 +39,8 @@ def parse():
     ap.add_argument("--resolution", type=int, default=512)
     ap.add_argument("--n-inference-steps", type=int, default=50)
     ap.add_argument("--sample-batch-size", type=int, default=8)
+    ap.add_argument("--datapath", default=os.environ.get("DDPO_DATAPATH", "bf16x3"), choices=["fp32", "bf16x3", "bf16"],
+                    help="contraction datapath: exact-fp32 MFMA, bf16-split MFMA x3 (fp32-accurate to ~1e-5, default), single-pass bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -100,11 +103,15 @@ def main():
     from ddpo_amd.utils import prng
 
     L.load()
+    L.DATAPATH = args.datapath
     ucfg = UNetConfig.named(args.model)
     unet = UNet2DCondition(ucfg, dev)
     unet.params.init_synthetic(seed=0)
     vae = VAEDecoder(VAEConfig.named("sd" if args.model == "sd15" else "tiny"), dev)
     vae.params.init_synthetic(seed=1)
+    if L.DATAPATH != "fp32":
+        unet.params.pack_bf16(bwd=False)
+        vae.params.pack_bf16(bwd=False)
     sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", set_alpha_to_one=False, steps_offset=1)
     state = sched.create_state(device=dev)
     pipe = StableDiffusionPipeline(unet, vae, sched)
@@ -159,13 +166,19 @@ def main():
         unet(lat2, ts2, ctx2)
         torch.cuda.synchronize()
         recs, L.PROFILE = L.PROFILE, None
+        dom = args.datapath if any(r[3] == args.datapath for r in recs) else "fp32"
+        recs = [r for r in recs if r[3] == dom]                    # the dominant kernel family of this datapath
         flops = sum(r[2] for r in recs)
         ms = sum(r[0].elapsed_time(r[1]) for r in recs)
         achieved = flops / (ms * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": "gemm_conv_kernel (v_mfma_f32_32x32x2_f32)", "achieved": achieved,
-                    "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
-                    "launches": len(recs), "avg_launch_ms": ms / max(len(recs), 1),
-                    "algorithmic_gflop_per_launch": flops / max(len(recs), 1) / 1e9}
+        passes = {"fp32": 1, "bf16": 1, "bf16x3": 3}[dom]
+        peak = FP32_MFMA_PEAK_TFLOPS if dom == "fp32" else BF16_MFMA_PEAK_TFLOPS
+        kname = "gemm_conv_kernel (v_mfma_f32_32x32x2_f32)" if dom == "fp32" else \
+            f"gemm_conv_bf16_kernel<NPASS={passes}> (v_mfma_f32_32x32x16_bf16)"
+        roofline = {"bound": "mfma", "kernel": kname, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                    "frac": achieved / peak, "traffic": None, "launches": len(recs), "avg_launch_ms": ms / max(len(recs), 1),
+                    "algorithmic_gflop_per_launch": flops / max(len(recs), 1) / 1e9,
+                    "mfma_passes_per_algorithmic_flop": passes, "mfma_issue_frac": passes * achieved / peak}
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -179,11 +192,16 @@ def main():
     out = {
         "metric": "sampled images/sec (512^2, 50 DDIM steps)", "value": value, "unit": "images/sec", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": {"fp32": "f32", "bf16x3": "f32 (bf16x3-split MFMA)", "bf16": "bf16 products, f32 accumulate"}[args.datapath],
+        "data": "synthetic",
         "config": {"workload": f"BASELINE configs[1]: compressed-animals geometry, {args.model} U-Net+VAE (random init), "
                                f"{args.resolution}x{args.resolution}, {args.n_inference_steps} DDIM steps, CFG 5.0, eta 1.0, "
                                f"sample_batch_size {B}/GPU, VAE decode included",
-                   "datapath": "exact-fp32 MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4_f32)", "parallelism": f"dp{world}",
+                   "datapath": {"fp32": "exact-fp32 MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4_f32)",
+                                "bf16x3": "conv/GEMM: bf16x3-split MFMA (a_lo*b_hi + a_hi*b_lo + a_hi*b_hi, fp32 accumulate, ~1e-5 rel; "
+                                          "= XLA HIGH, the reference ran TPU DEFAULT = 1 pass); attention/norms: exact fp32",
+                                "bf16": "conv/GEMM: single-pass bf16 MFMA, fp32 accumulate (= XLA TPU DEFAULT precision)"}[args.datapath],
+                   "parallelism": f"dp{world}",
                    "global_batch": world * B},
         "end_to_end_tflops": None if tflop_per_image is None else value * tflop_per_image,
         "roofline": roofline, "cpu_baseline": cpu,

@@ -65,6 +65,10 @@ def load_unet(loadpath=None, epoch="latest", pretrained_model="duongna/stable-di
         if ck:
             print(f"[ utils/serialization ] loading fine-tuned U-Net from {ck}")
             _load_safetensors_into(unet.params, ck)
+    from .. import lib as L
+    if L.DATAPATH != "fp32":          # bf16-split MFMA datapath: pre-split the contraction weights once
+        unet.params.pack_bf16()
+        vae.params.pack_bf16(bwd=False)
     tokenizer = load_tokenizer(local)
     text_encoder = TextEncoder(local, hidden=ucfg.cross_attention_dim, device=device, seed=seed + 2)
     pred = ucfg.prediction_type
