@@ -35,10 +35,12 @@ __device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo) {
 
 __device__ __forceinline__ int swz_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }   // bytes
 
-template <int BM, int BN, int NPASS>
+// AFFINE: no upsampling / zero-insert in the gather, so the source address of tap (ky,kx) is rowptr + (ky*W + kx)*ld + ci
+// and all per-k-tile work is a mask test and one 64-bit add per row (the generic path recomputes coordinates).
+template <int BM, int BN, int NPASS, bool AFFINE>
 __global__ void __launch_bounds__(BF_THREADS) gemm_conv_bf16_kernel(const ddpo_gemm_desc d, const uint16_t* __restrict__ w_hi,
-                                                                   const uint16_t* __restrict__ w_lo, int ldw, int tiles_n,
-                                                                   int nblk) {
+                                                                   const uint16_t* __restrict__ w_lo, int ldw, int tiles_m,
+                                                                   int tiles_n, int nblk) {
   constexpr int BK = BF_BK;
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int AROWS = BM / 32;                 // float4 chunks per thread (A tile)
@@ -46,18 +48,24 @@ __global__ void __launch_bounds__(BF_THREADS) gemm_conv_bf16_kernel(const ddpo_g
   constexpr int NPL = (NPASS == 3) ? 2 : 1;      // planes per operand
   constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // layout per stage: A_hi | A_lo | B_hi | B_lo
-  constexpr int STAGE = NPL * (A_BYTES + B_BYTES);
+  constexpr int STAGE = NPL * (A_BYTES + B_BYTES);      // per stage: A_hi | A_lo | B_hi | B_lo
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
   const int wm = wid >> 1, wn = wid & 1;
 
+  // block -> tile: XCD-contiguous chunks (bijective remap), then GROUP_M x tiles_n super-rows swept m-fastest, so the
+  // ~64 blocks resident on one XCD cover a compact 2-D patch and share both A and W panels in that XCD's L2
   int bid = blockIdx.x;
   {
     const int xcd = bid & 7, idx = bid >> 3;
     const int q = nblk >> 3, r = nblk & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+  constexpr int GROUP_M = 8;
+  const int per_group = GROUP_M * tiles_n;
+  const int group = bid / per_group, in_group = bid - group * per_group;
+  const int gm0 = group * GROUP_M;
+  const int gsz = min(tiles_m - gm0, GROUP_M);
+  const int tile_n = in_group / gsz, tile_m = gm0 + (in_group - tile_n * gsz);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const bool conv = d.ksize > 0;
@@ -66,96 +74,130 @@ __global__ void __launch_bounds__(BF_THREADS) gemm_conv_bf16_kernel(const ddpo_g
 
   // ---- A loader: thread owns float4 index kq (k = 4*kq..) of rows (t>>3) + 32*i
   const int kq = t & 7;
+  const float* arow_ptr[AROWS];     // AFFINE conv: &src[pixel(oy*s-pad, ox*s-pad)][0] (may point outside; masked); dense: &src[m][0]
+  uint32_t amask[AROWS];            // bit tap = that tap is inside the image (and the row is a real row)
+  int aiy0[AROWS], aix0[AROWS];     // generic path
   int64_t abase[AROWS];
-  int aiy0[AROWS], aix0[AROWS];
-  bool avalid[AROWS];
 #pragma unroll
   for (int i = 0; i < AROWS; ++i) {
     const int m = m0 + (t >> 3) + 32 * i;
-    avalid[i] = m < d.M;
+    const bool valid = m < d.M;
+    amask[i] = 0;
     if (conv) {
       const int ohw = d.OH * d.OW;
-      const int mm = avalid[i] ? m : 0;
+      const int mm = valid ? m : 0;
       const int b = mm / ohw, rem = mm - b * ohw;
       const int oy = rem / d.OW, ox = rem - oy * d.OW;
+      const int iy0 = oy * d.stride - d.pad, ix0 = ox * d.stride - d.pad;
       abase[i] = (int64_t)b * d.H * d.W;
-      aiy0[i] = oy * d.stride - d.pad;
-      aix0[i] = ox * d.stride - d.pad;
+      aiy0[i] = iy0; aix0[i] = ix0;
+      arow_ptr[i] = d.src + (abase[i] + (int64_t)iy0 * d.W + ix0) * d.ld_src;
+      if (AFFINE && valid) {
+        for (int ky = 0; ky < d.ksize; ++ky)
+          for (int kx = 0; kx < d.ksize; ++kx)
+            if (iy0 + ky >= 0 && iy0 + ky < d.H && ix0 + kx >= 0 && ix0 + kx < d.W) amask[i] |= 1u << (ky * d.ksize + kx);
+      }
     } else {
-      abase[i] = (int64_t)m * d.ld_src;
-      aiy0[i] = aix0[i] = 0;
+      abase[i] = 0; aiy0[i] = aix0[i] = 0;
+      arow_ptr[i] = d.src + (int64_t)m * d.ld_src;
+      amask[i] = valid ? 1u : 0u;
     }
   }
+  // running (tap, ci) of this thread's k quad; advanced by BK per k-tile without divisions
+  int a_tap = 0, a_ci = kq * 4;
+  if (conv) { a_tap = a_ci / d.Cin; a_ci -= a_tap * d.Cin; }
   // ---- W loader: thread owns 16-byte chunk bc (8 bf16 of k) of rows (t>>2) + 64*i
   const int bc = t & 3;
+  int b_tap = 0, b_co = bc * 8;
+  if (d.w_dgrad) { b_tap = b_co / d.Cin; b_co -= b_tap * d.Cin; }
+  const int ntaps = conv ? d.ksize * d.ksize : 1;
 
-  float4 ra[AROWS];
-  uint4 rbh[BCH], rbl[BCH];
+  struct Stage { float4 a[AROWS]; uint4 bh[BCH], bl[BCH]; };
+  Stage s0, s1;       // two register stages: global loads run two k-tiles ahead of the MFMAs that consume them
 
-  auto load_tile = [&](int kt) {
-    const int kg = kt * BK + kq * 4;
-    int ky = 0, kx = 0, ci = kg;
+  auto load_tile = [&](int kt, Stage& sg) {
+    // ---- A
+    const bool kval = (kt * BK + kq * 4) < d.K;
     if (conv) {
-      const int tap = kg / d.Cin;
-      ci = kg - tap * d.Cin;
-      ky = tap / d.ksize;
-      kx = tap - ky * d.ksize;
-    }
-    const bool kval = kg < d.K;
+      const int ky = (a_tap * 11) >> 5;                 // a_tap / 3 for a_tap < 32 (ksize 3); ksize 1 -> tap 0
+      const int kyy = d.ksize == 3 ? ky : 0;
+      const int kxx = d.ksize == 3 ? a_tap - ky * 3 : 0;
+      if (AFFINE) {
+        const int toff = (kyy * d.W + kxx) * d.ld_src + a_ci;
 #pragma unroll
-    for (int i = 0; i < AROWS; ++i) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (conv) {
-        const int iy = aiy0[i] + ky, ix = aix0[i] + kx;
-        if (avalid[i] && kval && iy >= 0 && iy < VH && ix >= 0 && ix < VW && !(zins && ((iy | ix) & 1))) {
-          const int sy = d.upsample ? (iy >> 1) : iy, sx = d.upsample ? (ix >> 1) : ix;
-          v = *reinterpret_cast<const float4*>(d.src + (abase[i] + (int64_t)sy * d.W + sx) * d.ld_src + ci);
+        for (int i = 0; i < AROWS; ++i) {
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (kval && ((amask[i] >> a_tap) & 1u)) v = *reinterpret_cast<const float4*>(arow_ptr[i] + toff);
+          sg.a[i] = v;
         }
-      } else if (avalid[i] && kval) {
-        v = *reinterpret_cast<const float4*>(d.src + abase[i] + kg);
+      } else {
+#pragma unroll
+        for (int i = 0; i < AROWS; ++i) {
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          const int m = m0 + (t >> 3) + 32 * i;
+          const int iy = aiy0[i] + kyy, ix = aix0[i] + kxx;
+          if (m < d.M && kval && iy >= 0 && iy < VH && ix >= 0 && ix < VW && !(zins && ((iy | ix) & 1))) {
+            const int sy = d.upsample ? (iy >> 1) : iy, sx = d.upsample ? (ix >> 1) : ix;
+            v = *reinterpret_cast<const float4*>(d.src + (abase[i] + (int64_t)sy * d.W + sx) * d.ld_src + a_ci);
+          }
+          sg.a[i] = v;
+        }
       }
-      ra[i] = v;
+      a_ci += BK;
+      while (a_ci >= d.Cin) { a_ci -= d.Cin; ++a_tap; }
+    } else {
+      const int kg = kt * BK + kq * 4;
+#pragma unroll
+      for (int i = 0; i < AROWS; ++i) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (kval && amask[i]) v = *reinterpret_cast<const float4*>(arow_ptr[i] + kg);
+        sg.a[i] = v;
+      }
     }
-    const int kb = kt * BK + bc * 8;             // first k of this thread's 8-wide W chunk
+    // ---- W
+    const int kb = kt * BK + bc * 8;
+    const bool bval = kb < d.K;
 #pragma unroll
     for (int i = 0; i < BCH; ++i) {
       const int n = n0 + (t >> 2) + 64 * i;
       uint4 h = make_uint4(0u, 0u, 0u, 0u), l = h;
-      if (n < d.N && kb < d.K) {
+      if (n < d.N && bval) {
         int64_t off;
-        if (d.w_dgrad) {   // planes in the forward [K][N] order = [tap][ci_fwd = n][co_fwd]: flipped tap, co contiguous
-          const int tap = kb / d.Cin, co = kb - tap * d.Cin;
-          const int tapf = d.ksize * d.ksize - 1 - tap;
-          off = ((int64_t)tapf * d.N + n) * d.Cin + co;
-        } else {
-          off = (int64_t)n * ldw + kb;
-        }
+        if (d.w_dgrad) off = ((int64_t)(ntaps - 1 - b_tap) * d.N + n) * d.Cin + b_co;   // forward [tap][ci=n][co] order, flipped tap
+        else off = (int64_t)n * ldw + kb;
         h = *reinterpret_cast<const uint4*>(w_hi + off);
         if (NPASS == 3) l = *reinterpret_cast<const uint4*>(w_lo + off);
       }
-      rbh[i] = h;
-      rbl[i] = l;
+      sg.bh[i] = h;
+      sg.bl[i] = l;
+    }
+    if (d.w_dgrad) {
+      b_co += BK;
+      while (b_co >= d.Cin) { b_co -= d.Cin; ++b_tap; }
     }
   };
 
-  auto store_tile = [&](int buf) {
+  // LDS offsets are loop invariant
+  int a_st[AROWS], b_st[BCH];
+#pragma unroll
+  for (int i = 0; i < AROWS; ++i) a_st[i] = swz_off((t >> 3) + 32 * i, kq >> 1) + (kq & 1) * 8;
+#pragma unroll
+  for (int i = 0; i < BCH; ++i) b_st[i] = swz_off((t >> 2) + 64 * i, bc);
+
+  auto store_tile = [&](int buf, const Stage& sg) {
     char* st = smem + buf * STAGE;
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
-      const int row = (t >> 3) + 32 * i;
       uint2 hi, lo;
-      split4(ra[i], hi, lo);
-      const int off = swz_off(row, kq >> 1) + (kq & 1) * 8;
-      *reinterpret_cast<uint2*>(st + off) = hi;
-      if (NPASS == 3) *reinterpret_cast<uint2*>(st + A_BYTES + off) = lo;
+      split4(sg.a[i], hi, lo);
+      *reinterpret_cast<uint2*>(st + a_st[i]) = hi;
+      if (NPASS == 3) *reinterpret_cast<uint2*>(st + A_BYTES + a_st[i]) = lo;
     }
     char* sb = st + NPL * A_BYTES;
 #pragma unroll
     for (int i = 0; i < BCH; ++i) {
-      const int row = (t >> 2) + 64 * i;
-      const int off = swz_off(row, bc);
-      *reinterpret_cast<uint4*>(sb + off) = rbh[i];
-      if (NPASS == 3) *reinterpret_cast<uint4*>(sb + B_BYTES + off) = rbl[i];
+      *reinterpret_cast<uint4*>(sb + b_st[i]) = sg.bh[i];
+      if (NPASS == 3) *reinterpret_cast<uint4*>(sb + B_BYTES + b_st[i]) = sg.bl[i];
     }
   };
 
@@ -168,34 +210,31 @@ __global__ void __launch_bounds__(BF_THREADS) gemm_conv_bf16_kernel(const ddpo_g
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nk = (d.K + BK - 1) / BK;
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
-
-  const int arow = wm * (BM / 2) + (lane & 31);
-  const int brow = wn * (BN / 2) + (lane & 31);
   const int khalf = lane >> 5;
+  int a_ld[BK / 16][TM], b_ld[BK / 16][TN];
+#pragma unroll
+  for (int ks = 0; ks < BK / 16; ++ks) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a_ld[ks][i] = swz_off(wm * (BM / 2) + i * 32 + (lane & 31), ks * 2 + khalf);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b_ld[ks][j] = swz_off(wn * (BN / 2) + j * 32 + (lane & 31), ks * 2 + khalf);
+  }
 
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) load_tile(kt + 1);
+  auto compute = [&](int cur) {
     const char* sa = smem + cur * STAGE;
     const char* sb = sa + NPL * A_BYTES;
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
-      const int chunk = ks * 2 + khalf;
       bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        const int off = swz_off(arow + i * 32, chunk);
-        ah[i] = *reinterpret_cast<const bf16x8*>(sa + off);
-        if (NPASS == 3) al[i] = *reinterpret_cast<const bf16x8*>(sa + A_BYTES + off);
+        ah[i] = *reinterpret_cast<const bf16x8*>(sa + a_ld[ks][i]);
+        if (NPASS == 3) al[i] = *reinterpret_cast<const bf16x8*>(sa + A_BYTES + a_ld[ks][i]);
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const int off = swz_off(brow + j * 32, chunk);
-        bh[j] = *reinterpret_cast<const bf16x8*>(sb + off);
-        if (NPASS == 3) bl[j] = *reinterpret_cast<const bf16x8*>(sb + B_BYTES + off);
+        bh[j] = *reinterpret_cast<const bf16x8*>(sb + b_ld[ks][j]);
+        if (NPASS == 3) bl[j] = *reinterpret_cast<const bf16x8*>(sb + B_BYTES + b_ld[ks][j]);
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -208,7 +247,24 @@ __global__ void __launch_bounds__(BF_THREADS) gemm_conv_bf16_kernel(const ddpo_g
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
     }
-    if (kt + 1 < nk) store_tile(cur ^ 1);
+  };
+
+  // prologue: tile 0 -> LDS[0]; tile 1 in flight in s0.  Tiles past the end load as zeros (kval / bval guards), so the
+  // loop runs an even number of steps without a mid-body exit (keeps ONE copy of the accumulators live).
+  load_tile(0, s0);
+  store_tile(0, s0);
+  load_tile(1, s0);
+  __syncthreads();
+  const int nk2 = (nk + 1) & ~1;
+#pragma unroll 1
+  for (int kt = 0; kt < nk2; kt += 2) {
+    load_tile(kt + 2, s1);          // even step: MFMAs on LDS[0]; s0 holds tile kt+1, tile kt+2 starts loading into s1
+    compute(0);
+    store_tile(1, s0);
+    __syncthreads();
+    load_tile(kt + 3, s0);          // odd step: MFMAs on LDS[1]; s1 holds tile kt+2, tile kt+3 starts loading into s0
+    compute(1);
+    store_tile(0, s1);
     __syncthreads();
   }
 
@@ -240,11 +296,18 @@ static int launch_bf16(const ddpo_gemm_desc& d, const uint16_t* w_hi, const uint
   const size_t lds = 2 * NPL * (size_t)(BM + BN) * 64;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_bf16_kernel<BM, BN, NPASS>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_bf16_kernel<BM, BN, NPASS, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_bf16_kernel<BM, BN, NPASS, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_conv_bf16_kernel<BM, BN, NPASS>), dim3(nblk), dim3(BF_THREADS), lds, st, d, w_hi, w_lo, ldw, tiles_n, nblk);
+  if (d.upsample == 0)
+    hipLaunchKernelGGL((gemm_conv_bf16_kernel<BM, BN, NPASS, true>), dim3(nblk), dim3(BF_THREADS), lds, st, d, w_hi, w_lo, ldw,
+                       tiles_m, tiles_n, nblk);
+  else
+    hipLaunchKernelGGL((gemm_conv_bf16_kernel<BM, BN, NPASS, false>), dim3(nblk), dim3(BF_THREADS), lds, st, d, w_hi, w_lo, ldw,
+                       tiles_m, tiles_n, nblk);
   DDPO_LAUNCH_CHECK();
   return DDPO_OK;
 }
