@@ -1,0 +1,217 @@
+// Flash attention forward on the bf16 MFMA datapath (v_mfma_f32_32x32x16_bf16) with every operand (Q, K, V and the
+// probabilities P) split into bf16 hi + lo and three MFMA passes per product (a_lo*b_hi + a_hi*b_lo + a_hi*b_hi, fp32
+// accumulate) — the same "bf16x3" arithmetic as gemm_bf16.hip, ~1e-5 relative.  Structure mirrors attention.hip:
+//   S^T (keys x queries) = K Q^T : A = K tile (LDS, [key][dk] bf16), B = Q^T (registers, pre-scaled by scale*log2 e)
+//   O^T (d x queries)    = V^T P^T: A = V^T tile (LDS, [d][key] bf16, transposed while it is staged), B = P^T
+// One workgroup = 4 waves x 32 queries; the 32x32 C fragment of S^T (row = key, col = query = lane&31) is converted
+// in registers to the B operand of the second product: for lane half h the 8 k-slots of MFMA step u are the keys
+// 16u + 4h + {0,1,2,3, 8,9,10,11} (exactly the rows that half holds), and the V^T fragment is read with the same map.
+#include "common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ uint32_t cvt_pk_bf16_a(float lo, float hi) {
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+// two floats -> packed bf16 hi pair and packed bf16 lo pair
+__device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+  hi = cvt_pk_bf16_a(a, b);
+  lo = cvt_pk_bf16_a(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xFFFF0000u));
+}
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+template <int D, int DKP, int DVP>     // head dim, padded to 16 (QK^T reduction) and to 32 (rows of O^T)
+__global__ void __launch_bounds__(256) attn_fwd_bf16_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
+                                                            const float* __restrict__ v, int ldv, float* __restrict__ o, int ldo,
+                                                            float* __restrict__ lse, int heads, int Nq, int Nk, float scale_log2e) {
+  constexpr int KT = 64;                  // keys per tile
+  constexpr int LDK = DKP + 8;            // bf16 per K row: (DKP+8)*2 bytes = odd multiple of 16 B -> conflict-free b128 rows
+  constexpr int LDVT = KT + 4;            // bf16 per V^T row: 136 B -> 32 rows hit distinct even banks for ds_read_b64
+  constexpr int NKS = DKP / 16;           // k-steps of S^T
+  constexpr int NDT = DVP / 32;           // 32-row tiles of O^T
+  constexpr int K_BYTES = KT * LDK * 2, VT_BYTES = DVP * LDVT * 2;
+  __shared__ __attribute__((aligned(16))) char smem[2 * K_BYTES + 2 * VT_BYTES];
+  char* Khi = smem; char* Klo = smem + K_BYTES;
+  char* Vhi = smem + 2 * K_BYTES; char* Vlo = Vhi + VT_BYTES;
+
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+  const int li = lane & 31, h = lane >> 5;
+  const int bh = blockIdx.y, b = bh / heads, hd = bh - b * heads;
+  const int q0 = blockIdx.x * 128 + wid * 32;
+  const int qrow = min(q0 + li, Nq - 1);
+
+  // Q^T fragments (B operand): lane holds Q[q = li][dk = 16s + 8h .. +8], scaled, split
+  bf16x8 qh[NKS], ql[NKS];
+  {
+    const float* qp = q + ((int64_t)b * Nq + qrow) * ldq + hd * D;
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) {
+      uint32_t hi[4], lo[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int dk = 16 * s + 8 * h + 2 * e;
+        const float a = dk < D ? qp[dk] * scale_log2e : 0.f;
+        const float c = dk + 1 < D ? qp[dk + 1] * scale_log2e : 0.f;
+        split2(a, c, hi[e], lo[e]);
+      }
+      qh[s] = __builtin_bit_cast(bf16x8, make_uint4(hi[0], hi[1], hi[2], hi[3]));
+      ql[s] = __builtin_bit_cast(bf16x8, make_uint4(lo[0], lo[1], lo[2], lo[3]));
+    }
+  }
+  // zero the padding of both LDS images once (K columns D..DKP, V^T rows D..DVP are never written again)
+  for (int i = t; i < (2 * K_BYTES + 2 * VT_BYTES) / 16; i += 256) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0u, 0u, 0u, 0u);
+
+  f32x16 oacc[NDT];
+#pragma unroll
+  for (int n = 0; n < NDT; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[n][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const float* kb = k + (int64_t)b * Nk * ldk + hd * D;
+  const float* vb = v + (int64_t)b * Nk * ldv + hd * D;
+
+  for (int kt0 = 0; kt0 < Nk; kt0 += KT) {
+    __syncthreads();
+    // stage K (row-major) and V (transposed) as bf16 hi / lo
+    for (int i = t; i < KT * (D / 4); i += 256) {
+      const int key = i / (D / 4), c4 = i - key * (D / 4);
+      float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+      if (kt0 + key < Nk) {
+        kv = *reinterpret_cast<const float4*>(kb + (int64_t)(kt0 + key) * ldk + c4 * 4);
+        vv = *reinterpret_cast<const float4*>(vb + (int64_t)(kt0 + key) * ldv + c4 * 4);
+      }
+      uint32_t h0, l0, h1, l1;
+      split2(kv.x, kv.y, h0, l0);
+      split2(kv.z, kv.w, h1, l1);
+      *reinterpret_cast<uint2*>(Khi + (key * LDK + c4 * 4) * 2) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2*>(Klo + (key * LDK + c4 * 4) * 2) = make_uint2(l0, l1);
+      split2(vv.x, vv.y, h0, l0);
+      split2(vv.z, vv.w, h1, l1);
+      uint16_t* vh = reinterpret_cast<uint16_t*>(Vhi);
+      uint16_t* vl = reinterpret_cast<uint16_t*>(Vlo);
+      const int d0 = c4 * 4;
+      vh[(d0 + 0) * LDVT + key] = (uint16_t)(h0 & 0xFFFFu); vh[(d0 + 1) * LDVT + key] = (uint16_t)(h0 >> 16);
+      vh[(d0 + 2) * LDVT + key] = (uint16_t)(h1 & 0xFFFFu); vh[(d0 + 3) * LDVT + key] = (uint16_t)(h1 >> 16);
+      vl[(d0 + 0) * LDVT + key] = (uint16_t)(l0 & 0xFFFFu); vl[(d0 + 1) * LDVT + key] = (uint16_t)(l0 >> 16);
+      vl[(d0 + 2) * LDVT + key] = (uint16_t)(l1 & 0xFFFFu); vl[(d0 + 3) * LDVT + key] = (uint16_t)(l1 >> 16);
+    }
+    __syncthreads();
+
+    // ---- S^T = K Q^T for the two 32-key sub-tiles
+    f32x16 sacc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[j][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int off = ((j * 32 + li) * LDK + 16 * s + 8 * h) * 2;
+        const bf16x8 kh = *reinterpret_cast<const bf16x8*>(Khi + off);
+        const bf16x8 kl = *reinterpret_cast<const bf16x8*>(Klo + off);
+        sacc[j] = MFMA32(kl, qh[s], sacc[j]);
+        sacc[j] = MFMA32(kh, ql[s], sacc[j]);
+        sacc[j] = MFMA32(kh, qh[s], sacc[j]);
+      }
+    }
+    // ---- online softmax: query = lane column; this lane holds keys 32j + (r&3) + 8(r>>2) + 4h
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (kt0 + 32 * j + (r & 3) + 8 * (r >> 2) + 4 * h >= Nk) sacc[j][r] = -INFINITY;
+        mx = fmaxf(mx, sacc[j][r]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = exp2f(m_run - m_new);
+    m_run = m_new;
+    float ls = 0.f;
+    // P^T as B-operand fragments: step u = 2j + (r>>3) uses registers 8(u&1) .. +8 of sub-tile j
+    bf16x8 ph[4], pl[4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        uint32_t hi[4], lo[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float p0 = exp2f(sacc[j][8 * half + 2 * e] - m_new);
+          const float p1 = exp2f(sacc[j][8 * half + 2 * e + 1] - m_new);
+          ls += p0 + p1;
+          split2(p0, p1, hi[e], lo[e]);
+        }
+        ph[2 * j + half] = __builtin_bit_cast(bf16x8, make_uint4(hi[0], hi[1], hi[2], hi[3]));
+        pl[2 * j + half] = __builtin_bit_cast(bf16x8, make_uint4(lo[0], lo[1], lo[2], lo[3]));
+      }
+    }
+    l_run = l_run * alpha + ls;
+#pragma unroll
+    for (int n = 0; n < NDT; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[n][r] *= alpha;
+    // ---- O^T += V^T P^T ; A fragment of step u: V^T[d = 32n + li][16u + 4h + {0..3, 8..11}]
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int n = 0; n < NDT; ++n) {
+        const int off = ((32 * n + li) * LDVT + 16 * u + 4 * h) * 2;
+        const uint2 a0 = *reinterpret_cast<const uint2*>(Vhi + off), a1 = *reinterpret_cast<const uint2*>(Vhi + off + 16);
+        const uint2 c0 = *reinterpret_cast<const uint2*>(Vlo + off), c1 = *reinterpret_cast<const uint2*>(Vlo + off + 16);
+        const bf16x8 vh = __builtin_bit_cast(bf16x8, make_uint4(a0.x, a0.y, a1.x, a1.y));
+        const bf16x8 vl = __builtin_bit_cast(bf16x8, make_uint4(c0.x, c0.y, c1.x, c1.y));
+        oacc[n] = MFMA32(vl, ph[u], oacc[n]);
+        oacc[n] = MFMA32(vh, pl[u], oacc[n]);
+        oacc[n] = MFMA32(vh, ph[u], oacc[n]);
+      }
+    }
+  }
+
+  float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  if (lse && h == 0 && q0 + li < Nq) lse[(int64_t)bh * Nq + q0 + li] = m_run + log2f(l_tot);
+  if (q0 + li < Nq) {
+    float* op = o + ((int64_t)b * Nq + q0 + li) * ldo + hd * D;
+#pragma unroll
+    for (int n = 0; n < NDT; ++n) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {          // registers 4g..4g+3 are rows 32n + 8g + 4h + {0,1,2,3}
+        const int dc = 32 * n + 8 * g + 4 * h;
+        if (dc < D) *reinterpret_cast<float4*>(op + dc) =
+            make_float4(oacc[n][4 * g] * inv, oacc[n][4 * g + 1] * inv, oacc[n][4 * g + 2] * inv, oacc[n][4 * g + 3] * inv);
+      }
+    }
+  }
+}
+
+template <int D, int DKP, int DVP>
+static int launch_attn_bf16(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo, float* lse,
+                            int B, int heads, int Nq, int Nk, float scale, hipStream_t st) {
+  dim3 grid((Nq + 127) / 128, B * heads);
+  hipLaunchKernelGGL((attn_fwd_bf16_kernel<D, DKP, DVP>), grid, dim3(256), 0, st, q, ldq, k, ldk, v, ldv, o, ldo, lse, heads, Nq, Nk,
+                     scale * 1.4426950408889634f);
+  DDPO_LAUNCH_CHECK();
+  return DDPO_OK;
+}
+
+extern "C" int ddpo_attention_fwd_bf16x3(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
+                                         float* lse, int B, int heads, int Nq, int Nk, int d, float scale, void* stream) {
+  if (!q || !k || !v || !o || B <= 0 || heads <= 0 || Nq <= 0 || Nk <= 0) return DDPO_EINVAL;
+  if ((ldq & 3) || (ldk & 3) || (ldv & 3) || (ldo & 3) || (long)B * heads > 65535) return DDPO_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v) |
+       reinterpret_cast<uintptr_t>(o)) & 15) return DDPO_EINVAL;
+  hipStream_t st = as_stream(stream);
+  switch (d) {
+    case 8:  return launch_attn_bf16<8, 16, 32>(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, heads, Nq, Nk, scale, st);
+    case 16: return launch_attn_bf16<16, 16, 32>(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, heads, Nq, Nk, scale, st);
+    case 40: return launch_attn_bf16<40, 48, 64>(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, heads, Nq, Nk, scale, st);
+    case 64: return launch_attn_bf16<64, 64, 64>(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, heads, Nq, Nk, scale, st);
+    case 80: return launch_attn_bf16<80, 80, 96>(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, heads, Nq, Nk, scale, st);
+    default: return DDPO_EINVAL;      // other head dims stay on the exact-fp32 kernel
+  }
+}

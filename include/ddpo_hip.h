@@ -159,6 +159,11 @@ int ddpo_pack_weights_bf16(const float* w, int K, int N, int Kp, uint16_t* fwd_h
 int ddpo_attention_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
                        float* o, int ldo, float* lse, int B, int heads, int Nq, int Nk, int d, float scale,
                        void* stream);
+/* Same contract on the bf16 MFMA datapath: Q, K, V and the probabilities are split into bf16 hi + lo and every
+ * product takes three passes (fp32 accumulate, ~1e-5 relative).  d in {8, 16, 40, 64, 80}. */
+int ddpo_attention_fwd_bf16x3(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                              float* o, int ldo, float* lse, int B, int heads, int Nq, int Nk, int d, float scale,
+                              void* stream);
 /* Attention backward with probability recomputation (no N x N tensor is ever materialised):
  * dvec (B,heads,Nq) scratch = rowsum(dO * O); dq/dk/dv have the layout of q/k/v with contiguous rows of heads*d. */
 int ddpo_attention_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o,

@@ -121,3 +121,19 @@ def test_unet_and_train_step_bf16(datapath, mode, tol):
     gn = math.sqrt(float((unet.grads.flat.double() ** 2).sum()))
     assert gn == pytest.approx(gn_o, rel=tol)
     assert float(info["loss"]) == pytest.approx(oinfo["loss"], rel=tol, abs=1e-6)
+
+
+@pytest.mark.parametrize("B,heads,Nq,Nk,d", [(2, 8, 64, 64, 8), (1, 8, 200, 77, 16), (2, 8, 1024, 1024, 40), (2, 8, 1024, 77, 40),
+                                             (1, 8, 256, 256, 80), (1, 5, 130, 333, 64), (1, 8, 4096, 4096, 40)])
+def test_attention_bf16x3(datapath, B, heads, Nq, Nk, d):
+    L.DATAPATH = "bf16x3"
+    g = torch.Generator().manual_seed(Nq + Nk + d)
+    C = heads * d
+    q, k, v = torch.randn(B * Nq, C, generator=g), torch.randn(B * Nk, C, generator=g), torch.randn(B * Nk, C, generator=g)
+    k[min(50, Nk - 1)] = q[3] * 3.0                      # a late spike exercises the running-max rescale
+    out, lse = L.attention(q.to(DEV), k.to(DEV), v.to(DEV), B, heads, Nq, Nk, d, return_lse=True)
+    sp = lambda t, n: t.view(B, n, heads, d).permute(0, 2, 1, 3).double()
+    s_ = sp(q, Nq) @ sp(k, Nk).transpose(-1, -2) * d ** -0.5
+    ref = (torch.softmax(s_, -1) @ sp(v, Nk)).permute(0, 2, 1, 3).reshape(B * Nq, C)
+    assert _rel(out, ref) < 1e-4
+    assert _rel(lse.view(B, heads, Nq), torch.logsumexp(s_, -1) / math.log(2.0)) < 1e-4
