@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--sample-batch-size", type=int, default=8)
     ap.add_argument("--datapath", default=os.environ.get("DDPO_DATAPATH", "bf16x3"), choices=["fp32", "bf16x3", "bf16"],
                     help="contraction datapath: exact-fp32 MFMA, bf16-split MFMA x3 (fp32-accurate to ~1e-5, default), single-pass bf16")
+    ap.add_argument("--no-graph", action="store_true", help="launch the U-Net kernels eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -128,7 +129,8 @@ def main():
         sample_rng, sample_seed = prng.split(sample_rng)
         key = prng.split(sample_seed, world)[rank]
         final, lat, nxt, lps, ts = pipe(emb, neg, {"unet": unet.params, "scheduler": state}, key, args.n_inference_steps,
-                                        height=args.resolution, width=args.resolution, guidance_scale=5.0, eta=1.0)
+                                        height=args.resolution, width=args.resolution, guidance_scale=5.0, eta=1.0,
+                                        jit=not args.no_graph)
         img = vae.decode(final)
         return img, lps
 

@@ -39,7 +39,7 @@ class StableDiffusionPipeline:
         return text_input.input_ids
 
     def _generate(self, prompt_embeds, neg_prompt_embeds, params, rng, num_inference_steps, height, width,
-                  guidance_scale, eta, latents=None):
+                  guidance_scale, eta, latents=None, jit=False):
         assert isinstance(self.scheduler, DDIMScheduler)
         if height % 8 != 0 or width % 8 != 0:
             raise ValueError(f"`height` and `width` have to be divisible by 8 but are {height} and {width}.")
@@ -76,11 +76,13 @@ class StableDiffusionPipeline:
         consts = self.scheduler.kernel_consts(state, eta)
         z = torch.empty(shape, dtype=torch.float32, device=dev)
         lat2 = torch.empty((2 * B,) + shape[1:], dtype=torch.float32, device=dev)
+        # jit=True (the reference's pmapped/jitted path): replay the U-Net as a captured HIP graph
+        unet_fwd = self.unet.forward_graphed if jit else self.unet
         for s in range(T):
             x = traj[s]
             lat2[:B].copy_(x)                                       # jnp.concatenate([old_latents] * 2)
             lat2[B:].copy_(x)
-            noise_pred = self.unet(lat2, ts_dev[s], context)
+            noise_pred = unet_fwd(lat2, ts_dev[s], context)
             L.threefry_normal(step_keys[s], shape, out=z)
             L.ddim_step_fwd(noise_pred[:B], noise_pred[B:], x, z, ts_dev[s, :B], guidance_scale, consts,
                             x_next=traj[s + 1], logp=log_probs[s])
@@ -105,7 +107,7 @@ class StableDiffusionPipeline:
                 latents = latents[0]
         to_t = lambda a: a if torch.is_tensor(a) else torch.as_tensor(np.asarray(a))
         outs = self._generate(to_t(prompt_embeds), to_t(neg_prompt_embeds), params, prng_seed, num_inference_steps,
-                              height, width, float(guidance_scale), float(eta), latents)
+                              height, width, float(guidance_scale), float(eta), latents, jit=bool(jit))
         if dev_axis:
             outs = tuple(o.unsqueeze(0) for o in outs)
         return outs

@@ -78,6 +78,10 @@ def test_sampler_matches_oracle_config1(tiny):
     assert _rel(final.cpu().numpy(), ofinal) < 1e-3
     assert _rel(nxt.cpu().numpy(), onxt) < 1e-3
     np.testing.assert_allclose(lps.cpu().numpy(), olps, rtol=1e-3, atol=1e-3)
+    # jit=True replays a captured HIP graph of the U-Net: bit-identical to the eager launches
+    outs_g = pipe(emb.to(DEV), neg.to(DEV), {"unet": unet.params, "scheduler": state}, key, 4, height=64, width=64,
+                  guidance_scale=5.0, eta=1.0, jit=True)
+    assert torch.equal(outs_g[0], final) and torch.equal(outs_g[3], lps)
     # leading device axis of the reference's pmap convention is accepted and preserved
     outs = pipe(emb[None].to(DEV), neg[None].to(DEV), {"unet": unet.params, "scheduler": state}, key[None], 4,
                 height=64, width=64, guidance_scale=5.0, eta=1.0)
