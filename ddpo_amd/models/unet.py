@@ -39,6 +39,9 @@ class UNetConfig:
                               prediction_type="v_prediction")
         if name == "tiny":
             return UNetConfig(block_out_channels=(32, 64, 128, 128), cross_attention_dim=64)
+        if name == "tiny21":   # SD-2.1-shaped toy: linear projections, v-prediction, head dim 16 at every level
+            return UNetConfig(block_out_channels=(32, 64, 128, 128), num_heads=(2, 4, 8, 8), cross_attention_dim=96,
+                              use_linear_projection=True, prediction_type="v_prediction")
         raise KeyError(name)
 
 
@@ -367,6 +370,11 @@ class UNet2DCondition:
         B, Cin, H, W = sample.shape
         boc = cfg.block_out_channels
         nlev = len(boc)
+        if H % (1 << (nlev - 1)) or W % (1 << (nlev - 1)) or Cin != cfg.in_channels:
+            raise ValueError(f"latent size {H}x{W} must be divisible by {1 << (nlev - 1)} (the U-Net halves it {nlev - 1} times) "
+                             f"and carry {cfg.in_channels} channels")
+        if context.shape[0] != B or context.shape[2] != cfg.cross_attention_dim or timesteps.shape[0] != B:
+            raise ValueError("context must be (B, L, cross_attention_dim) and timesteps (B,)")
         G = cfg.norm_groups
         Lc = context.shape[1]
         ctx = context.reshape(B * Lc, context.shape[2]).contiguous()

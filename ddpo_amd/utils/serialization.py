@@ -47,7 +47,7 @@ def load_unet(loadpath=None, epoch="latest", pretrained_model="duongna/stable-di
         raise NotImplementedError("this engine computes on the exact-fp32 MFMA datapath; dtype must be float32")
     family = model_family(pretrained_model)
     ucfg = UNetConfig.named(family)
-    vcfg = VAEConfig.named("tiny" if family == "tiny" else "sd")
+    vcfg = VAEConfig.named("tiny" if family.startswith("tiny") else "sd")
     unet, vae = UNet2DCondition(ucfg, device), VAEDecoder(vcfg, device)
     local = pretrained_model if os.path.isdir(str(pretrained_model)) else None
     synthetic = True

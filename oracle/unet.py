@@ -42,6 +42,9 @@ SD15 = UNetCfg()
 SD21 = UNetCfg(attention_head_dim=(5, 10, 20, 20), cross_attention_dim=1024, use_linear_projection=True,
                prediction_type="v_prediction")
 TINY = UNetCfg(block_out_channels=(32, 64, 128, 128), attention_head_dim=(8, 8, 8, 8), cross_attention_dim=64)
+# SD-2.1-shaped toy: linear projections, v-prediction, head counts growing with width (head dim 16 everywhere)
+TINY21 = UNetCfg(block_out_channels=(32, 64, 128, 128), attention_head_dim=(2, 4, 8, 8), cross_attention_dim=96,
+                 use_linear_projection=True, prediction_type="v_prediction")
 
 
 # ------------------------------------------------------------------------------------------------

@@ -59,3 +59,27 @@ def test_entrypoint_two_ranks_share_one_gpu(tmp_path):
     r0 = np.load(tmp_path / "rewards_0.npy")
     r1 = np.load(tmp_path / "rewards_1.npy")
     assert r0.shape == (2, 1) and not np.array_equal(r0, r1)                         # different seeds -> different samples
+
+
+def test_entrypoint_llava_bertscore_with_stub_server(tmp_path, monkeypatch):
+    """BASELINE configs[3] plumbing: nouns_activities prompts + llava_bertscore reward over HTTP against the stub server."""
+    import threading
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import llava_stub_server
+    srv = llava_stub_server.serve(8085)
+    threading.Thread(target=srv.serve_forever, daemon=True).start()
+    try:
+        monkeypatch.setenv("DDPO_MODEL_CONFIG", "tiny")
+        monkeypatch.chdir(tmp_path)
+        import importlib
+        pg = importlib.import_module("pipeline.policy_gradient")
+        out = pg.main(["--dataset", "llava-bertscore", "--resolution", "64", "--n_inference_steps", "4", "--sample_batch_size", "2",
+                       "--train_batch_size", "1", "--train_accumulation_steps", "2", "--num_train_epochs", "1", "--save_freq", "1",
+                       "--per_prompt_stats_min_count", "2", "--logbase", str(tmp_path / "run")])
+        r = np.load(os.path.join(out["localpath"], "rewards/0_0.npy"))
+        info = np.load(os.path.join(out["localpath"], "callback_info/0_0.npy"), allow_pickle=True).item()
+        prompts = np.load(os.path.join(out["localpath"], "prompts/0_0.npy"))
+        assert r.shape == (2,) and set(info) == {"precision", "f1", "outputs"} and all(" " in p for p in prompts)
+        assert out["state"].step == 1                                   # 2 minibatches of 1, accumulation 2 -> one update
+    finally:
+        srv.shutdown()

@@ -107,3 +107,53 @@ def test_unet_sd15_single_sample_64x64():
         ref = OU.unet_forward(op, OU.SD15, x, t, ctx)
     out = unet(x.to(DEV), t.to(DEV), ctx.to(DEV)).cpu()
     assert _rel(out.numpy(), ref.numpy()) < 1e-3
+
+
+@pytest.mark.parametrize("datapath", ["fp32", "bf16x3"])
+def test_sd21_shaped_config_sampler_and_train_step(datapath):
+    """BASELINE configs[4] shape class on the toy scale: SD-2.1 architecture switches (linear proj_in/out, per-level head
+    counts with d_head 16, 96-wide text context) + v-prediction DDIM, sampler and one PPO step against the oracle."""
+    import math
+    from ddpo_amd import lib as L
+    from ddpo_amd.training.policy_gradient import AccumulatingTrainState, AdamWConfig, train_step
+    from oracle.sampler import train_step_grads
+    old = L.DATAPATH
+    L.DATAPATH = datapath
+    try:
+        op = OU.init_params(OU.unet_param_shapes(OU.TINY21), seed=4)
+        unet = UNet2DCondition(UNetConfig.named("tiny21"), DEV)
+        unet.params.load_dict(op)
+        if datapath != "fp32":
+            unet.params.pack_bf16()
+        sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", set_alpha_to_one=False,
+                              steps_offset=1, prediction_type="v_prediction")
+        pipe = StableDiffusionPipeline(unet, None, sched)
+        state = sched.create_state(device=DEV)
+        g = torch.Generator().manual_seed(9)
+        emb = torch.randn(2, 77, 96, generator=g)
+        neg = torch.randn(1, 77, 96, generator=g).expand(2, -1, -1).contiguous()
+        key = OP.PRNGKey(7)
+        final, lat, nxt, lps, ts = pipe(emb.to(DEV), neg.to(DEV), {"unet": unet.params, "scheduler": state}, key, 4,
+                                        height=128, width=128, guidance_scale=5.0, eta=1.0)
+        dd = DDIMOracle(prediction_type="v_prediction")
+        ofinal, olat, onxt, olps, ots = oracle_sample(op, OU.TINY21, dd, dd.create_state(), emb, neg, key, 4, 128, 128, 5.0, 1.0)
+        assert np.array_equal(ts.cpu().numpy(), ots)
+        assert _rel(final.cpu().numpy(), ofinal) < 1e-3
+        np.testing.assert_allclose(lps.cpu().numpy(), olps, rtol=1e-3, atol=1e-3)
+        # one PPO micro-step on the sampled trajectory at timestep index 1
+        ost = dd.set_timesteps(dd.create_state(), 4)
+        st4 = sched.set_timesteps(state, 4)
+        batch = {"latents": torch.from_numpy(olat[:, 1]), "next_latents": torch.from_numpy(onxt[:, 1]), "ts": torch.from_numpy(ots[:, 1].copy()),
+                 "log_probs": torch.from_numpy(olps[:, 1]) + torch.tensor([3e-5, -2e-5]), "advantages": torch.tensor([0.9, -1.4]),
+                 "prompt_embeds": emb, "uncond_embeds": neg}
+        ograds, oinfo, _ = train_step_grads(op, OU.TINY21, dd, ost, {k: (v if k == "ts" else v.double()) for k, v in batch.items()},
+                                            5.0, 1.0, 1e-4, True, dtype=torch.float64)
+        tstate = AccumulatingTrainState(unet, AdamWConfig())
+        tstate, info = train_step(tstate, {k: v.to(DEV) for k, v in batch.items()}, st4, sched, True, 5.0, 1.0, 1e-4, do_opt_update=False)
+        gn_o = math.sqrt(sum(float((v.double() ** 2).sum()) for v in ograds.values()))
+        gn = math.sqrt(float((unet.grads.flat.double() ** 2).sum()))
+        tol = 1e-3 if datapath == "fp32" else 3e-3     # PPO's 1e-4 clip range amplifies log-prob noise on the bf16x3 path
+        assert gn == pytest.approx(gn_o, rel=tol)
+    finally:
+        L.DATAPATH = old
+        L.PACKED.clear()
