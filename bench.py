@@ -41,6 +41,10 @@ def parse():
     ap.add_argument("--sample-batch-size", type=int, default=8)
     ap.add_argument("--datapath", default=os.environ.get("DDPO_DATAPATH", "bf16x3"), choices=["fp32", "bf16x3", "bf16"],
                     help="contraction datapath: exact-fp32 MFMA, bf16-split MFMA x3 (fp32-accurate to ~1e-5, default), single-pass bf16")
+    ap.add_argument("--mode", default="sample", choices=["sample", "train"],
+                    help="sample (headline): images/sec of the sampling hot path; train: PPO sample-timesteps/sec of train_step "
+                         "(U-Net fwd cond+uncond, log-prob, PPO-clip, backward, one AdamW update per step group)")
+    ap.add_argument("--train-batch-size", type=int, default=2)
     ap.add_argument("--no-graph", action="store_true", help="launch the U-Net kernels eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -79,6 +83,59 @@ def cpu_baseline(args):
             "sample": f"one oracle U-Net forward (batch 1, {hw}x{hw} latents) timed, x2 for a CFG step = {dt:.2f} s on "
                       f"{cores} torch-CPU threads; x{T} steps + VAE decode scaled by analytic FLOPs",
             "seconds_per_cfg_step": dt, "cpu_gflops": gflops}
+
+
+def bench_train(args, world, rank, dev, dist, unet, sched, state, emb, neg):
+    """Secondary metric: one "step" = `train_batch_size` sample-timesteps through train_step with train_cfg=True, every
+    4th step applying the optimizer (grad all-reduce over ranks + fused AdamW), as at the reference defaults scaled down."""
+    from ddpo_amd import lib as L
+    from ddpo_amd.training.policy_gradient import AccumulatingTrainState, AdamWConfig, train_step
+    if L.DATAPATH != "fp32":
+        unet.params.pack_bf16(bwd=True)
+    b = args.train_batch_size
+    hw = args.resolution // 8
+    g = torch.Generator().manual_seed(3 + rank)
+    st = sched.set_timesteps(state, args.n_inference_steps)
+    lat = torch.randn(b, 4, hw, hw, generator=g).to(dev)
+    batch = {"latents": lat, "next_latents": (0.98 * lat + 0.05 * torch.randn(b, 4, hw, hw, generator=g).to(dev)),
+             "ts": torch.tensor([481, 21, 961, 241][:b], dtype=torch.int32, device=dev),
+             "log_probs": torch.full((b,), -1.0, device=dev), "advantages": torch.tensor([0.7, -1.1, 0.3, -0.2][:b], device=dev),
+             "prompt_embeds": emb[:b].contiguous(), "uncond_embeds": neg[:b].contiguous()}
+    tstate = AccumulatingTrainState(unet, AdamWConfig())
+    k = 0
+
+    def one():
+        nonlocal k
+        k += 1
+        train_step(tstate, batch, st, sched, True, 5.0, 1.0, 1e-4, do_opt_update=(k % 4 == 0))
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        one()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one()
+    sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    value = world * b * args.steps / dt
+    if rank == 0:
+        tf = value * 6 * UNET_FWD_TFLOP["sd15"] if (args.model == "sd15" and args.resolution == 512) else None
+        print(json.dumps({"metric": "PPO train sample-timesteps/sec (train_cfg, 512^2)", "value": value, "unit": "sample-timesteps/sec",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.datapath, "data": "synthetic",
+                          "config": {"workload": f"train_step, {args.model}, train_batch_size {b}/GPU, train_cfg, optimizer update every 4 steps",
+                                     "parallelism": f"dp{world}"},
+                          "end_to_end_tflops": tf}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
 
 
 def main():
@@ -123,6 +180,9 @@ def main():
     # reference key tree (pipeline/policy_gradient.py:51,201,244-245): rank r uses row r of split(sample_seed, n_devices)
     rng = prng.PRNGKey(0)
     _, sample_rng = prng.split(rng)
+
+    if args.mode == "train":
+        return bench_train(args, world, rank, dev, dist, unet, sched, state, emb, neg)
 
     def one_step():
         nonlocal sample_rng
@@ -177,8 +237,18 @@ def main():
         peak = FP32_MFMA_PEAK_TFLOPS if dom == "fp32" else BF16_MFMA_PEAK_TFLOPS
         kname = "gemm_conv_kernel (v_mfma_f32_32x32x2_f32)" if dom == "fp32" else \
             f"gemm_conv_bf16_kernel<NPASS={passes}> (v_mfma_f32_32x32x16_bf16)"
+        traffic, traffic_note = None, None
+        tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath)).get(dom)
+            if tj:
+                traffic = tj["traffic_bytes_per_launch"]
+                traffic_note = ("PMC (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes) measured per launch of this kernel family, from "
+                                "profiles/roofline_traffic.json; not collectable inside this process")
         roofline = {"bound": "mfma", "kernel": kname, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                    "frac": achieved / peak, "traffic": None, "launches": len(recs), "avg_launch_ms": ms / max(len(recs), 1),
+                    "frac": achieved / peak, "traffic": traffic, "traffic_note": traffic_note,
+                    "algorithmic_bytes_per_launch": sum(r[4] for r in recs) / max(len(recs), 1),
+                    "launches": len(recs), "avg_launch_ms": ms / max(len(recs), 1),
                     "algorithmic_gflop_per_launch": flops / max(len(recs), 1) / 1e9,
                     "mfma_passes_per_algorithmic_flop": passes, "mfma_issue_frac": passes * achieved / peak}
     if rank != 0:

@@ -276,10 +276,12 @@ def pack_weights(w, bwd=True):
     K = w.numel() // N
     Kp = (K + 7) // 8 * 8
     ent = PACKED.get(w.data_ptr())
+    mk = lambda *s: torch.zeros(*s, dtype=torch.int16, device=w.device)
     if ent is None or ent["K"] != K or ent["N"] != N:
-        mk = lambda *s: torch.zeros(*s, dtype=torch.int16, device=w.device)
-        ent = dict(K=K, N=N, fwd=(mk(N, Kp), mk(N, Kp), Kp), bwd=(mk(K, N), mk(K, N)) if bwd else None)
+        ent = dict(K=K, N=N, fwd=(mk(N, Kp), mk(N, Kp), Kp), bwd=None)
         PACKED[w.data_ptr()] = ent
+    if bwd and ent["bwd"] is None:
+        ent["bwd"] = (mk(K, N), mk(K, N))
     fh, fl, _ = ent["fwd"]
     bh, bl = ent["bwd"] if ent["bwd"] is not None else (None, None)
     _check(load().ddpo_pack_weights_bf16(_p(w), K, N, Kp, _p(fh), _p(fl), _p(bh), _p(bl), _stream()), "ddpo_pack_weights_bf16")
@@ -336,7 +338,10 @@ def gemm_conv(src, w, *, M, N, K, bias=None, rowbias=None, rows_per_batch=0, res
         _check(load().ddpo_gemm_conv_fwd(byref(d), _stream()), "ddpo_gemm_conv_fwd")
     if PROFILE is not None:
         e1.record()
-        PROFILE.append((e0, e1, 2.0 * M * N * K, "fp32" if route is None else DATAPATH))
+        a_bytes = 4.0 * (conv["B"] * conv["H"] * conv["W"] * conv["Cin"] if conv else M * K)       # unique operand bytes
+        w_bytes = (4.0 if route is None else (4.0 if DATAPATH == "bf16x3" else 2.0)) * K * N
+        io_bytes = a_bytes + w_bytes + 4.0 * M * N * (2 if residual is not None else 1)
+        PROFILE.append((e0, e1, 2.0 * M * N * K, "fp32" if route is None else DATAPATH, io_bytes))
     return out
 
 
