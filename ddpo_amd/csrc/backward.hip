@@ -274,15 +274,27 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const float* __restr
       }
     }
   }
+  // combine the 4 waves of the block in LDS (fixed order), then one atomic per (block, channel)
+  __shared__ float4 s_dg[3][MAXV * 64], s_db[3][MAXV * 64];
+  const int w = threadIdx.x >> 6;
 #pragma unroll
-  for (int j = 0; j < MAXV; ++j) {
-    const int c4 = lane + j * 64;
-    if (c4 < C4) {
-      const float* pdg = &dg[j].x; const float* pdb = &dbt[j].x;
+  for (int j = 0; j < MAXV; ++j)
+    if (w > 0) { s_dg[w - 1][j * 64 + lane] = dg[j]; s_db[w - 1][j * 64 + lane] = dbt[j]; }
+  __syncthreads();
+  if (w == 0) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        atomicAdd(&dgamma[(c4 << 2) + e], pdg[e]);
-        atomicAdd(&dbeta[(c4 << 2) + e], pdb[e]);
+    for (int j = 0; j < MAXV; ++j) {
+      const int c4 = lane + j * 64;
+      if (c4 < C4) {
+        float4 a = dg[j], b = dbt[j];
+        for (int k = 0; k < 3; ++k) {
+          const float4 x = s_dg[k][j * 64 + lane], y = s_db[k][j * 64 + lane];
+          a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
+          b.x += y.x; b.y += y.y; b.z += y.z; b.w += y.w;
+        }
+        float* pg = dgamma + (c4 << 2); float* pb = dbeta + (c4 << 2);
+        atomicAdd(pg, a.x); atomicAdd(pg + 1, a.y); atomicAdd(pg + 2, a.z); atomicAdd(pg + 3, a.w);
+        atomicAdd(pb, b.x); atomicAdd(pb + 1, b.y); atomicAdd(pb + 2, b.z); atomicAdd(pb + 3, b.w);
       }
     }
   }
@@ -291,8 +303,9 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const float* __restr
 extern "C" int ddpo_layernorm_bwd(const float* x, const float* dy, const float* gamma, int rows, int C, float eps,
                                   const float* dx_add, float* dx, float* dgamma, float* dbeta, void* stream) {
   if (!x || !dy || !gamma || !dx || !dgamma || !dbeta || rows <= 0 || C <= 0 || (C & 3) || C > 2560) return DDPO_EINVAL;
-  int blocks = (rows + 3) / 4;
-  if (blocks > 256) blocks = 256;
+  int blocks = (rows + 15) / 16;           // ~4 rows per wave: enough waves in flight to stream at HBM rate
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
   hipStream_t st = as_stream(stream);
   const int nv = ((C >> 2) + 63) / 64;
   if (nv <= 2) hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3(blocks), dim3(256), 0, st, x, dy, gamma, rows, C, eps, dx_add, dx, dgamma, dbeta);

@@ -87,17 +87,13 @@ class AccumulatingTrainState:
         return self
 
 
-def train_step(state: AccumulatingTrainState, batch, noise_scheduler_state, noise_scheduler, train_cfg, guidance_scale,
-               eta, clip_range, do_opt_update):
-    """One PPO micro-step (reference :63-146).  batch: latents, next_latents (b,4,h,w), ts (b,) int32, log_probs,
-    advantages (b,), prompt_embeds, uncond_embeds (b,77,D) — device tensors.  Returns (state, info) with info a dict
-    of device scalars {approx_kl, clipfrac, loss}."""
-    assert isinstance(state, AccumulatingTrainState)
-    lat = batch["latents"].contiguous()
-    b = lat.shape[0]
-    assert b == batch["ts"].shape[0] == batch["next_latents"].shape[0] == batch["log_probs"].shape[0]
+def _fwd_bwd(state, batch, noise_scheduler_state, noise_scheduler, train_cfg, guidance_scale, eta, clip_range):
+    """U-Net forward (cond + uncond as one batch), scoring-mode log-prob + PPO-clip forward/backward, U-Net backward
+    (parameter gradients accumulate in place).  Pure device work: capturable into a HIP graph."""
     unet = state.unet
-    ts = batch["ts"].to(torch.int32).contiguous()
+    lat = batch["latents"]
+    b = lat.shape[0]
+    ts = batch["ts"]
     tape = []
     if train_cfg:
         lat2 = torch.cat([lat, lat])
@@ -108,10 +104,60 @@ def train_step(state: AccumulatingTrainState, batch, noise_scheduler_state, nois
         out = unet.forward(lat, ts, batch["prompt_embeds"], tape=tape)
         eps_u, eps_c = None, out
     consts = noise_scheduler.kernel_consts(noise_scheduler_state, eta)
-    d_c, d_u, per_sample, info = L.ddim_logprob_ppo_fwd_bwd(eps_c, eps_u, lat, batch["next_latents"].contiguous(), ts,
-                                                            batch["log_probs"].contiguous(), batch["advantages"].contiguous(),
-                                                            guidance_scale, clip_range, train_cfg, consts)
+    d_c, d_u, per_sample, info = L.ddim_logprob_ppo_fwd_bwd(eps_c, eps_u, lat, batch["next_latents"], ts, batch["log_probs"],
+                                                            batch["advantages"], guidance_scale, clip_range, train_cfg, consts)
     d_out = torch.cat([d_u, d_c]) if train_cfg else d_c
     unet.backward(tape, d_out)
+    return info, per_sample
+
+
+_KEYS = ("latents", "next_latents", "ts", "log_probs", "advantages", "prompt_embeds", "uncond_embeds")
+
+
+def _graphed_fwd_bwd(state, batch, sched_state, sched, train_cfg, guidance_scale, eta, clip_range):
+    """Replay of _fwd_bwd as a captured HIP graph (one per batch geometry / hyper-parameter set): ~3000 kernel launches per
+    micro-step become one graph launch.  Gradients still accumulate into the same flat buffer."""
+    key = (tuple(batch["latents"].shape), tuple(batch["prompt_embeds"].shape), bool(train_cfg), float(guidance_scale), float(eta),
+           float(clip_range), sched_state.num_inference_steps, L.DATAPATH)
+    cache = state.__dict__.setdefault("_graphs", {})
+    ent = cache.get(key)
+    if ent is None:
+        static = {k: batch[k].clone() for k in _KEYS}
+        gflat = state.grad_acc.flat
+        saved = gflat.clone()
+        side = torch.cuda.Stream(gflat.device)
+        side.wait_stream(torch.cuda.current_stream(gflat.device))
+        with torch.cuda.stream(side):
+            _fwd_bwd(state, static, sched_state, sched, train_cfg, guidance_scale, eta, clip_range)      # warm-up (allocations, attrs)
+        torch.cuda.current_stream(gflat.device).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            info, per_sample = _fwd_bwd(state, static, sched_state, sched, train_cfg, guidance_scale, eta, clip_range)
+        gflat.copy_(saved)                      # warm-up passes must not leak into the accumulated gradients
+        ent = (graph, static, info, per_sample)
+        cache[key] = ent
+    graph, static, info, per_sample = ent
+    for k in _KEYS:
+        static[k].copy_(batch[k])
+    graph.replay()
+    return info.clone(), per_sample.clone()
+
+
+def train_step(state: AccumulatingTrainState, batch, noise_scheduler_state, noise_scheduler, train_cfg, guidance_scale,
+               eta, clip_range, do_opt_update, jit=True):
+    """One PPO micro-step (reference :63-146).  batch: latents, next_latents (b,4,h,w), ts (b,) int32, log_probs,
+    advantages (b,), prompt_embeds, uncond_embeds (b,77,D) — device tensors.  Returns (state, info) with info a dict
+    of device scalars {approx_kl, clipfrac, loss}."""
+    assert isinstance(state, AccumulatingTrainState)
+    b = batch["latents"].shape[0]
+    assert b == batch["ts"].shape[0] == batch["next_latents"].shape[0] == batch["log_probs"].shape[0]
+    dbatch = {k: batch[k].contiguous() for k in _KEYS if k in batch}
+    dbatch["ts"] = dbatch["ts"].to(torch.int32)
+    if not train_cfg and "uncond_embeds" not in dbatch:
+        dbatch["uncond_embeds"] = dbatch["prompt_embeds"]
+    if jit:
+        info, per_sample = _graphed_fwd_bwd(state, dbatch, noise_scheduler_state, noise_scheduler, train_cfg, guidance_scale, eta, clip_range)
+    else:
+        info, per_sample = _fwd_bwd(state, dbatch, noise_scheduler_state, noise_scheduler, train_cfg, guidance_scale, eta, clip_range)
     state = state.apply_gradients(do_update=do_opt_update)
     return state, {"approx_kl": info[0], "clipfrac": info[1], "loss": info[2], "log_prob": per_sample[:, 0]}
