@@ -33,6 +33,12 @@ __device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo) {
   lo.y = cvt_pk_bf16(r2, r3);
 }
 
+// two floats -> packed bf16 hi pair and packed bf16 lo pair
+__device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+  hi = cvt_pk_bf16(a, b);
+  lo = cvt_pk_bf16(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xFFFF0000u));
+}
+
 __device__ __forceinline__ int swz_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }   // bytes
 
 // AFFINE: no upsampling / zero-insert in the gather, so the source address of tap (ky,kx) is rowptr + (ky*W + kx)*ld + ci
@@ -378,6 +384,190 @@ extern "C" int ddpo_pack_weights_bf16(const float* w, int K, int N, int Kp, uint
   if (!w || !fwd_hi || !fwd_lo || K <= 0 || N <= 0 || Kp < K || (Kp & 7) || (bwd_hi && !bwd_lo)) return DDPO_EINVAL;
   dim3 grid((N + 31) / 32, (Kp + 31) / 32);
   hipLaunchKernelGGL(pack_weights_kernel, grid, dim3(256), 0, as_stream(stream), w, K, N, Kp, fwd_hi, fwd_lo, bwd_hi, bwd_lo);
+  DDPO_LAUNCH_CHECK();
+  return DDPO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient on the bf16x3 MFMA datapath:  dW[k][n] += sum_m A(m,k) * dY[m][n]   (k = (ky,kx,ci); m = pixels)
+// Both operands have the reduction index m as their SLOW memory dimension, so each is transposed while it is staged:
+// a thread loads float4s of two consecutive pixels and writes, per channel, the packed (pixel m, pixel m+1) bf16 pair
+// as one dword of the [row][m] LDS image.  Row pitch is 18 dwords (72 B): the pair writes of a half-wave hit 32
+// distinct banks (x2, free) and the two ds_read_b64 of a fragment are conflict free.  Fast path only: stride 1,
+// no upsampling (output pixel m == input pixel m, source address linear in m); other layers use gemm_wgrad_kernel.
+// ------------------------------------------------------------------------------------------------
+#define WG_PITCH 18     // dwords per LDS row (16 dwords = 32 pixels of the k-tile, +2 pad)
+
+__device__ __forceinline__ bf16x8 lds_frag(const uint32_t* base, int row, int dw) {
+  const uint2 a = *reinterpret_cast<const uint2*>(base + row * WG_PITCH + dw);
+  const uint2 b = *reinterpret_cast<const uint2*>(base + row * WG_PITCH + dw + 2);
+  return __builtin_bit_cast(bf16x8, make_uint4(a.x, a.y, b.x, b.y));
+}
+
+__global__ void __launch_bounds__(BF_THREADS) gemm_wgrad_bf16_kernel(const ddpo_gemm_desc d, int tiles_n, int m_per_split) {
+  constexpr int BM = 128, BN = 128, BK = 32;
+  constexpr int PLANE = BM * WG_PITCH;                 // dwords per plane (BM == BN)
+  __shared__ __attribute__((aligned(16))) uint32_t smem[2][4 * PLANE];     // per stage: A_hi | A_lo | B_hi | B_lo
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
+  const int k0 = tile_m * BM, n0 = tile_n * BN;
+  const int m_begin = blockIdx.y * m_per_split;
+  const int m_end = min(m_begin + m_per_split, d.M);
+  if (m_begin >= m_end) return;
+
+  const bool conv = d.ksize > 0;
+  // loader geometry: quad q = lane&7 (4 consecutive k or n), pixel pair pp = lane>>3, wave w covers rows 32w..32w+31
+  const int q = lane & 7, pp = lane >> 3;
+  const int arow = 32 * wid + 4 * q;                   // first of this thread's 4 LDS rows (same for A and B tiles)
+  const int kg = k0 + arow;                            // global k of those rows
+  const bool kvalid = kg < d.K;
+  int dky = 0, dkx = 0, ci = kg;
+  if (conv) {
+    const int tap = kg / d.Cin;
+    ci = kg - tap * d.Cin;
+    const int ky = tap / d.ksize;
+    dky = ky - d.pad;
+    dkx = tap - ky * d.ksize - d.pad;
+  }
+  const int ng = n0 + arow;
+  const bool nvalid = ng < d.N;
+  // the 4 pixels this thread stages per k-tile: m = m_begin + kt*32 + 16*p + 2*pp + e ; track (oy, ox) incrementally
+  int poy[2][2], pox[2][2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int m = m_begin + 16 * p + 2 * pp + e;
+      poy[p][e] = conv ? (m / d.W) % d.H : 0;
+      pox[p][e] = conv ? m % d.W : 0;
+    }
+  const int64_t tap_off = conv ? ((int64_t)dky * d.W + dkx) * d.ld_src + ci : kg;
+
+  float4 ra[2][2], rb[2][2];
+  auto load_tile = [&](int kt) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int m = m_begin + kt * BK + 16 * p + 2 * pp + e;
+        float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
+        if (m < m_end) {
+          bool ok = kvalid;
+          if (conv) {
+            const int iy = poy[p][e] + dky, ix = pox[p][e] + dkx;
+            ok = ok && iy >= 0 && iy < d.H && ix >= 0 && ix < d.W;
+          }
+          if (ok) va = *reinterpret_cast<const float4*>(d.src + (int64_t)m * d.ld_src + tap_off);
+          if (nvalid) vb = *reinterpret_cast<const float4*>(d.w + (int64_t)m * d.ld_w + ng);
+        }
+        ra[p][e] = va;
+        rb[p][e] = vb;
+        if (conv) {          // advance this pixel by BK
+          pox[p][e] += BK;
+          while (pox[p][e] >= d.W) { pox[p][e] -= d.W; ++poy[p][e]; }
+          while (poy[p][e] >= d.H) poy[p][e] -= d.H;
+        }
+      }
+  };
+  auto store_tile = [&](int buf) {
+    uint32_t* st = smem[buf];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int dw = pp + 8 * p;                        // dword (= pixel pair) index within the row
+      const float* a0 = &ra[p][0].x; const float* a1 = &ra[p][1].x;
+      const float* b0 = &rb[p][0].x; const float* b1 = &rb[p][1].x;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        uint32_t hi, lo;
+        split2(a0[j], a1[j], hi, lo);                   // (pixel m, pixel m+1) of channel k+j
+        st[(arow + j) * WG_PITCH + dw] = hi;
+        st[PLANE + (arow + j) * WG_PITCH + dw] = lo;
+        split2(b0[j], b1[j], hi, lo);
+        st[2 * PLANE + (arow + j) * WG_PITCH + dw] = hi;
+        st[3 * PLANE + (arow + j) * WG_PITCH + dw] = lo;
+      }
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = (m_end - m_begin + BK - 1) / BK;
+  const int li = lane & 31, h = lane >> 5;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) load_tile(kt + 1);
+    const uint32_t* st = smem[cur];
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms) {
+      const int dw = 8 * ms + 4 * h;
+      bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        ah[i] = lds_frag(st, wm * 64 + i * 32 + li, dw);
+        al[i] = lds_frag(st + PLANE, wm * 64 + i * 32 + li, dw);
+        bh[i] = lds_frag(st + 2 * PLANE, wn * 64 + i * 32 + li, dw);
+        bl[i] = lds_frag(st + 3 * PLANE, wn * 64 + i * 32 + li, dw);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    if (kt + 1 < nk) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + li;
+      if (col >= d.N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = k0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row >= d.K) continue;
+        atomicAdd(d.out + (int64_t)row * d.ld_out + col, d.alpha * acc[i][j][r]);
+      }
+    }
+}
+
+extern "C" int ddpo_gemm_conv_wgrad_bf16x3(const ddpo_gemm_desc* dp, void* stream) {
+  if (!dp) return DDPO_EINVAL;
+  ddpo_gemm_desc d = *dp;
+  if (!d.src || !d.w || !d.out || d.M <= 0 || d.N <= 0 || d.K <= 0) return DDPO_EINVAL;
+  if ((d.ld_src & 3) || (d.ld_w & 3) || (d.N & 3) || (d.K & 3)) return DDPO_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(d.src) | reinterpret_cast<uintptr_t>(d.w)) & 15) return DDPO_EINVAL;
+  if (d.ksize > 0) {
+    if (d.ksize != 1 && d.ksize != 3) return DDPO_EINVAL;
+    if ((d.Cin & 3) || d.K != d.ksize * d.ksize * d.Cin || d.M != d.B * d.OH * d.OW) return DDPO_EINVAL;
+    if (d.stride != 1 || d.upsample != 0 || d.pad != d.ksize / 2 || d.OH != d.H || d.OW != d.W) return DDPO_EINVAL;   // fast path only
+  }
+  const int tiles_m = (d.K + 127) / 128, tiles_n = (d.N + 127) / 128, tiles = tiles_m * tiles_n;
+  int splits = d.splits;
+  if (splits <= 0) {
+    splits = (1024 + tiles - 1) / tiles;
+    const int max_splits = (d.M + 255) / 256;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+  }
+  int mps = (d.M + splits - 1) / splits;
+  mps = (mps + 31) / 32 * 32;
+  splits = (d.M + mps - 1) / mps;
+  hipLaunchKernelGGL(gemm_wgrad_bf16_kernel, dim3(tiles, splits), dim3(BF_THREADS), 0, as_stream(stream), d, tiles_n, mps);
   DDPO_LAUNCH_CHECK();
   return DDPO_OK;
 }

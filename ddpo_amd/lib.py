@@ -57,6 +57,7 @@ _SIGS = {
     "ddpo_gemm_conv_fwd": (c_int, [POINTER(GemmDesc), c_void_p]),
     "ddpo_gemm_conv_wgrad": (c_int, [POINTER(GemmDesc), c_void_p]),
     "ddpo_gemm_conv_fwd_bf16": (c_int, [POINTER(GemmDesc), c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "ddpo_gemm_conv_wgrad_bf16x3": (c_int, [POINTER(GemmDesc), c_void_p]),
     "ddpo_pack_weights_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ddpo_attention_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int,
                                    c_int, c_int, c_int, c_float, c_void_p]),
@@ -471,7 +472,12 @@ def gemm_wgrad(src, dy, dw, *, M, N, K, conv=None, ld_src=None, ld_dy=None, accu
     if conv:
         for k in ("ksize", "stride", "pad", "upsample", "B", "H", "W", "Cin", "OH", "OW"):
             setattr(d, k, int(conv[k]))
-    _check(load().ddpo_gemm_conv_wgrad(byref(d), _stream()), "ddpo_gemm_conv_wgrad")
+    fast = DATAPATH != "fp32" and accumulate and (conv is None or (conv["stride"] == 1 and not conv["upsample"] and
+                                                                      conv["pad"] == conv["ksize"] // 2)) and K >= 64 and N >= 32
+    if fast:
+        _check(load().ddpo_gemm_conv_wgrad_bf16x3(byref(d), _stream()), "ddpo_gemm_conv_wgrad_bf16x3")
+    else:
+        _check(load().ddpo_gemm_conv_wgrad(byref(d), _stream()), "ddpo_gemm_conv_wgrad")
     return dw
 
 

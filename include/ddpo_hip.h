@@ -148,6 +148,10 @@ int ddpo_gemm_conv_wgrad(const ddpo_gemm_desc* d, void* stream);
  * d->w_dgrad = 1 for data gradients.  d->w / d->w_trans are ignored.  Requires Cin % 8 == 0 (K % 8 == 0 if dense). */
 int ddpo_gemm_conv_fwd_bf16(const ddpo_gemm_desc* d, const uint16_t* w_hi, const uint16_t* w_lo, int ldw, int npass,
                             void* stream);
+/* Weight gradient on the bf16x3 MFMA datapath (same arguments as ddpo_gemm_conv_wgrad; always accumulates with fp32
+ * atomics).  Fast path only: dense, or convolutions with stride 1, pad = ksize/2 and no upsampling (returns
+ * DDPO_EINVAL otherwise - callers fall back to ddpo_gemm_conv_wgrad). */
+int ddpo_gemm_conv_wgrad_bf16x3(const ddpo_gemm_desc* d, void* stream);
 /* fp32 W (K,N) -> bf16 hi/lo planes: fwd_* (N, Kp) k-contiguous (Kp = K rounded up to 8, zero padded) and, if
  * bwd_hi != NULL, bwd_* (K, N).  Call after every optimizer update (weights only change there). */
 int ddpo_pack_weights_bf16(const float* w, int K, int N, int Kp, uint16_t* fwd_hi, uint16_t* fwd_lo,

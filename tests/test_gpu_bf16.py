@@ -137,3 +137,30 @@ def test_attention_bf16x3(datapath, B, heads, Nq, Nk, d):
     ref = (torch.softmax(s_, -1) @ sp(v, Nk)).permute(0, 2, 1, 3).reshape(B * Nq, C)
     assert _rel(out, ref) < 1e-4
     assert _rel(lse.view(B, heads, Nq), torch.logsumexp(s_, -1) / math.log(2.0)) < 1e-4
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,ks", [(2, 8, 8, 64, 64, 3), (2, 8, 8, 96, 128, 3), (2, 8, 8, 64, 128, 1), (1, 32, 32, 320, 320, 3),
+                                               (3, 6, 10, 64, 64, 3), (2, 16, 16, 640, 320, 3)])
+def test_conv_wgrad_bf16x3(datapath, B, H, W, Cin, Cout, ks):
+    L.DATAPATH = "bf16x3"
+    g = torch.Generator().manual_seed(H + Cin + Cout + ks)
+    x = torch.randn(B, H, W, Cin, generator=g)
+    dy = torch.randn(B, H, W, Cout, generator=g)
+    wd = torch.zeros(Cout, Cin, ks, ks, dtype=torch.float64, requires_grad=True)
+    TF.conv2d(x.permute(0, 3, 1, 2).double(), wd, None, padding=ks // 2).backward(dy.permute(0, 3, 1, 2).double())
+    ref = wd.grad.permute(2, 3, 1, 0)
+    dw = torch.zeros(ks, ks, Cin, Cout, device=DEV)
+    L.conv2d_wgrad(x.reshape(-1, Cin).to(DEV), dy.reshape(-1, Cout).to(DEV), dw, B, H, W, Cin, Cout, ks)
+    assert _rel(dw, ref) < 5e-5
+    L.conv2d_wgrad(x.reshape(-1, Cin).to(DEV), dy.reshape(-1, Cout).to(DEV), dw, B, H, W, Cin, Cout, ks)
+    assert _rel(dw, 2 * ref) < 5e-5
+
+
+@pytest.mark.parametrize("M,K,N", [(300, 320, 640), (4096, 64, 128), (2048, 640, 5120), (154, 768, 320), (4, 1280, 320)])
+def test_linear_wgrad_bf16x3(datapath, M, K, N):
+    L.DATAPATH = "bf16x3"
+    g = torch.Generator().manual_seed(M + K)
+    x, dy = torch.randn(M, K, generator=g), torch.randn(M, N, generator=g)
+    dw = torch.zeros(K, N, device=DEV)
+    L.linear_wgrad(x.to(DEV), dy.to(DEV), dw)
+    assert _rel(dw, x.double().t() @ dy.double()) < 5e-5
