@@ -20,7 +20,7 @@ __global__ void __launch_bounds__(GN_THREADS) gn_bwd_stats_kernel(const float* _
                                                                   int lddy, const float* __restrict__ ab, const float* __restrict__ mr,
                                                                   const float* __restrict__ gamma, int HW, int C, int G,
                                                                   int pix_per_block, double* __restrict__ part,
-                                                                  float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                                  float* __restrict__ cpart) {
   __shared__ float s_dz[GN_MAXC], s_dzx[GN_MAXC];
   const int b = blockIdx.y;
   const int C4 = C >> 2, cpg = C / G, t = threadIdx.x;
@@ -77,12 +77,13 @@ __global__ void __launch_bounds__(GN_THREADS) gn_bwd_stats_kernel(const float* _
     }
   }
   __syncthreads();
-  // parameter gradients: per channel over the slots, then one atomic per (block, channel)
+  // parameter gradients: per-channel partial of this block -> cpart[block][{dgamma | dbeta}][C]; a column-sum pass follows
+  float* cp = cpart + ((int64_t)b * gridDim.x + blockIdx.x) * 2 * C;
   for (int c = t; c < C; c += GN_THREADS) {
     float a = 0.f, q = 0.f;
     for (int slot = 0; slot < ppi; ++slot) { a += s_dz[slot * C + c]; q += s_dzx[slot * C + c]; }
-    atomicAdd(&dbeta[c], a);
-    atomicAdd(&dgamma[c], q);
+    cp[c] = q;
+    cp[C + c] = a;
   }
   if (t < G) {
     double a = 0.0, q = 0.0;
@@ -160,8 +161,9 @@ static inline int gn_ppb(int C) {
 extern "C" size_t ddpo_groupnorm_bwd_ws_bytes(int B, int HW, int C, int G) {
   if (B <= 0 || HW <= 0 || C <= 0 || G <= 0) return 0;
   const int chunks = (HW + gn_ppb(C) - 1) / gn_ppb(C);
-  return (size_t)B * chunks * G * 2 * sizeof(double) + (size_t)B * C * 2 * sizeof(float);
+  return (size_t)B * chunks * G * 2 * sizeof(double) + (size_t)B * C * 2 * sizeof(float) + (size_t)B * chunks * 2 * C * sizeof(float);
 }
+extern "C" int ddpo_colsum_accum(const float* x, int ldx, int64_t rows, int cols, int rows_per_seg, float* out, void* stream);
 
 extern "C" int ddpo_groupnorm_bwd(const float* x, int ldx, const float* dy, int lddy, const float* stats, const float* gamma, int B,
                                   int HW, int C, int G, int fuse_silu, const float* dx_add, int ld_add, float* dx, int lddx,
@@ -175,13 +177,24 @@ extern "C" int ddpo_groupnorm_bwd(const float* x, int ldx, const float* dy, int 
   const float* mr = stats + (size_t)B * C * 2;
   double* part = reinterpret_cast<double*>(ws);
   float* pq = reinterpret_cast<float*>(part + (size_t)B * chunks * G * 2);
+  float* cpart = pq + (size_t)B * C * 2;
   if (fuse_silu)
     hipLaunchKernelGGL(gn_bwd_stats_kernel<true>, dim3(chunks, B), dim3(GN_THREADS), 0, st, x, ldx, dy, lddy, ab, mr, gamma, HW, C, G,
-                       ppb, part, dgamma, dbeta);
+                       ppb, part, cpart);
   else
     hipLaunchKernelGGL(gn_bwd_stats_kernel<false>, dim3(chunks, B), dim3(GN_THREADS), 0, st, x, ldx, dy, lddy, ab, mr, gamma, HW, C, G,
-                       ppb, part, dgamma, dbeta);
+                       ppb, part, cpart);
   DDPO_LAUNCH_CHECK();
+  {   // second stage of the parameter gradients: column sums of the per-block partials (few atomics per address)
+    int rc;
+    if (dbeta == dgamma + C) {          // scale and bias are adjacent in the flat gradient buffer: one pass over 2C columns
+      rc = ddpo_colsum_accum(cpart, 2 * C, (int64_t)B * chunks, 2 * C, 0, dgamma, stream);
+    } else {
+      rc = ddpo_colsum_accum(cpart, 2 * C, (int64_t)B * chunks, C, 0, dgamma, stream);
+      if (rc == DDPO_OK) rc = ddpo_colsum_accum(cpart + C, 2 * C, (int64_t)B * chunks, C, 0, dbeta, stream);
+    }
+    if (rc != DDPO_OK) return rc;
+  }
   hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B * G), dim3(64), 0, st, part, mr, pq, chunks, C, G, HW);
   DDPO_LAUNCH_CHECK();
   int64_t blocks = ((int64_t)B * HW * C4 + 255) / 256;
@@ -203,7 +216,7 @@ template <int MAXV>
 __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                             const float* __restrict__ gamma, int rows, int C, float eps,
                                                             const float* __restrict__ dx_add, float* __restrict__ dx,
-                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                            float* __restrict__ cpart) {
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
   const int C4 = C >> 2;
@@ -292,27 +305,37 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const float* __restr
           a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
           b.x += y.x; b.y += y.y; b.z += y.z; b.w += y.w;
         }
-        float* pg = dgamma + (c4 << 2); float* pb = dbeta + (c4 << 2);
-        atomicAdd(pg, a.x); atomicAdd(pg + 1, a.y); atomicAdd(pg + 2, a.z); atomicAdd(pg + 3, a.w);
-        atomicAdd(pb, b.x); atomicAdd(pb + 1, b.y); atomicAdd(pb + 2, b.z); atomicAdd(pb + 3, b.w);
+        float* cp = cpart + (int64_t)blockIdx.x * 2 * C;          // [block][{dgamma | dbeta}][C]
+        *reinterpret_cast<float4*>(cp + (c4 << 2)) = a;
+        *reinterpret_cast<float4*>(cp + C + (c4 << 2)) = b;
       }
     }
   }
 }
 
-extern "C" int ddpo_layernorm_bwd(const float* x, const float* dy, const float* gamma, int rows, int C, float eps,
-                                  const float* dx_add, float* dx, float* dgamma, float* dbeta, void* stream) {
-  if (!x || !dy || !gamma || !dx || !dgamma || !dbeta || rows <= 0 || C <= 0 || (C & 3) || C > 2560) return DDPO_EINVAL;
+static inline int ln_bwd_blocks(int rows) {
   int blocks = (rows + 15) / 16;           // ~4 rows per wave: enough waves in flight to stream at HBM rate
-  if (blocks > 2048) blocks = 2048;
-  if (blocks < 1) blocks = 1;
+  if (blocks > 1024) blocks = 1024;
+  return blocks < 1 ? 1 : blocks;
+}
+extern "C" size_t ddpo_layernorm_bwd_ws_bytes(int rows, int C) { return (size_t)ln_bwd_blocks(rows) * 2 * C * sizeof(float); }
+
+extern "C" int ddpo_layernorm_bwd(const float* x, const float* dy, const float* gamma, int rows, int C, float eps,
+                                  const float* dx_add, float* dx, float* dgamma, float* dbeta, void* ws, void* stream) {
+  if (!x || !dy || !gamma || !dx || !dgamma || !dbeta || !ws || rows <= 0 || C <= 0 || (C & 3) || C > 2560) return DDPO_EINVAL;
+  if (reinterpret_cast<uintptr_t>(ws) & 15) return DDPO_EINVAL;
+  const int blocks = ln_bwd_blocks(rows);
+  float* cpart = reinterpret_cast<float*>(ws);
   hipStream_t st = as_stream(stream);
   const int nv = ((C >> 2) + 63) / 64;
-  if (nv <= 2) hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3(blocks), dim3(256), 0, st, x, dy, gamma, rows, C, eps, dx_add, dx, dgamma, dbeta);
-  else if (nv <= 5) hipLaunchKernelGGL(layernorm_bwd_kernel<5>, dim3(blocks), dim3(256), 0, st, x, dy, gamma, rows, C, eps, dx_add, dx, dgamma, dbeta);
-  else hipLaunchKernelGGL(layernorm_bwd_kernel<10>, dim3(blocks), dim3(256), 0, st, x, dy, gamma, rows, C, eps, dx_add, dx, dgamma, dbeta);
+  if (nv <= 2) hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3(blocks), dim3(256), 0, st, x, dy, gamma, rows, C, eps, dx_add, dx, cpart);
+  else if (nv <= 5) hipLaunchKernelGGL(layernorm_bwd_kernel<5>, dim3(blocks), dim3(256), 0, st, x, dy, gamma, rows, C, eps, dx_add, dx, cpart);
+  else hipLaunchKernelGGL(layernorm_bwd_kernel<10>, dim3(blocks), dim3(256), 0, st, x, dy, gamma, rows, C, eps, dx_add, dx, cpart);
   DDPO_LAUNCH_CHECK();
-  return DDPO_OK;
+  if (dbeta == dgamma + C) return ddpo_colsum_accum(cpart, 2 * C, blocks, 2 * C, 0, dgamma, stream);
+  int rc = ddpo_colsum_accum(cpart, 2 * C, blocks, C, 0, dgamma, stream);
+  if (rc != DDPO_OK) return rc;
+  return ddpo_colsum_accum(cpart + C, 2 * C, blocks, C, 0, dbeta, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -371,7 +394,7 @@ extern "C" int ddpo_silu_bwd(const float* x, const float* dy, float* dx, int64_t
 }
 
 // column sums (bias / time-embedding-add gradients): 16 float4 column lanes x 16 row lanes per block
-#define CS_ROWS 256
+#define CS_ROWS 512
 __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ x, int ldx, int64_t rows, int cols, int rows_per_seg,
                                                      int chunks_per_seg, float* __restrict__ out) {
   __shared__ float4 red[16][17];

@@ -69,7 +69,8 @@ _SIGS = {
     "ddpo_groupnorm_bwd_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "ddpo_groupnorm_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                    c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "ddpo_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ddpo_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ddpo_layernorm_bwd_ws_bytes": (c_size_t, [c_int, c_int]),
     "ddpo_geglu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "ddpo_silu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "ddpo_colsum_accum": (c_int, [c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p]),
@@ -394,7 +395,8 @@ def attention_bwd(q, k, v, o, d_o, lse, B, heads, Nq, Nk, d, scale=None):
 def layernorm_bwd(x, dy, gamma, dgamma, dbeta, eps=1e-5, dx_add=None):
     rows, C = x.shape
     dx = torch.empty_like(x)
-    _check(load().ddpo_layernorm_bwd(_p(x), _p(dy), _p(gamma), rows, C, float(eps), _p(dx_add), _p(dx), _p(dgamma), _p(dbeta), _stream()),
+    ws = _scratch(load().ddpo_layernorm_bwd_ws_bytes(rows, C), x.device, "lnb")
+    _check(load().ddpo_layernorm_bwd(_p(x), _p(dy), _p(gamma), rows, C, float(eps), _p(dx_add), _p(dx), _p(dgamma), _p(dbeta), _p(ws), _stream()),
            "ddpo_layernorm_bwd")
     return dx
 

@@ -102,9 +102,11 @@ int ddpo_groupnorm_bwd(const float* x, int ldx, const float* dy, int lddy, const
 /* LayerNorm over the last dim: x,y:(rows,C) contiguous. */
 int ddpo_layernorm_fwd(const float* x, float* y, const float* gamma, const float* beta, int rows, int C,
                        float eps, void* stream);
-/* dx = LayerNorm backward (+ dx_add if given; statistics recomputed from x); dgamma/dbeta accumulated atomically. */
+/* dx = LayerNorm backward (+ dx_add if given; statistics recomputed from x); dgamma/dbeta += (two-stage reduction
+ * through ws = ddpo_layernorm_bwd_ws_bytes(rows, C) bytes of 16-byte aligned scratch). */
+size_t ddpo_layernorm_bwd_ws_bytes(int rows, int C);
 int ddpo_layernorm_bwd(const float* x, const float* dy, const float* gamma, int rows, int C, float eps,
-                       const float* dx_add, float* dx, float* dgamma, float* dbeta, void* stream);
+                       const float* dx_add, float* dx, float* dgamma, float* dbeta, void* ws, void* stream);
 
 /* Implicit-GEMM convolution / dense GEMM on the exact-fp32 MFMA datapath (v_mfma_f32_32x32x2_f32).
  *   out[m][n] = alpha * sum_k A(m,k) * W[k][n] (+ bias[n]) (+ rowbias[m / rows_per_batch][n]) (+ residual[m][n])
