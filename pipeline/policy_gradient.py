@@ -52,6 +52,10 @@ def main(argv=None):
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
+    # contraction datapath of the HIP kernels: bf16x3-split MFMA by default, DDPO_DATAPATH=fp32 for exact fp32
+    from ddpo_amd import lib as L
+    L.DATAPATH = os.environ.get("DDPO_DATAPATH", "bf16x3")
+
     args = Parser(argv).parse_args("pg", process_index=worker_id)
     utils.init_logging("policy_gradient", args.verbose)
 
