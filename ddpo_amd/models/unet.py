@@ -447,6 +447,8 @@ class UNet2DCondition:
         if not hasattr(self, "_graphs"):
             self._graphs = {}
         ent = self._graphs.get(key)
+        if ent == "eager":
+            return self.forward(sample, timesteps, context)
         if ent is None:
             s_in = sample.clone().contiguous()
             t_in = timesteps.to(torch.int32).clone().contiguous()
@@ -457,9 +459,16 @@ class UNet2DCondition:
                 for _ in range(2):                      # warm-up: first-call attribute setup, scratch allocation
                     self.forward(s_in, t_in, c_in)
             torch.cuda.current_stream(self.device).wait_stream(side)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                out = self.forward(s_in, t_in, c_in)
+            try:
+                graph = torch.cuda.CUDAGraph()
+                # thread_local: other host threads (RCCL watchdog, reward callbacks) may touch the device during capture
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                    out = self.forward(s_in, t_in, c_in)
+            except Exception as exc:          # capture is an optimisation only: fall back to eager launches, loudly
+                print(f"[ ddpo_amd ] WARNING: HIP-graph capture of the U-Net failed ({type(exc).__name__}: {exc}); launching eagerly")
+                torch.cuda.synchronize(self.device)
+                self._graphs[key] = "eager"
+                return self.forward(sample, timesteps, context)
             ent = (graph, s_in, t_in, c_in, out)
             self._graphs[key] = ent
         graph, s_in, t_in, c_in, out = ent

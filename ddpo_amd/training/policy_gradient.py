@@ -121,6 +121,8 @@ def _graphed_fwd_bwd(state, batch, sched_state, sched, train_cfg, guidance_scale
            float(clip_range), sched_state.num_inference_steps, L.DATAPATH)
     cache = state.__dict__.setdefault("_graphs", {})
     ent = cache.get(key)
+    if ent == "eager":
+        return _fwd_bwd(state, batch, sched_state, sched, train_cfg, guidance_scale, eta, clip_range)
     if ent is None:
         static = {k: batch[k].clone() for k in _KEYS}
         gflat = state.grad_acc.flat
@@ -130,9 +132,16 @@ def _graphed_fwd_bwd(state, batch, sched_state, sched, train_cfg, guidance_scale
         with torch.cuda.stream(side):
             _fwd_bwd(state, static, sched_state, sched, train_cfg, guidance_scale, eta, clip_range)      # warm-up (allocations, attrs)
         torch.cuda.current_stream(gflat.device).wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            info, per_sample = _fwd_bwd(state, static, sched_state, sched, train_cfg, guidance_scale, eta, clip_range)
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                info, per_sample = _fwd_bwd(state, static, sched_state, sched, train_cfg, guidance_scale, eta, clip_range)
+        except Exception as exc:                # capture is an optimisation only: fall back to eager launches, loudly
+            print(f"[ ddpo_amd ] WARNING: HIP-graph capture of train_step failed ({type(exc).__name__}: {exc}); launching eagerly")
+            torch.cuda.synchronize(gflat.device)
+            gflat.copy_(saved)
+            cache[key] = "eager"
+            return _fwd_bwd(state, batch, sched_state, sched, train_cfg, guidance_scale, eta, clip_range)
         gflat.copy_(saved)                      # warm-up passes must not leak into the accumulated gradients
         ent = (graph, static, info, per_sample)
         cache[key] = ent
