@@ -46,7 +46,8 @@ __device__ __forceinline__ int swz_off(int row, int chunk) { return row * 64 + (
 template <int BM, int BN, int NPASS, bool AFFINE>
 __global__ void __launch_bounds__(BF_THREADS) gemm_conv_bf16_kernel(const ddpo_gemm_desc d, const uint16_t* __restrict__ w_hi,
                                                                    const uint16_t* __restrict__ w_lo, int ldw, int tiles_m,
-                                                                   int tiles_n, int nblk) {
+                                                                   int tiles_n, int nblk, int kt_per_split,
+                                                                   float* __restrict__ part) {
   constexpr int BK = BF_BK;
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int AROWS = BM / 32;                 // float4 chunks per thread (A tile)
@@ -109,21 +110,27 @@ __global__ void __launch_bounds__(BF_THREADS) gemm_conv_bf16_kernel(const ddpo_g
       amask[i] = valid ? 1u : 0u;
     }
   }
+  // split-K: blockIdx.y owns k-tiles [kt0, kt0 + nk) and writes raw partial sums to part[split] (reduced afterwards)
+  const int nk_total = (d.K + BK - 1) / BK;
+  const int kt0 = blockIdx.y * kt_per_split;
+  const int nk = min(kt_per_split, nk_total - kt0);
   // running (tap, ci) of this thread's k quad; advanced by BK per k-tile without divisions
-  int a_tap = 0, a_ci = kq * 4;
+  int a_tap = 0, a_ci = kt0 * BK + kq * 4;
   if (conv) { a_tap = a_ci / d.Cin; a_ci -= a_tap * d.Cin; }
   // ---- W loader: thread owns 16-byte chunk bc (8 bf16 of k) of rows (t>>2) + 64*i
   const int bc = t & 3;
-  int b_tap = 0, b_co = bc * 8;
+  int b_tap = 0, b_co = kt0 * BK + bc * 8;
   if (d.w_dgrad) { b_tap = b_co / d.Cin; b_co -= b_tap * d.Cin; }
   const int ntaps = conv ? d.ksize * d.ksize : 1;
 
   struct Stage { float4 a[AROWS]; uint4 bh[BCH], bl[BCH]; };
   Stage s0, s1;       // two register stages: global loads run two k-tiles ahead of the MFMAs that consume them
 
-  auto load_tile = [&](int kt, Stage& sg) {
+  auto load_tile = [&](int ktr, Stage& sg) {
+    const int kt = kt0 + ktr;                  // absolute k-tile; tiles at or beyond this split's end load as zeros
+    const bool in_split = ktr < nk;
     // ---- A
-    const bool kval = (kt * BK + kq * 4) < d.K;
+    const bool kval = in_split && (kt * BK + kq * 4) < d.K;
     if (conv) {
       const int ky = (a_tap * 11) >> 5;                 // a_tap / 3 for a_tap < 32 (ksize 3); ksize 1 -> tap 0
       const int kyy = d.ksize == 3 ? ky : 0;
@@ -162,7 +169,7 @@ __global__ void __launch_bounds__(BF_THREADS) gemm_conv_bf16_kernel(const ddpo_g
     }
     // ---- W
     const int kb = kt * BK + bc * 8;
-    const bool bval = kb < d.K;
+    const bool bval = in_split && kb < d.K;
 #pragma unroll
     for (int i = 0; i < BCH; ++i) {
       const int n = n0 + (t >> 2) + 64 * i;
@@ -215,7 +222,6 @@ __global__ void __launch_bounds__(BF_THREADS) gemm_conv_bf16_kernel(const ddpo_g
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nk = (d.K + BK - 1) / BK;
   const int khalf = lane >> 5;
   int a_ld[BK / 16][TM], b_ld[BK / 16][TN];
 #pragma unroll
@@ -274,6 +280,22 @@ __global__ void __launch_bounds__(BF_THREADS) gemm_conv_bf16_kernel(const ddpo_g
     __syncthreads();
   }
 
+  if (part) {      // split-K: raw partial sums, epilogue applied by splitk_reduce_kernel
+    float* pp = part + (int64_t)blockIdx.y * d.M * d.N;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+        if (col >= d.N) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+          if (row < d.M) pp[(int64_t)row * d.N + col] = acc[i][j][r];
+        }
+      }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -294,10 +316,46 @@ __global__ void __launch_bounds__(BF_THREADS) gemm_conv_bf16_kernel(const ddpo_g
   }
 }
 
+// fixed-order reduction of the split-K partials + the fused epilogue (bit-reproducible: no atomics)
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const ddpo_gemm_desc d, const float* __restrict__ part, int splits) {
+  const int n4 = d.N >> 2;
+  const int64_t total = (int64_t)d.M * n4, mn = (int64_t)d.M * d.N;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int row = (int)(i / n4), col = (int)(i - (int64_t)row * n4) << 2;
+    float4 a = *reinterpret_cast<const float4*>(part + (int64_t)row * d.N + col);
+    for (int s = 1; s < splits; ++s) {
+      const float4 b = *reinterpret_cast<const float4*>(part + s * mn + (int64_t)row * d.N + col);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    float v[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float x = d.alpha * v[e] + (d.bias ? d.bias[col + e] : 0.f);
+      if (d.rowbias) x += d.rowbias[(int64_t)(row / d.rows_per_batch) * d.ld_rowbias + col + e];
+      if (d.residual) x += d.residual[(int64_t)row * d.ld_res + col + e];
+      d.out[(int64_t)row * d.ld_out + col + e] = x;
+    }
+  }
+}
+
 template <int BM, int BN, int NPASS>
-static int launch_bf16(const ddpo_gemm_desc& d, const uint16_t* w_hi, const uint16_t* w_lo, int ldw, hipStream_t st) {
+static int launch_bf16(const ddpo_gemm_desc& d, const uint16_t* w_hi, const uint16_t* w_lo, int ldw, float* ws, size_t ws_bytes,
+                       hipStream_t st) {
   const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;
   const int nblk = tiles_m * tiles_n;
+  // split-K when the tile grid under-fills the 256 CUs and the reduction is long (8x8 / 16x16 latent levels)
+  const int nk_total = (d.K + BF_BK - 1) / BF_BK;
+  int splits = 1;
+  if (ws && nblk < 192 && nk_total >= 32 && (d.N & 3) == 0) {
+    splits = (384 + nblk - 1) / nblk;
+    if (splits > 8) splits = 8;
+    if (splits > nk_total / 8) splits = nk_total / 8;
+    while (splits > 1 && (size_t)splits * d.M * d.N * sizeof(float) > ws_bytes) --splits;
+  }
+  int ktps = (nk_total + splits - 1) / splits;
+  ktps = (ktps + 1) & ~1;                                  // the pipelined loop consumes k-tiles in pairs
+  splits = (nk_total + ktps - 1) / ktps;
+  float* part = splits > 1 ? ws : nullptr;
   constexpr int NPL = (NPASS == 3) ? 2 : 1;
   const size_t lds = 2 * NPL * (size_t)(BM + BN) * 64;
   static bool attr_set = false;
@@ -309,17 +367,23 @@ static int launch_bf16(const ddpo_gemm_desc& d, const uint16_t* w_hi, const uint
     attr_set = true;
   }
   if (d.upsample == 0)
-    hipLaunchKernelGGL((gemm_conv_bf16_kernel<BM, BN, NPASS, true>), dim3(nblk), dim3(BF_THREADS), lds, st, d, w_hi, w_lo, ldw,
-                       tiles_m, tiles_n, nblk);
+    hipLaunchKernelGGL((gemm_conv_bf16_kernel<BM, BN, NPASS, true>), dim3(nblk, splits), dim3(BF_THREADS), lds, st, d, w_hi, w_lo, ldw,
+                       tiles_m, tiles_n, nblk, ktps, part);
   else
-    hipLaunchKernelGGL((gemm_conv_bf16_kernel<BM, BN, NPASS, false>), dim3(nblk), dim3(BF_THREADS), lds, st, d, w_hi, w_lo, ldw,
-                       tiles_m, tiles_n, nblk);
+    hipLaunchKernelGGL((gemm_conv_bf16_kernel<BM, BN, NPASS, false>), dim3(nblk, splits), dim3(BF_THREADS), lds, st, d, w_hi, w_lo, ldw,
+                       tiles_m, tiles_n, nblk, ktps, part);
   DDPO_LAUNCH_CHECK();
+  if (splits > 1) {
+    int64_t blocks = ((int64_t)d.M * (d.N >> 2) + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)blocks), dim3(256), 0, st, d, part, splits);
+    DDPO_LAUNCH_CHECK();
+  }
   return DDPO_OK;
 }
 
 extern "C" int ddpo_gemm_conv_fwd_bf16(const ddpo_gemm_desc* dp, const uint16_t* w_hi, const uint16_t* w_lo, int ldw, int npass,
-                                       void* stream) {
+                                       void* ws, size_t ws_bytes, void* stream) {
   if (!dp || !w_hi) return DDPO_EINVAL;
   const ddpo_gemm_desc& d = *dp;
   if (npass != 1 && npass != 3) return DDPO_EINVAL;
@@ -341,8 +405,10 @@ extern "C" int ddpo_gemm_conv_fwd_bf16(const ddpo_gemm_desc* dp, const uint16_t*
   hipStream_t st = as_stream(stream);
   const long t128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128);
   const bool big = (d.N % 128 == 0) && t128 >= 256;
-  if (npass == 3) return big ? launch_bf16<128, 128, 3>(d, w_hi, w_lo, ldw, st) : launch_bf16<128, 64, 3>(d, w_hi, w_lo, ldw, st);
-  return big ? launch_bf16<128, 128, 1>(d, w_hi, w_lo, ldw, st) : launch_bf16<128, 64, 1>(d, w_hi, w_lo, ldw, st);
+  float* wsf = (ws && !(reinterpret_cast<uintptr_t>(ws) & 15)) ? reinterpret_cast<float*>(ws) : nullptr;
+  if (npass == 3)
+    return big ? launch_bf16<128, 128, 3>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st) : launch_bf16<128, 64, 3>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st);
+  return big ? launch_bf16<128, 128, 1>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st) : launch_bf16<128, 64, 1>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st);
 }
 
 // ------------------------------------------------------------------------------------------------

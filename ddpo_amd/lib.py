@@ -56,7 +56,7 @@ _SIGS = {
     "ddpo_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "ddpo_gemm_conv_fwd": (c_int, [POINTER(GemmDesc), c_void_p]),
     "ddpo_gemm_conv_wgrad": (c_int, [POINTER(GemmDesc), c_void_p]),
-    "ddpo_gemm_conv_fwd_bf16": (c_int, [POINTER(GemmDesc), c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "ddpo_gemm_conv_fwd_bf16": (c_int, [POINTER(GemmDesc), c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "ddpo_gemm_conv_wgrad_bf16x3": (c_int, [POINTER(GemmDesc), c_void_p]),
     "ddpo_pack_weights_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ddpo_attention_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int,
@@ -92,6 +92,7 @@ _lib = None
 # 3 passes, ~1e-5 relative) or "bf16" (single pass = XLA's TPU default precision).  The bf16 paths are used for
 # weights that have been registered with `pack_weights` (ParamStore.pack_bf16); everything else stays on fp32.
 DATAPATH = os.environ.get("DDPO_DATAPATH", "fp32")
+SPLITK_WS_BYTES = 64 << 20       # scratch for the deterministic split-K of under-filled launches
 PACKED = {}          # data_ptr of an fp32 weight tensor -> dict(fwd=(hi, lo, Kp), bwd=(hi, lo) | None, K, N)
 
 # When set to a list, every ddpo_gemm_conv_fwd launch appends (start_event, end_event, algorithmic_flops);
@@ -335,7 +336,8 @@ def gemm_conv(src, w, *, M, N, K, bias=None, rowbias=None, rows_per_batch=0, res
         e0.record()
     if route is not None:
         hi, lo, ldw, npass = route
-        _check(load().ddpo_gemm_conv_fwd_bf16(byref(d), _p(hi), _p(lo), ldw, npass, _stream()), "ddpo_gemm_conv_fwd_bf16")
+        ws = _scratch(SPLITK_WS_BYTES, src.device, "splitk")
+        _check(load().ddpo_gemm_conv_fwd_bf16(byref(d), _p(hi), _p(lo), ldw, npass, _p(ws), SPLITK_WS_BYTES, _stream()), "ddpo_gemm_conv_fwd_bf16")
     else:
         _check(load().ddpo_gemm_conv_fwd(byref(d), _stream()), "ddpo_gemm_conv_fwd")
     if PROFILE is not None:
@@ -450,8 +452,9 @@ def linear_dgrad(dy, w, residual=None):
         d.out = out.data_ptr(); d.ld_out = int(K)
         d.alpha = 1.0
         d.M, d.N, d.K = int(M), int(K), int(N)
+        ws = _scratch(SPLITK_WS_BYTES, dy.device, "splitk")
         _check(load().ddpo_gemm_conv_fwd_bf16(byref(d), _p(ent["bwd"][0]), _p(ent["bwd"][1]), int(N), 3 if DATAPATH == "bf16x3" else 1,
-                                              _stream()), "ddpo_gemm_conv_fwd_bf16(dgrad)")
+                                              _p(ws), SPLITK_WS_BYTES, _stream()), "ddpo_gemm_conv_fwd_bf16(dgrad)")
         return out
     return gemm_conv(dy, w, M=M, N=K, K=N, w_trans=True, residual=residual)
 
@@ -521,7 +524,9 @@ def conv2d_dgrad(dy, w, B, H, W, Cin, Cout, ksize, stride=1, residual=None):
     route = _bf16_route(w, d.K, d.N, conv, True)
     if route is not None:
         hi, lo, _, npass = route
-        _check(load().ddpo_gemm_conv_fwd_bf16(byref(d), _p(hi), _p(lo), 0, npass, _stream()), "ddpo_gemm_conv_fwd_bf16(dgrad)")
+        ws = _scratch(SPLITK_WS_BYTES, dy.device, "splitk")
+        _check(load().ddpo_gemm_conv_fwd_bf16(byref(d), _p(hi), _p(lo), 0, npass, _p(ws), SPLITK_WS_BYTES, _stream()),
+               "ddpo_gemm_conv_fwd_bf16(dgrad)")
     else:
         _check(load().ddpo_gemm_conv_fwd(byref(d), _stream()), "ddpo_gemm_conv_fwd(dgrad)")
     return out

@@ -149,7 +149,9 @@ int ddpo_gemm_conv_wgrad(const ddpo_gemm_desc* d, void* stream);
  * ddpo_pack_weights_bf16: forward order (N, ldw=Kp) for the forward pass, the original (K, N) order with
  * d->w_dgrad = 1 for data gradients.  d->w / d->w_trans are ignored.  Requires Cin % 8 == 0 (K % 8 == 0 if dense). */
 int ddpo_gemm_conv_fwd_bf16(const ddpo_gemm_desc* d, const uint16_t* w_hi, const uint16_t* w_lo, int ldw, int npass,
-                            void* stream);
+                            void* ws, size_t ws_bytes, void* stream);
+/* ws (optional, 16-byte aligned): scratch for a deterministic split-K of launches whose tile grid under-fills the chip
+ * (partials + fixed-order reduce with the fused epilogue); pass NULL/0 to disable. */
 /* Weight gradient on the bf16x3 MFMA datapath (same arguments as ddpo_gemm_conv_wgrad; always accumulates with fp32
  * atomics).  Fast path only: dense, or convolutions with stride 1, pad = ksize/2 and no upsampling (returns
  * DDPO_EINVAL otherwise - callers fall back to ddpo_gemm_conv_wgrad). */
