@@ -65,6 +65,8 @@ _SIGS = {
                                           c_int, c_int, c_int, c_float, c_void_p]),
     "ddpo_attention_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "ddpo_attention_bwd_bf16x3": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "ddpo_groupnorm_stats_floats": (c_size_t, [c_int, c_int, c_int]),
     "ddpo_groupnorm_bwd_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "ddpo_groupnorm_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
@@ -388,9 +390,11 @@ def attention_bwd(q, k, v, o, d_o, lse, B, heads, Nq, Nk, d, scale=None):
     dk = torch.empty(B * Nk, C, dtype=torch.float32, device=q.device)
     dv = torch.empty(B * Nk, C, dtype=torch.float32, device=q.device)
     dvec = torch.empty(B * heads * Nq, dtype=torch.float32, device=q.device)
-    _check(load().ddpo_attention_bwd(_p(q), C, _p(k), C, _p(v), C, _p(o), _p(d_o), _p(lse), _p(dvec), _p(dq), _p(dk), _p(dv),
-                                     B, heads, Nq, Nk, d, float(scale if scale is not None else d ** -0.5), _stream()),
-           "ddpo_attention_bwd")
+    fn, name = load().ddpo_attention_bwd, "ddpo_attention_bwd"
+    if DATAPATH != "fp32" and d in (8, 16, 40, 64, 80):
+        fn, name = load().ddpo_attention_bwd_bf16x3, "ddpo_attention_bwd_bf16x3"
+    _check(fn(_p(q), C, _p(k), C, _p(v), C, _p(o), _p(d_o), _p(lse), _p(dvec), _p(dq), _p(dk), _p(dv),
+              B, heads, Nq, Nk, d, float(scale if scale is not None else d ** -0.5), _stream()), name)
     return dq, dk, dv
 
 

@@ -178,6 +178,11 @@ int ddpo_attention_bwd(const float* q, int ldq, const float* k, int ldk, const f
                        const float* d_o, const float* lse, float* dvec, float* dq, float* dk, float* dv,
                        int B, int heads, int Nq, int Nk, int d, float scale, void* stream);
 
+/* Attention backward on the bf16x3 datapath (same arguments; d in {8, 16, 40, 64, 80}). */
+int ddpo_attention_bwd_bf16x3(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o,
+                              const float* d_o, const float* lse, float* dvec, float* dq, float* dk, float* dv,
+                              int B, int heads, int Nq, int Nk, int d, float scale, void* stream);
+
 /* Small element-wise pieces. */
 int ddpo_geglu_fwd(const float* x, float* y, int64_t rows, int F, void* stream);      /* y = x[:, :F] * gelu_tanh(x[:, F:]) */
 int ddpo_silu_fwd(const float* x, float* y, int64_t n, void* stream);

@@ -164,3 +164,20 @@ def test_linear_wgrad_bf16x3(datapath, M, K, N):
     dw = torch.zeros(K, N, device=DEV)
     L.linear_wgrad(x.to(DEV), dy.to(DEV), dw)
     assert _rel(dw, x.double().t() @ dy.double()) < 5e-5
+
+
+@pytest.mark.parametrize("B,heads,Nq,Nk,d", [(2, 8, 64, 64, 8), (1, 8, 200, 77, 16), (2, 8, 256, 256, 40), (2, 8, 1024, 77, 40),
+                                             (1, 8, 256, 256, 80), (1, 5, 130, 333, 64), (1, 8, 1024, 1024, 40)])
+def test_attention_bwd_bf16x3(datapath, B, heads, Nq, Nk, d):
+    L.DATAPATH = "bf16x3"
+    g = torch.Generator().manual_seed(Nq + Nk + d)
+    C = heads * d
+    q, k, v = torch.randn(B * Nq, C, generator=g), torch.randn(B * Nk, C, generator=g), torch.randn(B * Nk, C, generator=g)
+    do = torch.randn(B * Nq, C, generator=g)
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
+    sp = lambda t, n: t.view(B, n, heads, d).permute(0, 2, 1, 3)
+    s_ = sp(qd, Nq) @ sp(kd, Nk).transpose(-1, -2) * d ** -0.5
+    (torch.softmax(s_, -1) @ sp(vd, Nk)).permute(0, 2, 1, 3).reshape(B * Nq, C).backward(do.double())
+    o, lse = L.attention(q.to(DEV), k.to(DEV), v.to(DEV), B, heads, Nq, Nk, d, return_lse=True)
+    dq, dk, dv = L.attention_bwd(q.to(DEV), k.to(DEV), v.to(DEV), o, do.to(DEV), lse, B, heads, Nq, Nk, d)
+    assert _rel(dq, qd.grad) < 2e-4 and _rel(dk, kd.grad) < 2e-4 and _rel(dv, vd.grad) < 2e-4
