@@ -189,29 +189,278 @@ __global__ void __launch_bounds__(256) attn_fwd_bf16_kernel(const float* __restr
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Long key sequences (self-attention at 64x64 / 32x32 latents): every 128-query workgroup of the kernel above re-splits
+// and re-transposes the same K / V tiles.  Here a pre-pass does that ONCE per (batch, head): it writes, per 64-key tile,
+// the exact LDS image [K hi | K lo | V^T hi | V^T lo] (padded pitches, zero padding included) to a workspace, and the
+// attention kernel streams images with 16-byte loads one tile ahead of the MFMAs (registers -> ds_write_b128): no
+// conversion, no 2-byte transpose scatter and no exposed global-load latency in the key loop.
+// ------------------------------------------------------------------------------------------------
+template <int D, int DKP, int DVP>
+struct AttnImg {
+  static constexpr int KT = 64, LDK = DKP + 8, LDVT = KT + 4;
+  static constexpr int K_BYTES = KT * LDK * 2, VT_BYTES = DVP * LDVT * 2;
+  static constexpr int BYTES = 2 * K_BYTES + 2 * VT_BYTES;       // multiple of 16
+  static constexpr int CHUNKS = BYTES / 16;
+};
+
+template <int D, int DKP, int DVP>
+__global__ void __launch_bounds__(256) attn_pack_kv_kernel(const float* __restrict__ k, int ldk, const float* __restrict__ v, int ldv,
+                                                           uint4* __restrict__ img, int heads, int Nk, int ntiles) {
+  using I = AttnImg<D, DKP, DVP>;
+  __shared__ __attribute__((aligned(16))) char smem[I::BYTES];
+  char* Khi = smem; char* Klo = smem + I::K_BYTES;
+  char* Vhi = smem + 2 * I::K_BYTES; char* Vlo = Vhi + I::VT_BYTES;
+  const int t = threadIdx.x;
+  const int tile = blockIdx.x, bh = blockIdx.y, b = bh / heads, hd = bh - b * heads;
+  const int kt0 = tile * I::KT;
+  for (int i = t; i < I::CHUNKS; i += 256) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0u, 0u, 0u, 0u);
+  __syncthreads();
+  const float* kb = k + (int64_t)b * Nk * ldk + hd * D;
+  const float* vb = v + (int64_t)b * Nk * ldv + hd * D;
+  for (int i = t; i < I::KT * (D / 4); i += 256) {
+    const int key = i / (D / 4), c4 = i - key * (D / 4);
+    if (kt0 + key >= Nk) continue;
+    const float4 kv = *reinterpret_cast<const float4*>(kb + (int64_t)(kt0 + key) * ldk + c4 * 4);
+    const float4 vv = *reinterpret_cast<const float4*>(vb + (int64_t)(kt0 + key) * ldv + c4 * 4);
+    uint32_t h0, l0, h1, l1;
+    split2(kv.x, kv.y, h0, l0);
+    split2(kv.z, kv.w, h1, l1);
+    *reinterpret_cast<uint2*>(Khi + (key * I::LDK + c4 * 4) * 2) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(Klo + (key * I::LDK + c4 * 4) * 2) = make_uint2(l0, l1);
+    split2(vv.x, vv.y, h0, l0);
+    split2(vv.z, vv.w, h1, l1);
+    uint16_t* vh = reinterpret_cast<uint16_t*>(Vhi);
+    uint16_t* vl = reinterpret_cast<uint16_t*>(Vlo);
+    const int d0 = c4 * 4;
+    vh[(d0 + 0) * I::LDVT + key] = (uint16_t)(h0 & 0xFFFFu); vh[(d0 + 1) * I::LDVT + key] = (uint16_t)(h0 >> 16);
+    vh[(d0 + 2) * I::LDVT + key] = (uint16_t)(h1 & 0xFFFFu); vh[(d0 + 3) * I::LDVT + key] = (uint16_t)(h1 >> 16);
+    vl[(d0 + 0) * I::LDVT + key] = (uint16_t)(l0 & 0xFFFFu); vl[(d0 + 1) * I::LDVT + key] = (uint16_t)(l0 >> 16);
+    vl[(d0 + 2) * I::LDVT + key] = (uint16_t)(l1 & 0xFFFFu); vl[(d0 + 3) * I::LDVT + key] = (uint16_t)(l1 >> 16);
+  }
+  __syncthreads();
+  uint4* dst = img + ((int64_t)bh * ntiles + tile) * I::CHUNKS;
+  for (int i = t; i < I::CHUNKS; i += 256) dst[i] = reinterpret_cast<const uint4*>(smem)[i];
+}
+
+template <int D, int DKP, int DVP>
+__global__ void __launch_bounds__(256, (DVP <= 32 ? 4 : (DKP <= 48 ? 3 : 2))) attn_fwd_bf16_pk_kernel(const float* __restrict__ q, int ldq, const uint4* __restrict__ img,
+                                                               float* __restrict__ o, int ldo, float* __restrict__ lse, int heads,
+                                                               int Nq, int Nk, int ntiles, float scale_log2e) {
+  using I = AttnImg<D, DKP, DVP>;
+  constexpr int KT = I::KT, LDK = I::LDK, LDVT = I::LDVT;
+  constexpr int NKS = DKP / 16, NDT = DVP / 32;
+  constexpr int NCH = (I::CHUNKS + 255) / 256;
+  __shared__ __attribute__((aligned(16))) char smem[I::BYTES];
+  const char* Khi = smem; const char* Klo = smem + I::K_BYTES;
+  const char* Vhi = smem + 2 * I::K_BYTES; const char* Vlo = Vhi + I::VT_BYTES;
+
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+  const int li = lane & 31, h = lane >> 5;
+  const int bh = blockIdx.y, b = bh / heads, hd = bh - b * heads;
+  const int q0 = blockIdx.x * 128 + wid * 32;
+  const int qrow = min(q0 + li, Nq - 1);
+
+  bf16x8 qh[NKS], ql[NKS];
+  {
+    const float* qp = q + ((int64_t)b * Nq + qrow) * ldq + hd * D;
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) {
+      uint32_t hi[4], lo[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int dk = 16 * s + 8 * h + 2 * e;
+        const float a = dk < D ? qp[dk] * scale_log2e : 0.f;
+        const float c = dk + 1 < D ? qp[dk + 1] * scale_log2e : 0.f;
+        split2(a, c, hi[e], lo[e]);
+      }
+      qh[s] = __builtin_bit_cast(bf16x8, make_uint4(hi[0], hi[1], hi[2], hi[3]));
+      ql[s] = __builtin_bit_cast(bf16x8, make_uint4(lo[0], lo[1], lo[2], lo[3]));
+    }
+  }
+
+  f32x16 oacc[NDT];
+#pragma unroll
+  for (int n = 0; n < NDT; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[n][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const uint4* src = img + (int64_t)bh * ntiles * I::CHUNKS;
+  uint4 pre[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int i = t + 256 * c;
+    pre[c] = (NCH * 256 == I::CHUNKS || i < I::CHUNKS) ? src[i] : make_uint4(0u, 0u, 0u, 0u);
+  }
+
+  for (int tile = 0; tile < ntiles; ++tile) {
+    const int kt0 = tile * KT;
+    __syncthreads();                       // every wave is done reading the previous image
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int i = t + 256 * c;
+      if (NCH * 256 == I::CHUNKS || i < I::CHUNKS) reinterpret_cast<uint4*>(smem)[i] = pre[c];
+    }
+    __syncthreads();
+    {                                      // next image streams in behind the MFMAs of this one (last tile: re-reads itself)
+      const uint4* nsrc = src + (int64_t)min(tile + 1, ntiles - 1) * I::CHUNKS;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int i = t + 256 * c;
+        pre[c] = (NCH * 256 == I::CHUNKS || i < I::CHUNKS) ? nsrc[i] : make_uint4(0u, 0u, 0u, 0u);
+      }
+    }
+
+    f32x16 sacc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[j][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int off = ((j * 32 + li) * LDK + 16 * s + 8 * h) * 2;
+        const bf16x8 kh = *reinterpret_cast<const bf16x8*>(Khi + off);
+        const bf16x8 kl = *reinterpret_cast<const bf16x8*>(Klo + off);
+        sacc[j] = MFMA32(kl, qh[s], sacc[j]);
+        sacc[j] = MFMA32(kh, ql[s], sacc[j]);
+        sacc[j] = MFMA32(kh, qh[s], sacc[j]);
+      }
+    }
+    if (kt0 + KT > Nk) {                   // only the last tile can hold padded keys (uniform branch)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (kt0 + 32 * j + (r & 3) + 8 * (r >> 2) + 4 * h >= Nk) sacc[j][r] = -INFINITY;
+    }
+    float mx = sacc[0][0];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[j][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    const bool grew = m_new > m_run;
+    m_run = m_new;
+    float ls = 0.f;
+    bf16x8 ph[4], pl[4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        uint32_t hi[4], lo[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float p0 = __builtin_amdgcn_exp2f(sacc[j][8 * half + 2 * e] - m_new);
+          const float p1 = __builtin_amdgcn_exp2f(sacc[j][8 * half + 2 * e + 1] - m_new);
+          ls += p0 + p1;
+          split2(p0, p1, hi[e], lo[e]);
+        }
+        ph[2 * j + half] = __builtin_bit_cast(bf16x8, make_uint4(hi[0], hi[1], hi[2], hi[3]));
+        pl[2 * j + half] = __builtin_bit_cast(bf16x8, make_uint4(lo[0], lo[1], lo[2], lo[3]));
+      }
+    }
+    l_run = l_run * alpha + ls;
+    if (__any(grew)) {                     // the running maximum settles after a few tiles; skip the no-op rescale (alpha == 1)
+#pragma unroll
+      for (int n = 0; n < NDT; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[n][r] *= alpha;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int n = 0; n < NDT; ++n) {
+        const int off = ((32 * n + li) * LDVT + 16 * u + 4 * h) * 2;
+        const uint2 a0 = *reinterpret_cast<const uint2*>(Vhi + off), a1 = *reinterpret_cast<const uint2*>(Vhi + off + 16);
+        const uint2 c0 = *reinterpret_cast<const uint2*>(Vlo + off), c1 = *reinterpret_cast<const uint2*>(Vlo + off + 16);
+        const bf16x8 vh = __builtin_bit_cast(bf16x8, make_uint4(a0.x, a0.y, a1.x, a1.y));
+        const bf16x8 vl = __builtin_bit_cast(bf16x8, make_uint4(c0.x, c0.y, c1.x, c1.y));
+        oacc[n] = MFMA32(vl, ph[u], oacc[n]);
+        oacc[n] = MFMA32(vh, pl[u], oacc[n]);
+        oacc[n] = MFMA32(vh, ph[u], oacc[n]);
+      }
+    }
+  }
+
+  float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  if (lse && h == 0 && q0 + li < Nq) lse[(int64_t)bh * Nq + q0 + li] = m_run + log2f(l_tot);
+  if (q0 + li < Nq) {
+    float* op = o + ((int64_t)b * Nq + q0 + li) * ldo + hd * D;
+#pragma unroll
+    for (int n = 0; n < NDT; ++n) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int dc = 32 * n + 8 * g + 4 * h;
+        if (dc < D) *reinterpret_cast<float4*>(op + dc) =
+            make_float4(oacc[n][4 * g] * inv, oacc[n][4 * g + 1] * inv, oacc[n][4 * g + 2] * inv, oacc[n][4 * g + 3] * inv);
+      }
+    }
+  }
+}
+
+#define ATTN_PK_MIN_NK 256      /* shorter key sequences (cross-attention over 77 tokens) stay on the self-staging kernel */
+
 template <int D, int DKP, int DVP>
 static int launch_attn_bf16(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo, float* lse,
-                            int B, int heads, int Nq, int Nk, float scale, hipStream_t st) {
+                            int B, int heads, int Nq, int Nk, float scale, void* ws, size_t ws_bytes, hipStream_t st) {
+  using I = AttnImg<D, DKP, DVP>;
   dim3 grid((Nq + 127) / 128, B * heads);
+  const int ntiles = (Nk + I::KT - 1) / I::KT;
+  const size_t need = (size_t)B * heads * ntiles * I::BYTES;
+  if (Nk >= ATTN_PK_MIN_NK && ws && ws_bytes >= need && !(reinterpret_cast<uintptr_t>(ws) & 15)) {
+    uint4* img = reinterpret_cast<uint4*>(ws);
+    hipLaunchKernelGGL((attn_pack_kv_kernel<D, DKP, DVP>), dim3(ntiles, B * heads), dim3(256), 0, st, k, ldk, v, ldv, img, heads, Nk, ntiles);
+    DDPO_LAUNCH_CHECK();
+    hipLaunchKernelGGL((attn_fwd_bf16_pk_kernel<D, DKP, DVP>), grid, dim3(256), 0, st, q, ldq, img, o, ldo, lse, heads, Nq, Nk, ntiles,
+                       scale * 1.4426950408889634f);
+    DDPO_LAUNCH_CHECK();
+    return DDPO_OK;
+  }
   hipLaunchKernelGGL((attn_fwd_bf16_kernel<D, DKP, DVP>), grid, dim3(256), 0, st, q, ldq, k, ldk, v, ldv, o, ldo, lse, heads, Nq, Nk,
                      scale * 1.4426950408889634f);
   DDPO_LAUNCH_CHECK();
   return DDPO_OK;
 }
 
+template <int D, int DKP, int DVP>
+static size_t attn_ws(int B, int heads, int Nk) {
+  using I = AttnImg<D, DKP, DVP>;
+  if (Nk < ATTN_PK_MIN_NK) return 0;
+  return (size_t)B * heads * ((Nk + I::KT - 1) / I::KT) * I::BYTES;
+}
+
+extern "C" size_t ddpo_attention_fwd_bf16x3_ws_bytes(int B, int heads, int Nk, int d) {
+  if (B <= 0 || heads <= 0 || Nk <= 0) return 0;
+  switch (d) {
+    case 8:  return attn_ws<8, 16, 32>(B, heads, Nk);
+    case 16: return attn_ws<16, 16, 32>(B, heads, Nk);
+    case 40: return attn_ws<40, 48, 64>(B, heads, Nk);
+    case 64: return attn_ws<64, 64, 64>(B, heads, Nk);
+    case 80: return attn_ws<80, 80, 96>(B, heads, Nk);
+    default: return 0;
+  }
+}
+
 extern "C" int ddpo_attention_fwd_bf16x3(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
-                                         float* lse, int B, int heads, int Nq, int Nk, int d, float scale, void* stream) {
+                                         float* lse, int B, int heads, int Nq, int Nk, int d, float scale, void* ws, size_t ws_bytes,
+                                         void* stream) {
   if (!q || !k || !v || !o || B <= 0 || heads <= 0 || Nq <= 0 || Nk <= 0) return DDPO_EINVAL;
   if ((ldq & 3) || (ldk & 3) || (ldv & 3) || (ldo & 3) || (long)B * heads > 65535) return DDPO_EINVAL;
   if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v) |
        reinterpret_cast<uintptr_t>(o)) & 15) return DDPO_EINVAL;
   hipStream_t st = as_stream(stream);
   switch (d) {
-    case 8:  return launch_attn_bf16<8, 16, 32>(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, heads, Nq, Nk, scale, st);
-    case 16: return launch_attn_bf16<16, 16, 32>(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, heads, Nq, Nk, scale, st);
-    case 40: return launch_attn_bf16<40, 48, 64>(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, heads, Nq, Nk, scale, st);
-    case 64: return launch_attn_bf16<64, 64, 64>(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, heads, Nq, Nk, scale, st);
-    case 80: return launch_attn_bf16<80, 80, 96>(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, heads, Nq, Nk, scale, st);
+    case 8:  return launch_attn_bf16<8, 16, 32>(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, heads, Nq, Nk, scale, ws, ws_bytes, st);
+    case 16: return launch_attn_bf16<16, 16, 32>(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, heads, Nq, Nk, scale, ws, ws_bytes, st);
+    case 40: return launch_attn_bf16<40, 48, 64>(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, heads, Nq, Nk, scale, ws, ws_bytes, st);
+    case 64: return launch_attn_bf16<64, 64, 64>(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, heads, Nq, Nk, scale, ws, ws_bytes, st);
+    case 80: return launch_attn_bf16<80, 80, 96>(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, heads, Nq, Nk, scale, ws, ws_bytes, st);
     default: return DDPO_EINVAL;      // other head dims stay on the exact-fp32 kernel
   }
 }

@@ -316,6 +316,300 @@ __global__ void __launch_bounds__(BF_THREADS) gemm_conv_bf16_kernel(const ddpo_g
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fast variant for the regular layers (conv: Cin % 32 == 0; dense: K % 32 == 0; every byte offset < 2^31): operands are
+// fetched with raw BUFFER loads.  A k-tile of 32 never straddles a filter tap, so the tap is wave-uniform: the per-row
+// byte offsets of the current tap live in VGPRs and are recomputed only when the tap changes (every Cin/32 k-tiles,
+// covering padding, stride, nearest-2x upsampling and zero-insertion alike); masked rows carry an out-of-range offset
+// and the buffer unit returns zeros for them.  The per-k-tile advance is one scalar add on the instruction's soffset:
+// no per-load branches, no 64-bit address arithmetic, no zero-fill moves (the generic kernel above spends ~8 VALU +
+// 1 branch per MFMA on those; here the only VALU work left in the k-loop is the fp32 -> bf16 hi/lo split).
+// ------------------------------------------------------------------------------------------------
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define BUF_OOB 0x80000000u
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7FFFFFFF, 0x00020000);
+}
+
+template <int BM, int BN, int NPASS, int ABL = 0>     // ABL: timing ablations for tools/ablate_gemm.py only (wrong results)
+__global__ void __launch_bounds__(BF_THREADS) gemm_conv_bf16_buf_kernel(const ddpo_gemm_desc d, const uint16_t* __restrict__ w_hi,
+                                                                       const uint16_t* __restrict__ w_lo, int ldw, int tiles_m,
+                                                                       int tiles_n, int nblk, int kt_per_split,
+                                                                       float* __restrict__ part) {
+  constexpr int BK = BF_BK;
+  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int AROWS = BM / 32;
+  constexpr int BCH = BN / 64;
+  constexpr int NPL = (NPASS == 3) ? 2 : 1;
+  constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int STAGE = NPL * (A_BYTES + B_BYTES);
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+
+  int bid = blockIdx.x;
+  {
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int q = nblk >> 3, r = nblk & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  constexpr int GROUP_M = 8;
+  const int per_group = GROUP_M * tiles_n;
+  const int group = bid / per_group, in_group = bid - group * per_group;
+  const int gm0 = group * GROUP_M;
+  const int gsz = min(tiles_m - gm0, GROUP_M);
+  const int tile_n = in_group / gsz, tile_m = gm0 + (in_group - tile_n * gsz);
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const bool conv = d.ksize > 0;
+  const int VH = d.upsample ? d.H * 2 : d.H, VW = d.upsample ? d.W * 2 : d.W;
+  const bool zins = d.upsample == 2;
+  const int cin = conv ? d.Cin : d.K;            // reduction channels per tap (dense: one "tap" spanning K)
+  const int ntaps = conv ? d.ksize * d.ksize : 1;
+
+  const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(d.src);
+  const __amdgpu_buffer_rsrc_t rs_wh = make_rsrc(w_hi);
+  const __amdgpu_buffer_rsrc_t rs_wl = make_rsrc(NPASS == 3 ? w_lo : w_hi);
+
+  // ---- A rows of this thread: (t>>3) + 32*i, float4 index kq inside the 32-wide k-tile
+  const int kq = t & 7;
+  int aiy0[AROWS], aix0[AROWS], apix[AROWS];    // top-left input coordinate and batch pixel base; invalid rows get iy0 << 0
+  uint32_t avoff[AROWS];                        // byte offset of the CURRENT tap's pixel (+ kq*16), or BUF_OOB
+#pragma unroll
+  for (int i = 0; i < AROWS; ++i) {
+    const int m = m0 + (t >> 3) + 32 * i;
+    const bool valid = m < d.M;
+    if (conv) {
+      const int ohw = d.OH * d.OW;
+      const int mm = valid ? m : 0;
+      const int b = mm / ohw, rem = mm - b * ohw;
+      const int oy = rem / d.OW, ox = rem - oy * d.OW;
+      aiy0[i] = valid ? oy * d.stride - d.pad : -(1 << 24);
+      aix0[i] = ox * d.stride - d.pad;
+      apix[i] = b * d.H * d.W;
+      avoff[i] = BUF_OOB;
+    } else {
+      aiy0[i] = aix0[i] = apix[i] = 0;
+      avoff[i] = valid ? (uint32_t)m * (uint32_t)d.ld_src * 4u + kq * 16u : BUF_OOB;
+    }
+  }
+  auto set_tap = [&](int tap) {                 // conv only; wave-uniform tap
+    const int ky = d.ksize == 3 ? (tap * 11) >> 5 : 0;
+    const int kx = d.ksize == 3 ? tap - ky * 3 : 0;
+#pragma unroll
+    for (int i = 0; i < AROWS; ++i) {
+      const int iy = aiy0[i] + ky, ix = aix0[i] + kx;
+      const bool ok = (unsigned)iy < (unsigned)VH && (unsigned)ix < (unsigned)VW && !(zins && ((iy | ix) & 1));
+      const int sy = d.upsample ? (iy >> 1) : iy, sx = d.upsample ? (ix >> 1) : ix;
+      const uint32_t off = (uint32_t)(apix[i] + sy * d.W + sx) * (uint32_t)d.ld_src * 4u + kq * 16u;
+      avoff[i] = ok ? off : BUF_OOB;
+    }
+  };
+
+  // ---- W rows of this thread: (t>>2) + 64*i, 16-byte chunk bc of the k-tile
+  const int bc = t & 3;
+  uint32_t bvoff[BCH];
+#pragma unroll
+  for (int i = 0; i < BCH; ++i) {
+    const int n = n0 + (t >> 2) + 64 * i;
+    const uint32_t row_bytes = d.w_dgrad ? (uint32_t)d.Cin * 2u : (uint32_t)ldw * 2u;
+    bvoff[i] = n < d.N ? (uint32_t)n * row_bytes + bc * 16u : BUF_OOB;
+  }
+
+  const int nk_total = d.K / BK;
+  const int kt0 = blockIdx.y * kt_per_split;
+  const int nk = min(kt_per_split, nk_total - kt0);
+  // wave-uniform running position of the NEXT k-tile to load: tap index and channel base inside the tap
+  int tap = (kt0 * BK) / cin, cib = kt0 * BK - tap * cin;
+  if (conv) set_tap(tap);
+
+  struct Stage { float4 a[AROWS]; uint4 bh[BCH], bl[BCH]; };
+  Stage s0, s1;
+
+  // Loads are unconditional (a branch around them would make the compiler's s_waitcnt placement conservative and
+  // collapse the prefetch distance): requests past this split's last k-tile re-fetch the last tile and are never consumed.
+  auto load_tile = [&](int ktr, Stage& sg) {
+    const int so_a = cib * 4;
+    const int so_w = d.w_dgrad ? ((ntaps - 1 - tap) * d.N * d.Cin + cib) * 2 : (kt0 + min(ktr, nk - 1)) * (BK * 2);
+#pragma unroll
+    for (int i = 0; i < AROWS; ++i) {
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_a, avoff[i], so_a, 0);
+      sg.a[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    }
+#pragma unroll
+    for (int i = 0; i < BCH; ++i) {
+      const u32x4 h = __builtin_amdgcn_raw_buffer_load_b128(rs_wh, bvoff[i], so_w, 0);
+      sg.bh[i] = make_uint4(h.x, h.y, h.z, h.w);
+      if (NPASS == 3) {
+        const u32x4 l = __builtin_amdgcn_raw_buffer_load_b128(rs_wl, bvoff[i], so_w, 0);
+        sg.bl[i] = make_uint4(l.x, l.y, l.z, l.w);
+      }
+    }
+    if (ktr < nk - 1) {                         // uniform; no memory operations inside
+      cib += BK;
+      if (cib >= cin) {                         // next k-tile starts a new tap
+        cib = 0; ++tap;
+        if (conv) set_tap(tap);
+      }
+    }
+  };
+
+  int a_st[AROWS], b_st[BCH];
+#pragma unroll
+  for (int i = 0; i < AROWS; ++i) a_st[i] = swz_off((t >> 3) + 32 * i, kq >> 1) + (kq & 1) * 8;
+#pragma unroll
+  for (int i = 0; i < BCH; ++i) b_st[i] = swz_off((t >> 2) + 64 * i, bc);
+
+  auto store_tile = [&](int buf, const Stage& sg) {
+    char* st = smem + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < AROWS; ++i) {
+      uint2 hi, lo;
+      split4(sg.a[i], hi, lo);
+      *reinterpret_cast<uint2*>(st + a_st[i]) = hi;
+      if (NPASS == 3) *reinterpret_cast<uint2*>(st + A_BYTES + a_st[i]) = lo;
+    }
+    char* sb = st + NPL * A_BYTES;
+#pragma unroll
+    for (int i = 0; i < BCH; ++i) {
+      *reinterpret_cast<uint4*>(sb + b_st[i]) = sg.bh[i];
+      if (NPASS == 3) *reinterpret_cast<uint4*>(sb + B_BYTES + b_st[i]) = sg.bl[i];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int khalf = lane >> 5;
+  int a_ld[BK / 16][TM], b_ld[BK / 16][TN];
+#pragma unroll
+  for (int ks = 0; ks < BK / 16; ++ks) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a_ld[ks][i] = swz_off(wm * (BM / 2) + i * 32 + (lane & 31), ks * 2 + khalf);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b_ld[ks][j] = swz_off(wn * (BN / 2) + j * 32 + (lane & 31), ks * 2 + khalf);
+  }
+
+  // Fragment loads are software-pipelined by hand across the barrier: the ks=0 fragments of the NEXT k-tile are requested
+  // right after the barrier that publishes it and the second half of the current tile's ks=1 MFMAs is issued behind them,
+  // so the LDS latency is covered by matrix work instead of stalling the wave at the top of every k-tile.
+  struct Frag { bf16x8 ah[TM], al[TM], bh[TN], bl[TN]; };
+  auto ldfrag = [&](int cur, int ks, Frag& f) {
+    const char* sa = smem + cur * STAGE;
+    const char* sb = sa + NPL * A_BYTES;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      f.ah[i] = *reinterpret_cast<const bf16x8*>(sa + a_ld[ks][i]);
+      if (NPASS == 3) f.al[i] = *reinterpret_cast<const bf16x8*>(sa + A_BYTES + a_ld[ks][i]);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      f.bh[j] = *reinterpret_cast<const bf16x8*>(sb + b_ld[ks][j]);
+      if (NPASS == 3) f.bl[j] = *reinterpret_cast<const bf16x8*>(sb + B_BYTES + b_ld[ks][j]);
+    }
+  };
+  auto mma = [&](const Frag& f, int ibeg, int iend) {       // row-blocks [ibeg, iend) of the wave tile
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      if (i < ibeg || i >= iend) continue;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if (NPASS == 3) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
+        }
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+      }
+    }
+  };
+  Frag f0, f1;
+  constexpr int TMH = TM / 2;
+
+  // prologue: tile 0 -> LDS[0]; tile 1 in flight in s0.  The loop consumes k-tiles in pairs; an odd last tile is
+  // computed after it (it already sits in LDS[0] with its ks=0 fragments in f0).
+  load_tile(0, s0);
+  store_tile(0, s0);
+  load_tile(1, s0);
+  __syncthreads();
+  ldfrag(0, 0, f0);
+  if (ABL & 8) ldfrag(0, 1, f1);
+  if (ABL & 1) s1 = s0;
+  const int nk2 = nk & ~1;
+#pragma unroll 1
+  for (int kt = 0; kt < nk2; kt += 2) {
+    // even step: MFMAs on LDS[0]; s0 holds tile kt+1, tile kt+2 starts loading into s1
+    if (!(ABL & 1)) load_tile(kt + 2, s1);
+    if (!(ABL & 8)) ldfrag(0, 1, f1);
+    mma(f0, 0, TM);
+    if (!(ABL & 2)) store_tile(1, s0);
+    __builtin_amdgcn_sched_barrier(0);          // LDS stores retire under the next MFMAs, not in front of the barrier
+    mma(f1, 0, TMH);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(ABL & 4)) __syncthreads();
+    if (!(ABL & 8)) ldfrag(1, 0, f0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(f1, TMH, TM);
+    // odd step: MFMAs on LDS[1]; s1 holds tile kt+2, tile kt+3 starts loading into s0
+    if (!(ABL & 1)) load_tile(kt + 3, s0);
+    if (!(ABL & 8)) ldfrag(1, 1, f1);
+    mma(f0, 0, TM);
+    if (!(ABL & 2)) store_tile(0, s1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(f1, 0, TMH);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(ABL & 4)) __syncthreads();
+    if (!(ABL & 8)) ldfrag(0, 0, f0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(f1, TMH, TM);
+  }
+  if (nk & 1) {
+    ldfrag(0, 1, f1);
+    mma(f0, 0, TM);
+    mma(f1, 0, TM);
+  }
+
+  if (part) {
+    float* pp = part + (int64_t)blockIdx.y * d.M * d.N;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+        if (col >= d.N) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+          if (row < d.M) pp[(int64_t)row * d.N + col] = acc[i][j][r];
+        }
+      }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+      if (col >= d.N) continue;
+      const float bv = d.bias ? d.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+        if (row >= d.M) continue;
+        float v = d.alpha * acc[i][j][r] + bv;
+        if (d.rowbias) v += d.rowbias[(int64_t)(row / d.rows_per_batch) * d.ld_rowbias + col];
+        if (d.residual) v += d.residual[(int64_t)row * d.ld_res + col];
+        d.out[(int64_t)row * d.ld_out + col] = v;
+      }
+    }
+  }
+}
+
 // fixed-order reduction of the split-K partials + the fused epilogue (bit-reproducible: no atomics)
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(const ddpo_gemm_desc d, const float* __restrict__ part, int splits) {
   const int n4 = d.N >> 2;
@@ -337,6 +631,24 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const ddpo_gemm_desc
     }
   }
 }
+
+// buffer-addressed fast path: k-tiles never straddle a tap and every byte offset fits the 31-bit buffer range
+static bool g_force_generic = false;
+static bool buf_path_ok(const ddpo_gemm_desc& d, int ldw) {
+  if (g_force_generic) return false;
+  const int64_t lim = 0x7FFFFFFF;
+  if (d.ksize > 0) {
+    if (d.Cin % BF_BK) return false;
+    if ((int64_t)d.B * d.H * d.W * d.ld_src * 4 >= lim) return false;
+    const int64_t wbytes = d.w_dgrad ? (int64_t)d.K * d.N * 2 : (int64_t)d.N * ldw * 2;
+    if (wbytes >= lim) return false;
+  } else {
+    if (d.K % BF_BK) return false;
+    if ((int64_t)d.M * d.ld_src * 4 >= lim || (int64_t)d.N * ldw * 2 >= lim) return false;
+  }
+  return true;
+}
+extern "C" void ddpo_debug_force_generic_gemm(int on) { g_force_generic = on != 0; }
 
 template <int BM, int BN, int NPASS>
 static int launch_bf16(const ddpo_gemm_desc& d, const uint16_t* w_hi, const uint16_t* w_lo, int ldw, float* ws, size_t ws_bytes,
@@ -364,9 +676,14 @@ static int launch_bf16(const ddpo_gemm_desc& d, const uint16_t* w_hi, const uint
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_bf16_kernel<BM, BN, NPASS, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_bf16_buf_kernel<BM, BN, NPASS>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  if (d.upsample == 0)
+  if (buf_path_ok(d, ldw))
+    hipLaunchKernelGGL((gemm_conv_bf16_buf_kernel<BM, BN, NPASS>), dim3(nblk, splits), dim3(BF_THREADS), lds, st, d, w_hi, w_lo, ldw,
+                       tiles_m, tiles_n, nblk, ktps, part);
+  else if (d.upsample == 0)
     hipLaunchKernelGGL((gemm_conv_bf16_kernel<BM, BN, NPASS, true>), dim3(nblk, splits), dim3(BF_THREADS), lds, st, d, w_hi, w_lo, ldw,
                        tiles_m, tiles_n, nblk, ktps, part);
   else
@@ -379,6 +696,34 @@ static int launch_bf16(const ddpo_gemm_desc& d, const uint16_t* w_hi, const uint
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)blocks), dim3(256), 0, st, d, part, splits);
     DDPO_LAUNCH_CHECK();
   }
+  return DDPO_OK;
+}
+
+
+// timing ablations of the 128x128 bf16x3 k-loop (results are WRONG for mode != 0); used by tools/ablate_gemm.py only
+template <int ABL>
+static void launch_abl(const ddpo_gemm_desc& d, const uint16_t* w_hi, const uint16_t* w_lo, int ldw, hipStream_t st) {
+  const int tiles_m = (d.M + 127) / 128, tiles_n = (d.N + 127) / 128, nblk = tiles_m * tiles_n;
+  const size_t lds = 2 * 2 * (size_t)(128 + 128) * 64;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_bf16_buf_kernel<128, 128, 3, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const int nk = d.K / BF_BK;
+  hipLaunchKernelGGL((gemm_conv_bf16_buf_kernel<128, 128, 3, ABL>), dim3(nblk, 1), dim3(BF_THREADS), lds, st, d, w_hi, w_lo, ldw, tiles_m, tiles_n,
+                     nblk, (nk + 1) & ~1, (float*)nullptr);
+}
+extern "C" int ddpo_debug_gemm_ablate(const ddpo_gemm_desc* dp, const uint16_t* w_hi, const uint16_t* w_lo, int ldw, int mode, void* stream) {
+  if (!dp || !buf_path_ok(*dp, ldw)) return DDPO_EINVAL;
+  hipStream_t st = as_stream(stream);
+  switch (mode) {
+    case 0: launch_abl<0>(*dp, w_hi, w_lo, ldw, st); break;
+    case 1: launch_abl<1>(*dp, w_hi, w_lo, ldw, st); break;
+    case 2: launch_abl<2>(*dp, w_hi, w_lo, ldw, st); break;
+    case 6: launch_abl<6>(*dp, w_hi, w_lo, ldw, st); break;
+    case 7: launch_abl<7>(*dp, w_hi, w_lo, ldw, st); break;
+    case 8: launch_abl<8>(*dp, w_hi, w_lo, ldw, st); break;
+    case 15: launch_abl<15>(*dp, w_hi, w_lo, ldw, st); break;
+    default: return DDPO_EINVAL;
+  }
+  DDPO_LAUNCH_CHECK();
   return DDPO_OK;
 }
 

@@ -62,7 +62,8 @@ _SIGS = {
     "ddpo_attention_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int,
                                    c_int, c_int, c_int, c_float, c_void_p]),
     "ddpo_attention_fwd_bf16x3": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int,
-                                          c_int, c_int, c_int, c_float, c_void_p]),
+                                          c_int, c_int, c_int, c_float, c_void_p, c_size_t, c_void_p]),
+    "ddpo_attention_fwd_bf16x3_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "ddpo_attention_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "ddpo_attention_bwd_bf16x3": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -375,11 +376,15 @@ def attention(q, k, v, B, heads, Nq, Nk, d, scale=None, out=None, ldq=None, ldk=
     if out is None:
         out = torch.empty(B * Nq, C, dtype=torch.float32, device=q.device)
     lse = torch.empty(B * heads * Nq, dtype=torch.float32, device=q.device) if return_lse else None
-    fn, name = load().ddpo_attention_fwd, "ddpo_attention_fwd"
+    sc = float(scale if scale is not None else d ** -0.5)
     if DATAPATH != "fp32" and d in (8, 16, 40, 64, 80):
-        fn, name = load().ddpo_attention_fwd_bf16x3, "ddpo_attention_fwd_bf16x3"
-    _check(fn(_p(q), int(ldq or C), _p(k), int(ldk or C), _p(v), int(ldv or C), _p(out), int(ldo or C),
-              _p(lse), B, heads, Nq, Nk, d, float(scale if scale is not None else d ** -0.5), _stream()), name)
+        nb = int(load().ddpo_attention_fwd_bf16x3_ws_bytes(B, heads, Nk, d))      # 0 for short key sequences
+        ws = _scratch(nb, q.device, "attn_kv") if nb else None
+        _check(load().ddpo_attention_fwd_bf16x3(_p(q), int(ldq or C), _p(k), int(ldk or C), _p(v), int(ldv or C), _p(out), int(ldo or C),
+                                                _p(lse), B, heads, Nq, Nk, d, sc, _p(ws), nb, _stream()), "ddpo_attention_fwd_bf16x3")
+    else:
+        _check(load().ddpo_attention_fwd(_p(q), int(ldq or C), _p(k), int(ldk or C), _p(v), int(ldv or C), _p(out), int(ldo or C),
+                                         _p(lse), B, heads, Nq, Nk, d, sc, _stream()), "ddpo_attention_fwd")
     return (out, lse) if return_lse else out
 
 

@@ -168,10 +168,14 @@ int ddpo_attention_fwd(const float* q, int ldq, const float* k, int ldk, const f
                        float* o, int ldo, float* lse, int B, int heads, int Nq, int Nk, int d, float scale,
                        void* stream);
 /* Same contract on the bf16 MFMA datapath: Q, K, V and the probabilities are split into bf16 hi + lo and every
- * product takes three passes (fp32 accumulate, ~1e-5 relative).  d in {8, 16, 40, 64, 80}. */
+ * product takes three passes (fp32 accumulate, ~1e-5 relative).  d in {8, 16, 40, 64, 80}.
+ * ws (optional, 16-byte aligned, >= ddpo_attention_fwd_bf16x3_ws_bytes): when given and Nk >= 256, K and V are split /
+ * transposed once per (batch, head) into per-tile LDS images that the attention kernel streams; without it (or for
+ * short key sequences, where the size query returns 0) every query tile stages K / V itself.  Results are identical. */
+size_t ddpo_attention_fwd_bf16x3_ws_bytes(int B, int heads, int Nk, int d);
 int ddpo_attention_fwd_bf16x3(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
                               float* o, int ldo, float* lse, int B, int heads, int Nq, int Nk, int d, float scale,
-                              void* stream);
+                              void* ws, size_t ws_bytes, void* stream);
 /* Attention backward with probability recomputation (no N x N tensor is ever materialised):
  * dvec (B,heads,Nq) scratch = rowsum(dO * O); dq/dk/dv have the layout of q/k/v with contiguous rows of heads*d. */
 int ddpo_attention_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o,
