@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Timing ablations of the 128x128 bf16x3 GEMM k-loop (debug entry ddpo_debug_gemm_ablate; results are wrong by design
-for mode != 0).  mode bits: 1 = no global loads in the loop, 2 = no split + LDS stores, 4 = no barriers, 8 = no fragment reads."""
+for mode != 0).  mode bits: 1 = no global loads in the loop, 2 = no split + LDS stores, 4 = no barriers, 8 = no fragment reads,
+16 = no epilogue stores, 32 = no prologue loads."""
 import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -10,6 +11,9 @@ dev = "cuda"
 lib = L.load()
 lib.ddpo_debug_gemm_ablate.restype = ctypes.c_int
 lib.ddpo_debug_gemm_ablate.argtypes = [ctypes.POINTER(L.GemmDesc), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+
+
+MODES = (0, 16, 15, 31, 47, 63) if len(sys.argv) > 1 and sys.argv[1] == "short" else (0, 1, 2, 6, 7, 8, 15)
 
 
 def run(M, K, N, conv=None):
@@ -28,7 +32,7 @@ def run(M, K, N, conv=None):
     if conv:
         d.ksize, d.stride, d.pad, d.upsample, d.B, d.H, d.W, d.Cin, d.OH, d.OW = 3, 1, 1, 0, B, H, H, Cin, H, H
     res = []
-    for mode in (0, 1, 2, 6, 7, 8, 15):
+    for mode in MODES:
         f = lambda: lib.ddpo_debug_gemm_ablate(ctypes.byref(d), hi.data_ptr(), lo.data_ptr(), ldw, mode, None)
         for _ in range(2): assert f() == 0
         torch.cuda.synchronize()
@@ -41,7 +45,16 @@ def run(M, K, N, conv=None):
     print(f"M={M} K={K} N={N} conv={conv}: " + " | ".join(res))
 
 
-run(4096, 1280, 10240)
-run(16384, 2560, 640)
-run(16 * 32 * 32, 9 * 640, 640, conv=(16, 32, 640))
-run(16 * 64 * 64, 9 * 640, 640, conv=(16, 64, 640))
+import sys
+MODES = (0, 16, 15, 31, 47, 63) if len(sys.argv) > 1 and sys.argv[1] == "short" else (0, 1, 2, 6, 7, 8, 15)
+if len(sys.argv) > 1 and sys.argv[1] == "short":
+    run(65536, 320, 2560)
+    run(65536, 320, 384)
+    run(16384, 640, 640)
+    run(4096, 1280, 1280)
+    run(65536, 1280, 384)
+else:
+    run(4096, 1280, 10240)
+    run(16384, 2560, 640)
+    run(16 * 32 * 32, 9 * 640, 640, conv=(16, 32, 640))
+    run(16 * 64 * 64, 9 * 640, 640, conv=(16, 64, 640))
