@@ -603,6 +603,25 @@ __global__ void __launch_bounds__(BF_THREADS) gemm_conv_bf16_buf_kernel(const dd
         for (int r = 0; r < 16; ++r)
           cw[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf) * WTN + j * 32 + (lane & 31)] = acc[i][j][r];
     // (wave-private slice: program order + lgkmcnt is all the synchronisation needed)
+    if (BN == 128 && d.epilogue == 1) {          // GEGLU: this wave's 64 columns are [a (32) | gate (32)] of output chunk q
+      const int q = (n0 + wn * 64) >> 6;
+      const int gc = (lane & 7) * 4, grow = lane >> 3;          // 8 lanes x float4 = 32 output columns; 8 rows per instruction
+      const float4 ba = d.bias ? *reinterpret_cast<const float4*>(d.bias + q * 64 + gc) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 bg = d.bias ? *reinterpret_cast<const float4*>(d.bias + q * 64 + 32 + gc) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int rr = it * 8 + grow;
+        const int row = m0 + wm * 64 + rr;
+        if (row >= d.M) continue;
+        const float4 a = *reinterpret_cast<const float4*>(cw + rr * 64 + gc);
+        const float4 g = *reinterpret_cast<const float4*>(cw + rr * 64 + 32 + gc);
+        float4 o;
+        o.x = (a.x + ba.x) * gelu_tanh_f(g.x + bg.x); o.y = (a.y + ba.y) * gelu_tanh_f(g.y + bg.y);
+        o.z = (a.z + ba.z) * gelu_tanh_f(g.z + bg.z); o.w = (a.w + ba.w) * gelu_tanh_f(g.w + bg.w);
+        *reinterpret_cast<float4*>(d.out + (int64_t)row * d.ld_out + q * 32 + gc) = o;
+      }
+      return;
+    }
     const int lcol = (lane % LPR) * 4, lrow = lane / LPR;
     const int col = n0 + wn * WTN + lcol;
     if (col < d.N) {
@@ -718,7 +737,7 @@ static int launch_bf16(const ddpo_gemm_desc& d, const uint16_t* w_hi, const uint
   // split-K when the tile grid under-fills the 256 CUs and the reduction is long (8x8 / 16x16 latent levels)
   const int nk_total = (d.K + BF_BK - 1) / BF_BK;
   int splits = 1;
-  if (ws && nblk < 192 && nk_total >= 32 && (d.N & 3) == 0) {
+  if (ws && nblk < 192 && nk_total >= 32 && (d.N & 3) == 0 && d.epilogue == 0) {
     splits = (384 + nblk - 1) / nblk;
     if (splits > 8) splits = 8;
     if (splits > nk_total / 8) splits = nk_total / 8;
@@ -813,6 +832,11 @@ extern "C" int ddpo_gemm_conv_fwd_bf16(const ddpo_gemm_desc* dp, const uint16_t*
     return DDPO_EINVAL;
   }
   hipStream_t st = as_stream(stream);
+  if (d.epilogue != 0) {       // GEGLU output stage: 128-wide tiles of the buffer-addressed kernel, vector epilogue only
+    if (d.epilogue != 1 || (d.N & 127) || !buf_path_ok(d, ldw) || d.rowbias || d.residual || d.alpha != 1.0f || d.w_dgrad) return DDPO_EINVAL;
+    if ((d.ld_out & 3) || (reinterpret_cast<uintptr_t>(d.out) & 15) || (d.bias && (reinterpret_cast<uintptr_t>(d.bias) & 15))) return DDPO_EINVAL;
+    return npass == 3 ? launch_bf16<128, 128, 3>(d, w_hi, w_lo, ldw, nullptr, 0, st) : launch_bf16<128, 128, 1>(d, w_hi, w_lo, ldw, nullptr, 0, st);
+  }
   const long t128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128);
   const bool big = (d.N % 128 == 0) && t128 >= 256;
   float* wsf = (ws && !(reinterpret_cast<uintptr_t>(ws) & 15)) ? reinterpret_cast<float*>(ws) : nullptr;

@@ -33,7 +33,7 @@ class GemmDesc(ctypes.Structure):
                 ("ksize", c_int), ("stride", c_int), ("pad", c_int), ("upsample", c_int),
                 ("B", c_int), ("H", c_int), ("W", c_int), ("Cin", c_int),
                 ("OH", c_int), ("OW", c_int),
-                ("w_dgrad", c_int), ("ld_w", c_int), ("splits", c_int), ("accumulate", c_int)]
+                ("w_dgrad", c_int), ("ld_w", c_int), ("splits", c_int), ("accumulate", c_int), ("epilogue", c_int)]
 
 
 _SIGS = {
@@ -288,10 +288,67 @@ def pack_weights(w, bwd=True):
         PACKED[w.data_ptr()] = ent
     if bwd and ent["bwd"] is None:
         ent["bwd"] = (mk(K, N), mk(K, N))
+    if "geglu" in ent:
+        ent["geglu"]["stale"] = True          # re-ordered GEGLU planes (pack_weights_geglu) no longer match w
     fh, fl, _ = ent["fwd"]
     bh, bl = ent["bwd"] if ent["bwd"] is not None else (None, None)
     _check(load().ddpo_pack_weights_bf16(_p(w), K, N, Kp, _p(fh), _p(fl), _p(bh), _p(bl), _stream()), "ddpo_pack_weights_bf16")
     return ent
+
+
+def pack_weights_geglu(w, bias):
+    """Second set of forward planes for a GEGLU feed-forward weight w (K, 2F) with its columns (and bias) re-ordered into
+    interleaved 32-column blocks [a_q | gate_q], the layout ddpo_gemm_desc.epilogue = 1 expects.  Returns False when
+    the shape does not qualify (the caller then keeps the unfused linear + geglu pair)."""
+    K, N = w.shape
+    F = N // 2
+    if DATAPATH == "fp32" or (N % 128) or (K % 32):
+        return False
+    ent = PACKED.get(w.data_ptr())
+    if ent is None:
+        return False
+    if "geglu" not in ent:
+        idx = torch.arange(F, device=w.device).view(F // 32, 1, 32)
+        perm = torch.cat([idx, idx + F], dim=1).reshape(-1)               # [a_0 | gate_0 | a_1 | gate_1 | ...]
+        mk = lambda: torch.zeros(N, K, dtype=torch.int16, device=w.device)
+        ent["geglu"] = dict(perm=perm, hi=mk(), lo=mk(), bias=torch.empty(N, dtype=torch.float32, device=w.device))
+    g = ent["geglu"]
+    wp = w.index_select(1, g["perm"]).contiguous()
+    torch.index_select(bias, 0, g["perm"], out=g["bias"])
+    _check(load().ddpo_pack_weights_bf16(_p(wp), K, N, K, _p(g["hi"]), _p(g["lo"]), None, None, _stream()), "ddpo_pack_weights_bf16")
+    g["stale"] = False
+    return True
+
+
+def linear_geglu(x, w, out=None):
+    """(x @ w + b)[:, :F] * gelu_tanh((x @ w + b)[:, F:]) in one launch; w must have been registered by pack_weights_geglu.
+    Returns None when it was not (caller falls back to linear + geglu)."""
+    ent = PACKED.get(w.data_ptr())
+    if DATAPATH == "fp32" or ent is None or "geglu" not in ent or ent["geglu"]["stale"]:
+        return None
+    g = ent["geglu"]
+    M, K = x.shape
+    N = w.shape[1]
+    if (M * K * 4) >= (1 << 31):
+        return None
+    if out is None:
+        out = torch.empty(M, N // 2, dtype=torch.float32, device=x.device)
+    d = GemmDesc()
+    d.src = x.data_ptr(); d.ld_src = K
+    d.bias = g["bias"].data_ptr()
+    d.out = out.data_ptr(); d.ld_out = N // 2
+    d.alpha = 1.0
+    d.M, d.N, d.K = int(M), int(N), int(K)
+    d.epilogue = 1
+    npass = 3 if DATAPATH == "bf16x3" else 1
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _check(load().ddpo_gemm_conv_fwd_bf16(byref(d), _p(g["hi"]), _p(g["lo"]), K, npass, None, 0, _stream()), "ddpo_gemm_conv_fwd_bf16")
+    if PROFILE is not None:
+        e1.record()
+        PROFILE.append((e0, e1, 2.0 * M * N * K, DATAPATH, 4.0 * (M * K + K * N + M * N // 2)))
+    return out
 
 
 def _bf16_route(w, K, N, conv, dgrad):

@@ -83,6 +83,8 @@ class ParamStore:
         for n, v in self.views.items():
             if n.endswith(".kernel"):
                 L.pack_weights(v, bwd=bwd)
+                if n.endswith(".ff.net_0.proj.kernel"):          # GEGLU feed-forward: extra planes for the fused forward
+                    L.pack_weights_geglu(v, self.views[n[:-len("kernel")] + "bias"])
 
     def init_synthetic(self, seed=0):
         """Random-init weights of the right architecture (no checkpoints are reachable offline)."""
@@ -304,8 +306,11 @@ class UNet2DCondition:
         a2 = self._attention(tb + ".attn2", l2, B, N, C, heads, ctx, ctx_len, a2r)
         h2 = L.linear(a2, P[tb + ".attn2.to_out_0.kernel"], P[tb + ".attn2.to_out_0.bias"], residual=h1)
         l3 = ln("norm3", h2)
-        f = L.linear(l3, P[tb + ".ff.net_0.proj.kernel"], P[tb + ".ff.net_0.proj.bias"])
-        gg = L.geglu(f)
+        f = None
+        gg = L.linear_geglu(l3, P[tb + ".ff.net_0.proj.kernel"]) if tape is None else None     # sampling: GEGLU fused into the GEMM epilogue
+        if gg is None:
+            f = L.linear(l3, P[tb + ".ff.net_0.proj.kernel"], P[tb + ".ff.net_0.proj.bias"])
+            gg = L.geglu(f)
         h3 = L.linear(gg, P[tb + ".ff.net_2.kernel"], P[tb + ".ff.net_2.bias"], residual=h2)
         if cfg.use_linear_projection:
             out = L.linear(h3, P[name + ".proj_out.kernel"], P[name + ".proj_out.bias"], residual=x.t)

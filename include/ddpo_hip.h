@@ -132,6 +132,12 @@ typedef struct {
   int ld_w;                       /* wgrad: row stride of dY (the `w` operand) */
   int splits;                     /* wgrad: split of the reduction over M (0 = auto) */
   int accumulate;                 /* wgrad: atomically add into out instead of storing */
+  /* fused output stage (ddpo_gemm_conv_fwd_bf16 only; 0 everywhere else) */
+  int epilogue;                   /* 0: out = alpha*acc + bias + rowbias + residual (N columns)
+                                     1: GEGLU.  The N columns of W / bias come as interleaved 32-column blocks
+                                        [a_0 | gate_0 | a_1 | gate_1 ...]; out has N/2 columns,
+                                        out[:, 32q + c] = (acc_a + bias_a) * gelu_tanh(acc_gate + bias_gate);
+                                        needs N % 128 == 0, K % 32 == 0, no rowbias / residual, alpha == 1 */
 } ddpo_gemm_desc;
 int ddpo_gemm_conv_fwd(const ddpo_gemm_desc* d, void* stream);
 /* Data gradients reuse ddpo_gemm_conv_fwd: src = dY, w = forward kernel with w_trans=1, w_dgrad=1, and for the

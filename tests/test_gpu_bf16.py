@@ -74,6 +74,33 @@ def test_conv_bf16(datapath, mode, B, H, W, Cin, Cout, ks, stride, ups):
         assert _rel(dx, xd.grad.permute(0, 2, 3, 1).reshape(B * H * W, Cin)) < TOL[mode]
 
 
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("M,K,F", [(300, 64, 128), (4096, 320, 1280), (1000, 640, 2560), (64, 1280, 5120)])
+def test_linear_geglu_fused_epilogue(datapath, mode, M, K, F):
+    """FF1 + GEGLU in one launch (ddpo_gemm_desc.epilogue = 1): same k-order and the same output arithmetic as
+    linear() followed by geglu(), so the results are bit-identical; and both match float64 within the datapath tolerance."""
+    L.DATAPATH = mode
+    g = torch.Generator().manual_seed(M + K + F)
+    x = torch.randn(M, K, generator=g).to(DEV)
+    w = (torch.randn(K, 2 * F, generator=g) / math.sqrt(K)).to(DEV)
+    b = torch.randn(2 * F, generator=g).to(DEV)
+    L.pack_weights(w)
+    assert L.linear_geglu(x, w) is None                      # not registered yet -> caller falls back
+    assert L.pack_weights_geglu(w, b)
+    fused = L.linear_geglu(x, w)
+    unfused = L.geglu(L.linear(x, w, b))
+    assert fused.shape == (M, F)
+    if M >= 256:
+        assert torch.equal(fused, unfused)
+    else:                                                    # few tiles: the unfused GEMM takes the split-K route (other summation order)
+        assert _rel(fused, unfused) < 1e-5
+    f64 = x.cpu().double() @ w.cpu().double() + b.cpu().double()
+    ref = f64[:, :F] * TF.gelu(f64[:, F:], approximate="tanh")
+    assert _rel(fused, ref) < TOL[mode]
+    L.pack_weights(w)                                        # weights "changed": fused planes are stale until re-packed
+    assert L.linear_geglu(x, w) is None
+
+
 def test_unregistered_weights_stay_on_fp32(datapath):
     L.DATAPATH = "bf16"
     g = torch.Generator().manual_seed(0)
