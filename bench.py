@@ -236,7 +236,7 @@ def main():
         passes = {"fp32": 1, "bf16": 1, "bf16x3": 3}[dom]
         peak = FP32_MFMA_PEAK_TFLOPS if dom == "fp32" else BF16_MFMA_PEAK_TFLOPS
         kname = "gemm_conv_kernel (v_mfma_f32_32x32x2_f32)" if dom == "fp32" else \
-            f"gemm_conv_bf16_kernel<NPASS={passes}> (v_mfma_f32_32x32x16_bf16)"
+            f"gemm_conv_bf16_buf_kernel<128,128|64,NPASS={passes}> (v_mfma_f32_32x32x16_bf16)"
         traffic, traffic_note = None, None
         tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
         if os.path.exists(tpath):
@@ -271,7 +271,7 @@ def main():
                                f"sample_batch_size {B}/GPU, VAE decode included",
                    "datapath": {"fp32": "exact-fp32 MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4_f32)",
                                 "bf16x3": "conv/GEMM: bf16x3-split MFMA (a_lo*b_hi + a_hi*b_lo + a_hi*b_hi, fp32 accumulate, ~1e-5 rel; "
-                                          "= XLA HIGH, the reference ran TPU DEFAULT = 1 pass); attention/norms: exact fp32",
+                                          "= XLA HIGH, the reference ran TPU DEFAULT = 1 pass); attention (d in 40/64/80): same split; d=160 attention and norms: exact fp32",
                                 "bf16": "conv/GEMM: single-pass bf16 MFMA, fp32 accumulate (= XLA TPU DEFAULT precision)"}[args.datapath],
                    "parallelism": f"dp{world}",
                    "global_batch": world * B},
