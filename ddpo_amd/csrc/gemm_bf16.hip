@@ -10,6 +10,7 @@
 // LDS tiles are [row][32 k] bf16 (64 B per row) with the 16-byte chunk index XOR-swizzled by (row>>2)&3: every
 // ds_read_b128 / ds_write of a 16-lane group touches 16 distinct 16-byte slots (conflict-free).
 #include "common.h"
+#include <cstdlib>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -838,7 +839,8 @@ extern "C" int ddpo_gemm_conv_fwd_bf16(const ddpo_gemm_desc* dp, const uint16_t*
     return npass == 3 ? launch_bf16<128, 128, 3>(d, w_hi, w_lo, ldw, nullptr, 0, st) : launch_bf16<128, 128, 1>(d, w_hi, w_lo, ldw, nullptr, 0, st);
   }
   const long t128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128);
-  const bool big = (d.N % 128 == 0) && t128 >= 256;
+  static const long big_min = [] { const char* e = getenv("DDPO_GEMM_BIG_MIN"); return e ? atol(e) : 256L; }();   // tuning knob (tools/)
+  const bool big = (d.N % 128 == 0) && t128 >= big_min;
   float* wsf = (ws && !(reinterpret_cast<uintptr_t>(ws) & 15)) ? reinterpret_cast<float*>(ws) : nullptr;
   if (npass == 3)
     return big ? launch_bf16<128, 128, 3>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st) : launch_bf16<128, 64, 3>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st);

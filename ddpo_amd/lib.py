@@ -36,6 +36,8 @@ class GemmDesc(ctypes.Structure):
                 ("w_dgrad", c_int), ("ld_w", c_int), ("splits", c_int), ("accumulate", c_int), ("epilogue", c_int)]
 
 
+ABI_VERSION = 2          # must equal ddpo_abi_version() of the loaded library (include/ddpo_hip.h)
+
 _SIGS = {
     "ddpo_abi_version": (c_int, []),
     "ddpo_sizeof_gemm_desc": (c_size_t, []),
@@ -122,6 +124,8 @@ def load():
         fn.argtypes = args
     if lib.ddpo_sizeof_gemm_desc() != ctypes.sizeof(GemmDesc) or lib.ddpo_sizeof_ddim_consts() != ctypes.sizeof(DdimConsts):
         raise DdpoHipError("struct layout mismatch between include/ddpo_hip.h and ddpo_amd/lib.py")
+    if lib.ddpo_abi_version() != ABI_VERSION:
+        raise DdpoHipError(f"libddpo_hip.so has ABI version {lib.ddpo_abi_version()}, lib.py expects {ABI_VERSION}: rebuild with `python __graft_entry__.py`")
     _lib = lib
     return lib
 

@@ -109,6 +109,34 @@ def test_unet_sd15_single_sample_64x64():
     assert _rel(out.numpy(), ref.numpy()) < 1e-3
 
 
+def test_unet_sd21_single_sample_96x96_bf16x3():
+    """BASELINE configs[4] architecture at full size: SD-2.1 U-Net (865.9 M params; linear proj_in/out, d_head 64 with
+    5/10/20/20 heads, 1024-wide context) on a 768^2 latent (96x96 -> self-attention over 9216 keys), one sample, on the
+    bf16x3 datapath (buffer-addressed GEMMs, pre-packed K/V attention) against the torch-CPU fp32 oracle."""
+    from ddpo_amd import lib as L
+    shapes = OU.unet_param_shapes(OU.SD21)
+    op = OU.init_params(shapes, seed=0)
+    old = L.DATAPATH
+    L.DATAPATH = "bf16x3"
+    try:
+        unet = UNet2DCondition(UNetConfig.named("sd21"), DEV)
+        assert unet.params.n_params == 865910724
+        unet.params.load_dict(op)
+        unet.params.pack_bf16(bwd=False)
+        g = torch.Generator().manual_seed(21)
+        x = torch.randn(1, 4, 96, 96, generator=g)
+        t = torch.tensor([261], dtype=torch.int32)
+        ctx = torch.randn(1, 77, 1024, generator=g)
+        with torch.no_grad():
+            ref = OU.unet_forward(op, OU.SD21, x, t, ctx)
+        out = unet(x.to(DEV), t.to(DEV), ctx.to(DEV)).cpu()
+        assert out.shape == ref.shape == (1, 4, 96, 96)
+        assert _rel(out.numpy(), ref.numpy()) < 1e-3
+    finally:
+        L.DATAPATH = old
+        L.PACKED.clear()
+
+
 @pytest.mark.parametrize("datapath", ["fp32", "bf16x3"])
 def test_sd21_shaped_config_sampler_and_train_step(datapath):
     """BASELINE configs[4] shape class on the toy scale: SD-2.1 architecture switches (linear proj_in/out, per-level head
