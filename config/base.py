@@ -48,3 +48,8 @@ a_dog_2 = _dataset("aesthetic_dogs_sweep/imagenet", "imagenet_dogs", "aesthetic"
                    train_accumulation_steps=2)
 a_animals = _dataset("aesthetic_simple_animals", "from_file", "aesthetic", _ANIMALS, train_batch_size=1,
                      train_accumulation_steps=2)
+
+# CFG-free ablations and the VQA-v0 prompt set of the reference (config/base.py of the reference, same names / overrides)
+compressed_animals_nocfg = _dataset("nocfg-compressed-animals-s1024-p90", "imagenet_animals", "jpeg")
+neg_compressed_animals_nocfg = _dataset("nocfg-neg-compressed-animals-s1024-p90", "imagenet_animals", "neg_jpeg")
+vqa_v0 = _dataset("vqa-v0-n2k-s5.0-e50", "vqa_dataset", "vqa", {"loadpath": "assets/vqa_v0.txt"})
