@@ -10,6 +10,9 @@ What runs from the reference, unmodified, loaded by file path:
   * ddpo/utils/imagenet.py                 (literals only)                   -> class / colour lists
   * ddpo/training/prompts.py               (needs `ddpo.utils`, `inflect`)   -> prompt streams under random.seed(s)
   * config/base.py + config/user.py        (literals only)                   -> the `pg` flag surface per dataset
+  * encode_jpeg (ddpo/utils/hdf5.py) and jpeg_fn / neg_jpeg_fn (ddpo/training/callbacks.py), lifted with `ast` like the
+    loaders below                                                              -> JPEG-size rewards of seeded images
+    (byte counts depend on the PIL / libjpeg build: the fixture records PIL's version and the test skips on another)
 The reference's `ddpo.utils` package cannot be imported here (jax / flax / gcsfs / h5py missing), so prompts.py gets a
 stand-in `ddpo.utils` whose `load_lines` / `load_general_prompts` are the reference's OWN function bodies, lifted out of
 ddpo/utils/serialization.py with `ast` and exec'd unchanged.  `inflect` is not installable offline: a three-call
@@ -38,10 +41,11 @@ def load_by_path(name, path):
     return mod
 
 
-def lift_functions(path, names):
+def lift_functions(path, names, extra=None):
     """exec only the named top-level functions of a reference file (its module-level imports are not executed)."""
     tree = ast.parse(open(path).read())
     ns = {"__builtins__": __builtins__}
+    ns.update(extra or {})
     import functools as _functools
     import re as _re
     ns.update(re=_re, functools=_functools)
@@ -71,6 +75,18 @@ class _Inflect:                       # stand-in, see module docstring
         if noun.endswith("y") and noun[-2:-1] not in "aeiou":
             return noun[:-1] + "ies"
         return noun + "s"
+
+
+def jpeg_test_images(seed, n, hw):
+    """float32 (n, hw, hw, 3) in [0,1]: smooth gradients + seeded noise (shared recipe with tests/test_reference_goldens.py)."""
+    rng = np.random.RandomState(seed)
+    yy, xx = np.meshgrid(np.linspace(0, 1, hw), np.linspace(0, 1, hw), indexing="ij")
+    imgs = []
+    for i in range(n):
+        base = np.stack([yy, xx, 0.5 + 0.5 * np.sin(6.0 * (xx + yy) + i)], axis=-1)
+        img = np.clip(base + rng.randn(hw, hw, 3) * 0.05 * (i + 1), 0.0, 1.0)
+        imgs.append(img.astype(np.float32))
+    return np.stack(imgs)
 
 
 def jsonable(x):
@@ -162,6 +178,23 @@ def main():
         if "pg" in val or "common" in val:
             cfg["datasets"][name] = {"common": jsonable(val.get("common", {})), "pg": jsonable(val.get("pg", {}))}
     out["config"] = cfg
+
+    # ---------------------------------------------------------------- jpeg rewards
+    import io
+    import PIL
+    from PIL import Image
+    enc = lift_functions(os.path.join(REF, "ddpo/utils/hdf5.py"), ["encode_jpeg"], {"np": np, "io": io, "Image": Image})
+    ref_utils = types.SimpleNamespace(encode_jpeg=enc["encode_jpeg"])
+    cb = lift_functions(os.path.join(REF, "ddpo/training/callbacks.py"), ["jpeg_fn", "neg_jpeg_fn"],
+                        {"np": np, "utils": ref_utils, "DEVICES": None})
+    jcases = []
+    for seed, n, hw in [(0, 3, 64), (1, 2, 96), (2, 1, 512)]:
+        images = jpeg_test_images(seed, n, hw)
+        s_jpeg, _ = cb["jpeg_fn"]()(images, None, None)
+        s_neg, _ = cb["neg_jpeg_fn"]()(images, None, None)
+        jcases.append({"seed": seed, "n": n, "hw": hw, "jpeg": np.asarray(s_jpeg).tolist(), "neg_jpeg": np.asarray(s_neg).tolist(),
+                       "dtype": str(np.asarray(s_jpeg).dtype), "shape": list(np.asarray(s_jpeg).shape)})
+    out["jpeg_rewards"] = {"pil_version": PIL.__version__, "cases": jcases}
 
     with open(OUT, "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)

@@ -83,3 +83,32 @@ def test_config_flag_surface_matches_reference():
                     assert mine_v.split("logs/", 1)[1] == v.split("logs/", 1)[1]
                     continue
                 assert mine_v == v, f"{name}.{sect}.{k}: {mine_v!r} != {v!r}"
+
+
+def _jpeg_test_images(seed, n, hw):
+    """Same recipe as tests/golden/make_reference_goldens.py:jpeg_test_images."""
+    rng = np.random.RandomState(seed)
+    yy, xx = np.meshgrid(np.linspace(0, 1, hw), np.linspace(0, 1, hw), indexing="ij")
+    imgs = []
+    for i in range(n):
+        base = np.stack([yy, xx, 0.5 + 0.5 * np.sin(6.0 * (xx + yy) + i)], axis=-1)
+        img = np.clip(base + rng.randn(hw, hw, 3) * 0.05 * (i + 1), 0.0, 1.0)
+        imgs.append(img.astype(np.float32))
+    return np.stack(imgs)
+
+
+def test_jpeg_rewards_match_reference_functions():
+    """jpeg / neg_jpeg rewards: integer byte counts / 1000 — bit-exact against the reference's own encode_jpeg + jpeg_fn
+    (executed by the fixture generator) for identical pixels and the same PIL / libjpeg build."""
+    import PIL
+    from ddpo_amd.training import callbacks as CB
+    ref = GOLD["jpeg_rewards"]
+    if PIL.__version__ != ref["pil_version"]:
+        pytest.skip(f"fixture was produced with PIL {ref['pil_version']}, this is {PIL.__version__}")
+    for case in ref["cases"]:
+        images = _jpeg_test_images(case["seed"], case["n"], case["hw"])
+        for name in ("jpeg", "neg_jpeg"):
+            scores, info = CB.callback_fns[name]()(images, ["p"] * case["n"], ({},) * case["n"])
+            scores = np.asarray(scores)
+            assert list(scores.shape) == case["shape"] and str(scores.dtype) == case["dtype"] and info == {}
+            assert scores.tolist() == case[name]
