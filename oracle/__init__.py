@@ -8,9 +8,14 @@ the product package ``ddpo_amd`` never does (and fails loudly without its HIP li
 Parity status:
   * PRNG (Threefry-2x32, split, uniform, normal): PINNED — Random123 known-answer
     vectors and the values printed in the JAX documentation (tests/golden/prng_kat.json).
-  * DDIM schedule / step / log-prob: restated line by line from
-    /root/reference/ddpo/diffusers_patch/scheduling_ddim_flax.py; schedule constants
-    pinned to tests/golden/ddim_schedule.json (published SD scaled-linear values).
+  * DDIM schedule / step / log-prob and the sampler loop (CFG ordering, key tree, scan carry, output layouts):
+    PINNED against the reference's own code executed in place — tests/golden/make_reference_ddim_goldens.py exec's
+    /root/reference/ddpo/diffusers_patch/scheduling_ddim_flax.py unmodified and runs the lifted body of
+    FlaxStableDiffusionPipeline._generate under numpy stand-ins for jax.numpy / flax / the diffusers base classes
+    (tests/golden/_jax_shim.py); tests/test_reference_ddim_goldens.py holds this oracle (CPU) and the HIP product (GPU)
+    to the recorded outputs.  Schedule constants additionally pinned to tests/golden/ddim_schedule.json.
+  * Stat tracker, prompt functions, config flag surface, jpeg rewards: PINNED the same way
+    (tests/golden/make_reference_goldens.py -> reference_host_logic.json).
   * PPO-clip loss, accumulation: restated from /root/reference/ddpo/training/policy_gradient.py;
     closed-form gradient cross-checked against torch float64 autograd.
   * U-Net / VAE / optax AdamW: the reference delegates these to un-vendored third-party

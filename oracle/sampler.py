@@ -13,8 +13,10 @@ from .unet import unet_forward
 
 
 def sample(unet_params, cfg, ddim: DDIMOracle, sched_state, prompt_embeds, neg_embeds, key, num_inference_steps,
-           height, width, guidance_scale, eta, dtype=torch.float32):
-    """Returns numpy (final_latents, latents (B,T,..), next_latents (B,T,..), log_probs (B,T), ts (B,T))."""
+           height, width, guidance_scale, eta, dtype=torch.float32, unet_fn=None):
+    """Returns numpy (final_latents, latents (B,T,..), next_latents (B,T,..), log_probs (B,T), ts (B,T)).
+    `unet_fn(latents (2B,C,h,w) f32 numpy, t (2B,) int32 numpy, context (2B,77,D) f32 numpy) -> numpy` replaces the U-Net
+    (tests/test_reference_ddim_goldens.py drives the loop with the closed-form model of the reference-run fixture)."""
     B = prompt_embeds.shape[0]
     context = torch.cat([neg_embeds, prompt_embeds]).to(dtype)
     shape = (B, cfg.in_channels, height // 8, width // 8)
@@ -27,10 +29,14 @@ def sample(unet_params, cfg, ddim: DDIMOracle, sched_state, prompt_embeds, neg_e
     lat_t, next_t, lp_t, ts_t = [], [], [], []
     for step in range(num_inference_steps):
         t = int(state.timesteps[step])
-        inp = torch.from_numpy(np.concatenate([latents] * 2)).to(dtype)
-        with torch.no_grad():
-            noise_pred = unet_forward(unet_params, cfg, inp, torch.full((2 * B,), t, dtype=torch.int32), context)
-        noise_pred = noise_pred.to(torch.float32).numpy()
+        if unet_fn is not None:
+            noise_pred = np.asarray(unet_fn(np.concatenate([latents] * 2), np.full((2 * B,), t, dtype=np.int32),
+                                            context.to(torch.float32).numpy()), dtype=np.float32)
+        else:
+            inp = torch.from_numpy(np.concatenate([latents] * 2)).to(dtype)
+            with torch.no_grad():
+                noise_pred = unet_forward(unet_params, cfg, inp, torch.full((2 * B,), t, dtype=torch.int32), context)
+            noise_pred = noise_pred.to(torch.float32).numpy()
         nu, nt = noise_pred[:B], noise_pred[B:]
         guided = (nu + np.float32(guidance_scale) * (nt - nu)).astype(np.float32)
         rng, k = prng.split(rng)
