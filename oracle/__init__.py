@@ -16,8 +16,10 @@ Parity status:
     to the recorded outputs.  Schedule constants additionally pinned to tests/golden/ddim_schedule.json.
   * Stat tracker, prompt functions, config flag surface, jpeg rewards: PINNED the same way
     (tests/golden/make_reference_goldens.py -> reference_host_logic.json).
-  * PPO-clip loss, accumulation: restated from /root/reference/ddpo/training/policy_gradient.py;
-    closed-form gradient cross-checked against torch float64 autograd.
+  * PPO-clip loss / info and gradient accumulation: PINNED — the reference's ddpo/training/policy_gradient.py is exec'd
+    unmodified by the same generator (train_step's loss closure with a value-only jax.grad stand-in; the real
+    AccumulatingTrainState over a minimal TrainState).  The closed-form gradient is cross-checked against torch float64
+    autograd of that loss.
   * U-Net / VAE / optax AdamW: the reference delegates these to un-vendored third-party
     packages (diffusers[flax]==0.12.1, optax==0.1.5, flax==0.6.9, jax==0.4.8 — none
     installable here, no weights on disk).  They are restated from the published

@@ -49,7 +49,7 @@ def make_jnp():
     jnp.where = lambda c, a, b: _f32(np.where(c, _f32(a), _f32(b)))
     jnp.clip = lambda x, a_min=None, a_max=None: _f32(np.clip(_f32(x), None if a_min is None else F32(a_min), None if a_max is None else F32(a_max)))
     for name in ("sqrt", "log", "exp", "mean", "sum", "concatenate", "broadcast_to", "stack", "transpose", "cumprod", "linspace",
-                 "abs", "maximum", "minimum", "zeros", "ones"):
+                 "abs", "maximum", "minimum", "zeros", "ones", "zeros_like", "add"):
         setattr(jnp, name, _wrap(getattr(np, name)))
     jnp.split = lambda x, n, axis=0: np.split(x, n, axis=axis)
     return jnp
@@ -76,7 +76,28 @@ def make_jax(jnp):
         stacked = tuple(np.stack([np.asarray(y[i]) for y in ys]) for i in range(len(ys[0])))
         return carry, stacked
     lax.scan = scan
+    lax.pmean = lambda x, axis_name=None: x                     # one device
     jax.lax = lax
+
+    def tree_map(f, *trees):
+        t0 = trees[0]
+        if isinstance(t0, dict):
+            return {k: tree_map(f, *[t[k] for t in trees]) for k in t0}
+        if isinstance(t0, (list, tuple)):
+            return type(t0)(tree_map(f, *[t[i] for t in trees]) for i in range(len(t0)))
+        return f(*trees)
+    jax.tree_map = tree_map
+
+    def grad(fn, has_aux=False):
+        """VALUE-ONLY stand-in: runs the reference's loss closure and hands back the marker gradients the caller
+        planted in GRAD_MARKER (there is no autodiff here; the fixtures pin loss / info and the accumulation rule)."""
+        def g(params):
+            out = fn(params)
+            marker = tree_map(lambda p: jax.GRAD_MARKER(p), params)
+            return (marker, out[1]) if has_aux else marker
+        return g
+    jax.grad = grad
+    jax.GRAD_MARKER = lambda p: np.zeros_like(p)
     return jax
 
 
@@ -90,6 +111,40 @@ def make_flax():
         return cls
     struct.dataclass = dataclass
     flax.struct = struct
+    training = types.ModuleType("flax.training")
+    ts_mod = types.ModuleType("flax.training.train_state")
+
+    class TrainState:
+        """Minimal flax.training.train_state.TrainState: apply_gradients hands the gradients to `tx(params, grads)`."""
+        _fields = ("step", "apply_fn", "params", "tx", "opt_state")
+
+        def __init__(self, **kw):
+            for k, v in kw.items():
+                setattr(self, k, v)
+
+        def replace(self, **kw):
+            new = object.__new__(type(self))
+            new.__dict__.update(self.__dict__)
+            new.__dict__.update(kw)
+            return new
+
+        def apply_gradients(self, *, grads, **kwargs):
+            new_params = self.tx(self.params, grads)
+            return self.replace(step=self.step + 1, params=new_params, **kwargs)
+
+        @classmethod
+        def create(cls, *, apply_fn, params, tx, **kwargs):
+            return cls(step=0, apply_fn=apply_fn, params=params, tx=tx, opt_state=None, **kwargs)
+    ts_mod.TrainState = TrainState
+    core = types.ModuleType("flax.core")
+    fd = types.ModuleType("flax.core.frozen_dict")
+
+    class FrozenDict(dict):
+        def __class_getitem__(cls, item):
+            return cls
+    fd.FrozenDict = FrozenDict
+    flax.training, training.train_state, flax.core, core.frozen_dict = training, ts_mod, core, fd
+    flax._extra = {"flax.training": training, "flax.training.train_state": ts_mod, "flax.core": core, "flax.core.frozen_dict": fd}
     return flax
 
 
@@ -168,6 +223,10 @@ def install():
     jax = make_jax(jnp)
     flax = make_flax()
     mods = {"jax": jax, "jax.numpy": jnp, "jax.random": jax.random, "jax.lax": jax.lax, "flax": flax, "flax.struct": flax.struct}
+    mods.update(flax._extra)
     mods.update(make_diffusers(jnp))
+    dm = types.ModuleType("diffusers.models")
+    dm.vae_flax = types.ModuleType("diffusers.models.vae_flax")            # imported by the reference, never used on this path
+    mods.update({"diffusers.models": dm, "diffusers.models.vae_flax": dm.vae_flax, "optax": types.ModuleType("optax")})
     sys.modules.update(mods)
     return list(mods)

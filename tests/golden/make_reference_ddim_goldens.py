@@ -119,6 +119,74 @@ def main():
         out[tag + "/emb"], out[tag + "/neg"] = emb, neg
         out[tag + "/final"], out[tag + "/latents"], out[tag + "/next_latents"] = (np.asarray(a, dtype=F) for a in (final, lat, nxt))
         out[tag + "/log_probs"], out[tag + "/ts"] = np.asarray(lps, dtype=F), np.asarray(ts, dtype=np.int32)
+    # ------------------------------------------------------------------ train_step + AccumulatingTrainState
+    # The reference module ddpo/training/policy_gradient.py is exec'd UNMODIFIED; `jax.grad` is a value-only stand-in
+    # (no autodiff here), so the fixture pins what the loss closure computes — CFG combine, scoring-mode log-prob,
+    # advantage clip, ratio, PPO-clip loss, approx_kl, clipfrac — and the gradient-accumulation rule.
+    sys.modules["ddpo"] = types.ModuleType("ddpo")
+    sys.modules["ddpo.diffusers_patch"] = types.ModuleType("ddpo.diffusers_patch")
+    sys.modules["ddpo.diffusers_patch.scheduling_ddim_flax"] = S
+    spec = importlib.util.spec_from_file_location("ref_pg", os.path.join(REF, "ddpo/training/policy_gradient.py"))
+    PG = importlib.util.module_from_spec(spec)
+    sys.modules["ref_pg"] = PG
+    spec.loader.exec_module(PG)
+
+    def apply_fn(variables, lat, ts, embeds, train=True):
+        p = variables["params"]
+        return types.SimpleNamespace(sample=(toy_unet_numpy(np.asarray(lat), np.asarray(ts), np.asarray(embeds)) * p["scale"] + p["bias"]).astype(F))
+
+    r3 = np.random.RandomState(77)
+    for ptype in ("epsilon", "v_prediction"):
+        for train_cfg in (True, False):
+            sch = S.FlaxDDIMScheduler(prediction_type=ptype, **sd_kwargs)
+            T = 50
+            st = sch.set_timesteps(sch.create_state(), T, (6, 4, 8, 8))
+            Bt = 6
+            lat = (r3.randn(Bt, 4, 8, 8) * 1.2).astype(F)
+            ts_vec = np.asarray(st.timesteps)[r3.randint(0, T, size=Bt)].astype(np.int32)
+            ts_vec[0] = 1                                          # last step: prev timestep < 0 -> final_alpha_cumprod
+            emb = r3.randn(Bt, 77, 16).astype(F)
+            unc = np.broadcast_to(r3.randn(1, 77, 16).astype(F), (Bt, 77, 16)).copy()
+            params = {"scale": F(0.9), "bias": F(0.05)}
+            # "sampled" next latents: one sampling-mode step of the same policy, then the stored log-probs are perturbed so
+            # that ratios fall inside, above and below the clip range
+            e_c = apply_fn({"params": params}, lat, ts_vec, emb).sample
+            e_u = apply_fn({"params": params}, lat, ts_vec, unc).sample
+            npred = (e_u + F(5.0) * (e_c - e_u)) if train_cfg else e_c
+            nxt = np.stack([np.asarray(sch.step(st, npred[i:i + 1], int(ts_vec[i]), lat[i:i + 1], jax.random.PRNGKey(500 + i), None, 1.0)[0])[0]
+                            for i in range(Bt)]).astype(F)
+            _, _, lp_now = sch.step(st, npred, ts_vec, lat, None, nxt, 1.0)
+            old_lp = (np.asarray(lp_now) + np.array([0.0, 3e-5, -6e-5, 2e-4, -3e-4, 5e-5], dtype=F)).astype(F)
+            adv = np.array([0.7, -1.3, 14.0, -12.5, 0.2, -0.4], dtype=F)     # two beyond the +-10 advantage clip
+            batch = {"latents": lat, "next_latents": nxt, "ts": ts_vec, "log_probs": old_lp, "advantages": adv,
+                     "prompt_embeds": emb, "uncond_embeds": unc}
+            received = []
+            state = PG.AccumulatingTrainState.create(apply_fn=apply_fn, params=params,
+                                                     tx=lambda p, g: (received.append(g), p)[1])
+            new_state, info = PG.train_step(state, batch, st, sch, train_cfg, 5.0, 1.0, 1e-4, False)
+            tag = f"train/{ptype}/cfg{int(train_cfg)}"
+            for k, v in batch.items():
+                out[f"{tag}/{k}"] = v
+            out[tag + "/eps_cond"], out[tag + "/eps_uncond"] = e_c, e_u
+            out[tag + "/loss"], out[tag + "/approx_kl"], out[tag + "/clipfrac"] = (np.asarray(info[k], dtype=F) for k in ("loss", "approx_kl", "clipfrac"))
+            assert new_state.n_acc == 1 and not received
+    # accumulation rule: 3 accumulating calls + 1 updating call; the optimizer must receive (g1+g2+g3+g4)/4, then reset
+    grads_seq = [{"w": (r3.randn(5) * (i + 1)).astype(F)} for i in range(6)]
+    received = []
+    state = PG.AccumulatingTrainState.create(apply_fn=None, params={"w": np.zeros(5, dtype=F)},
+                                             tx=lambda p, g: (received.append(g), {"w": p["w"] - g["w"]})[1])
+    trace = []
+    for i, g in enumerate(grads_seq):
+        state = state.apply_gradients(grads=g, do_update=(i in (3, 5)))
+        trace.append((state.n_acc, state.step, np.asarray(state.grad_acc["w"]).copy(), np.asarray(state.params["w"]).copy()))
+    out["accum/grads"] = np.stack([g["w"] for g in grads_seq])
+    out["accum/do_update"] = np.array([i in (3, 5) for i in range(6)])
+    out["accum/n_acc"] = np.array([t[0] for t in trace], dtype=np.int32)
+    out["accum/step"] = np.array([t[1] for t in trace], dtype=np.int32)
+    out["accum/grad_acc"] = np.stack([t[2] for t in trace])
+    out["accum/params"] = np.stack([t[3] for t in trace])
+    out["accum/received"] = np.stack([g["w"] for g in received])
+
     np.savez_compressed(OUT, **out)
     print(f"wrote {OUT}: {len(out)} arrays, {os.path.getsize(OUT)/1024:.0f} KiB")
 

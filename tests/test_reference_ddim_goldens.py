@@ -143,3 +143,75 @@ def test_product_pipeline_matches_reference_generate(tag):
     assert _rel(final.cpu().numpy(), G[tag + "/final"]) < 2e-5
     assert _rel(lat.cpu().numpy(), G[tag + "/latents"]) < 2e-5 and _rel(nxt.cpu().numpy(), G[tag + "/next_latents"]) < 2e-5
     np.testing.assert_allclose(lps.cpu().numpy(), G[tag + "/log_probs"], rtol=2e-4, atol=2e-4)
+
+
+# ------------------------------------------------------------------------------------------------ train_step / accumulation
+TRAIN = sorted({k.rsplit("/", 1)[0] for k in G.files if k.startswith("train/") and k.endswith("/loss")})
+
+
+def _train_args(tag):
+    _, ptype, cfg = tag.split("/")
+    return ptype, cfg == "cfg1"
+
+
+@pytest.mark.parametrize("tag", TRAIN)
+def test_oracle_ppo_loss_matches_reference_train_step(tag):
+    """The reference's train_step (ddpo/training/policy_gradient.py, exec'd unmodified by the fixture generator; jax.grad
+    replaced by a value-only stand-in) pins the loss closure: CFG combine, scoring-mode log-prob with per-sample timesteps,
+    advantage clip at +-10, ratio, PPO-clip loss, approx_kl, clipfrac."""
+    from oracle import ppo
+    ptype, train_cfg = _train_args(tag)
+    dd = DDIMOracle(prediction_type=ptype)
+    st = dd.set_timesteps(dd.create_state(), 50)
+    t = lambda k: torch.from_numpy(G[f"{tag}/{k}"])
+    batch = {k: t(k) for k in ("latents", "next_latents", "ts", "log_probs", "advantages")}
+    loss, info, _ = ppo.loss_and_info_torch(dd, st, t("eps_cond"), t("eps_uncond") if train_cfg else None, batch, 5.0, 1.0, 1e-4, train_cfg)
+    assert float(loss) == pytest.approx(float(G[tag + "/loss"]), rel=2e-5)
+    assert float(info["clipfrac"]) == pytest.approx(float(G[tag + "/clipfrac"]), abs=1e-7)
+    assert float(info["approx_kl"]) == pytest.approx(float(G[tag + "/approx_kl"]), rel=0.05)     # 0.5*mean((1e-4-scale differences of O(1) fp32 numbers)^2)
+    out = ppo.closed_form_numpy(dd, st, G[tag + "/eps_cond"], G[tag + "/eps_uncond"], G[tag + "/latents"], G[tag + "/next_latents"],
+                                G[tag + "/ts"], G[tag + "/log_probs"], G[tag + "/advantages"], 5.0, 1.0, 1e-4, train_cfg)
+    assert float(out[0]) == pytest.approx(float(G[tag + "/loss"]), rel=2e-5)
+
+
+def test_oracle_accumulation_matches_reference_class():
+    """AccumulatingTrainState of the reference (its real class over a minimal TrainState stand-in): n_acc / step / grad_acc
+    traces and the averaged gradient the optimizer receives."""
+    from oracle.optim import AccumulatingState
+
+    class _SGD:
+        def __init__(self):
+            self.received = []
+
+        def init(self, params):
+            return None
+
+        def update(self, params, grads, state):
+            self.received.append(grads[0].copy())
+            return [params[0] - grads[0]], state, None
+    opt = _SGD()
+    acc = AccumulatingState([np.zeros(5, dtype=F)], opt)
+    for i, g in enumerate(G["accum/grads"]):
+        acc.apply_gradients([g], bool(G["accum/do_update"][i]))
+        assert acc.n_acc == int(G["accum/n_acc"][i]) and acc.step == int(G["accum/step"][i])
+        np.testing.assert_allclose(acc.grad_acc[0], G["accum/grad_acc"][i], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(acc.params[0], G["accum/params"][i], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(np.stack(opt.received), G["accum/received"], rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", TRAIN)
+def test_product_ppo_kernel_matches_reference_train_step(tag):
+    """ddpo_ddim_logprob_ppo_fwd_bwd (C ABI) on the inputs of the reference-run train_step: loss / approx_kl / clipfrac."""
+    from ddpo_amd import lib as L
+    ptype, train_cfg = _train_args(tag)
+    sch = _product_scheduler(ptype)
+    st = sch.set_timesteps(sch.create_state(device="cuda"), 50)
+    d = lambda k: torch.from_numpy(np.ascontiguousarray(G[f"{tag}/{k}"])).cuda()
+    consts = sch.kernel_consts(st, 1.0)
+    _, _, per_sample, info = L.ddim_logprob_ppo_fwd_bwd(d("eps_cond"), d("eps_uncond") if train_cfg else None, d("latents"), d("next_latents"),
+                                                        d("ts"), d("log_probs"), d("advantages"), 5.0, 1e-4, train_cfg, consts)
+    info = info.cpu().numpy()
+    assert float(info[2]) == pytest.approx(float(G[tag + "/loss"]), rel=1e-4)
+    assert float(info[1]) == pytest.approx(float(G[tag + "/clipfrac"]), abs=1e-6)
+    assert float(info[0]) == pytest.approx(float(G[tag + "/approx_kl"]), rel=0.1)
