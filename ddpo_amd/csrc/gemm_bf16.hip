@@ -333,21 +333,29 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7FFFFFFF, 0x00020000);
 }
 
-template <int BM, int BN, int NPASS, int ABL = 0>     // ABL: timing ablations for tools/ablate_gemm.py only (wrong results)
-__global__ void __launch_bounds__(BF_THREADS) gemm_conv_bf16_buf_kernel(const ddpo_gemm_desc d, const uint16_t* __restrict__ w_hi,
+// WM x WN waves of (BM / WM) x (BN / WN) each: 2 x 2 waves for the 128x128 / 128x64 tiles (256 threads, 2-3 workgroups per
+// CU); 4 x 2 waves of 32 x 160 for the 128x320 tile (512 threads, one workgroup per CU), which moves 233 B from L2 per
+// MFMA instead of 341 (128x128) / 512 (128x64) and makes N = 320 / 640 / 1280 tile counts multiples of the 256 CUs.
+template <int BM, int BN, int NPASS, int ABL = 0, int WM = 2, int WN = 2>     // ABL: timing ablations (tools/ablate_gemm.py; wrong results)
+__global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const ddpo_gemm_desc d, const uint16_t* __restrict__ w_hi,
                                                                        const uint16_t* __restrict__ w_lo, int ldw, int tiles_m,
                                                                        int tiles_n, int nblk, int kt_per_split,
                                                                        float* __restrict__ part) {
   constexpr int BK = BF_BK;
-  constexpr int TM = BM / 64, TN = BN / 64;
-  constexpr int AROWS = BM / 32;
-  constexpr int BCH = BN / 64;
+  constexpr int THREADS = 64 * WM * WN;
+  constexpr int WTM = BM / WM, WTN = BN / WN;           // wave sub-tile
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int AR = THREADS / 8, BR = THREADS / 4;     // rows covered by one pass of the A / W loaders
+  constexpr int AROWS = BM / AR;
+  constexpr int BCH = (BN + BR - 1) / BR;
+  constexpr bool BFULL = (BN % BR) == 0;                // else the last W pass covers only part of the threads
+  static_assert(BM % AR == 0 && WTM % 32 == 0 && WTN % 32 == 0, "tile / wave-grid mismatch");
   constexpr int NPL = (NPASS == 3) ? 2 : 1;
   constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int STAGE = NPL * (A_BYTES + B_BYTES);
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
-  const int wm = wid >> 1, wn = wid & 1;
+  const int wm = wid / WN, wn = wid % WN;
 
   int bid = blockIdx.x;
   {
@@ -379,7 +387,7 @@ __global__ void __launch_bounds__(BF_THREADS) gemm_conv_bf16_buf_kernel(const dd
   uint32_t avoff[AROWS];                        // byte offset of the CURRENT tap's pixel (+ kq*16), or BUF_OOB
 #pragma unroll
   for (int i = 0; i < AROWS; ++i) {
-    const int m = m0 + (t >> 3) + 32 * i;
+    const int m = m0 + (t >> 3) + AR * i;
     const bool valid = m < d.M;
     if (conv) {
       const int ohw = d.OH * d.OW;
@@ -413,9 +421,10 @@ __global__ void __launch_bounds__(BF_THREADS) gemm_conv_bf16_buf_kernel(const dd
   uint32_t bvoff[BCH];
 #pragma unroll
   for (int i = 0; i < BCH; ++i) {
-    const int n = n0 + (t >> 2) + 64 * i;
+    const int br = (t >> 2) + BR * i;
+    const int n = n0 + br;
     const uint32_t row_bytes = d.w_dgrad ? (uint32_t)d.Cin * 2u : (uint32_t)ldw * 2u;
-    bvoff[i] = n < d.N ? (uint32_t)n * row_bytes + bc * 16u : BUF_OOB;
+    bvoff[i] = (n < d.N && (BFULL || br < BN)) ? (uint32_t)n * row_bytes + bc * 16u : BUF_OOB;
   }
 
   const int nk_total = d.K / BK;
@@ -458,9 +467,9 @@ __global__ void __launch_bounds__(BF_THREADS) gemm_conv_bf16_buf_kernel(const dd
 
   int a_st[AROWS], b_st[BCH];
 #pragma unroll
-  for (int i = 0; i < AROWS; ++i) a_st[i] = swz_off((t >> 3) + 32 * i, kq >> 1) + (kq & 1) * 8;
+  for (int i = 0; i < AROWS; ++i) a_st[i] = swz_off((t >> 3) + AR * i, kq >> 1) + (kq & 1) * 8;
 #pragma unroll
-  for (int i = 0; i < BCH; ++i) b_st[i] = swz_off((t >> 2) + 64 * i, bc);
+  for (int i = 0; i < BCH; ++i) b_st[i] = swz_off((t >> 2) + BR * i, bc);
 
   auto store_tile = [&](int buf, const Stage& sg) {
     char* st = smem + buf * STAGE;
@@ -474,6 +483,7 @@ __global__ void __launch_bounds__(BF_THREADS) gemm_conv_bf16_buf_kernel(const dd
     char* sb = st + NPL * A_BYTES;
 #pragma unroll
     for (int i = 0; i < BCH; ++i) {
+      if (!BFULL && (t >> 2) + BR * i >= BN) continue;
       *reinterpret_cast<uint4*>(sb + b_st[i]) = sg.bh[i];
       if (NPASS == 3) *reinterpret_cast<uint4*>(sb + B_BYTES + b_st[i]) = sg.bl[i];
     }
@@ -492,9 +502,9 @@ __global__ void __launch_bounds__(BF_THREADS) gemm_conv_bf16_buf_kernel(const dd
 #pragma unroll
   for (int ks = 0; ks < BK / 16; ++ks) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) a_ld[ks][i] = swz_off(wm * (BM / 2) + i * 32 + (lane & 31), ks * 2 + khalf);
+    for (int i = 0; i < TM; ++i) a_ld[ks][i] = swz_off(wm * WTM + i * 32 + (lane & 31), ks * 2 + khalf);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) b_ld[ks][j] = swz_off(wn * (BN / 2) + j * 32 + (lane & 31), ks * 2 + khalf);
+    for (int j = 0; j < TN; ++j) b_ld[ks][j] = swz_off(wn * WTN + j * 32 + (lane & 31), ks * 2 + khalf);
   }
 
   // Fragment loads are software-pipelined by hand across the barrier: the ks=0 fragments of the NEXT k-tile are requested
@@ -515,12 +525,12 @@ __global__ void __launch_bounds__(BF_THREADS) gemm_conv_bf16_buf_kernel(const dd
       if (NPASS == 3) f.bl[j] = *reinterpret_cast<const bf16x8*>(sb + B_BYTES + b_ld[ks][j]);
     }
   };
-  auto mma = [&](const Frag& f, int ibeg, int iend) {       // row-blocks [ibeg, iend) of the wave tile
+  auto mma = [&](const Frag& f, int tbeg, int tend) {       // 32x32 blocks [tbeg, tend) of the wave tile, row-major
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      if (i < ibeg || i >= iend) continue;
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
+        if (i * TN + j < tbeg || i * TN + j >= tend) continue;
         if (NPASS == 3) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
@@ -530,7 +540,7 @@ __global__ void __launch_bounds__(BF_THREADS) gemm_conv_bf16_buf_kernel(const dd
     }
   };
   Frag f0, f1;
-  constexpr int TMH = TM / 2;
+  constexpr int TT = TM * TN, TH = TT / 2;          // all blocks / the part issued in front of the barrier
 
   // prologue: tile 0 -> LDS[0]; tile 1 in flight in s0.  The loop consumes k-tiles in pairs; an odd last tile is
   // computed after it (it already sits in LDS[0] with its ks=0 fragments in f0).
@@ -555,32 +565,32 @@ __global__ void __launch_bounds__(BF_THREADS) gemm_conv_bf16_buf_kernel(const dd
     // even step: MFMAs on LDS[0]; s0 holds tile kt+1, tile kt+2 starts loading into s1
     if (!(ABL & 1)) load_tile(kt + 2, s1);
     if (!(ABL & 8)) ldfrag(0, 1, f1);
-    mma(f0, 0, TM);
+    mma(f0, 0, TT);
     if (!(ABL & 2)) store_tile(1, s0);
     __builtin_amdgcn_sched_barrier(0);          // LDS stores retire under the next MFMAs, not in front of the barrier
-    mma(f1, 0, TMH);
+    mma(f1, 0, TH);
     __builtin_amdgcn_sched_barrier(0);
     if (!(ABL & 4)) __syncthreads();
     if (!(ABL & 8)) ldfrag(1, 0, f0);
     __builtin_amdgcn_sched_barrier(0);
-    mma(f1, TMH, TM);
+    mma(f1, TH, TT);
     // odd step: MFMAs on LDS[1]; s1 holds tile kt+2, tile kt+3 starts loading into s0
     if (!(ABL & 1)) load_tile(kt + 3, s0);
     if (!(ABL & 8)) ldfrag(1, 1, f1);
-    mma(f0, 0, TM);
+    mma(f0, 0, TT);
     if (!(ABL & 2)) store_tile(0, s1);
     __builtin_amdgcn_sched_barrier(0);
-    mma(f1, 0, TMH);
+    mma(f1, 0, TH);
     __builtin_amdgcn_sched_barrier(0);
     if (!(ABL & 4)) __syncthreads();
     if (!(ABL & 8)) ldfrag(0, 0, f0);
     __builtin_amdgcn_sched_barrier(0);
-    mma(f1, TMH, TM);
+    mma(f1, TH, TT);
   }
   if (nk & 1) {
     ldfrag(0, 1, f1);
-    mma(f0, 0, TM);
-    mma(f1, 0, TM);
+    mma(f0, 0, TT);
+    mma(f1, 0, TT);
   }
 
   // ---- epilogue.  The C fragment gives a lane one column and 16 scattered rows (dword stores, 2 x 128 B per wave
@@ -591,11 +601,11 @@ __global__ void __launch_bounds__(BF_THREADS) gemm_conv_bf16_buf_kernel(const dd
                       (!d.rowbias || ((d.ld_rowbias & 3) == 0 && (reinterpret_cast<uintptr_t>(d.rowbias) & 15) == 0)) &&
                       (!d.bias || (reinterpret_cast<uintptr_t>(d.bias) & 15) == 0);
   if (vec_ok && !(ABL & 16)) {
-    constexpr int WTN = BN / 2;                  // wave sub-tile: 64 rows x WTN columns
-    constexpr int LPR = WTN / 4;                 // lanes per row (float4 each)
-    constexpr int RPI = 64 / LPR;                // rows per wave instruction
+    constexpr int LPR = WTN / 4;                 // float4 per row of the wave sub-tile (WTM rows x WTN columns)
+    constexpr int NIT = WTM * LPR / 64;          // wave instructions to move it
+    static_assert((WTM * LPR) % 64 == 0, "wave sub-tile must be a whole number of 1 KiB rows");
     __syncthreads();                             // all waves are done with the operand tiles
-    float* cw = reinterpret_cast<float*>(smem) + wid * (64 * WTN);
+    float* cw = reinterpret_cast<float*>(smem) + wid * (WTM * WTN);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -604,7 +614,7 @@ __global__ void __launch_bounds__(BF_THREADS) gemm_conv_bf16_buf_kernel(const dd
         for (int r = 0; r < 16; ++r)
           cw[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf) * WTN + j * 32 + (lane & 31)] = acc[i][j][r];
     // (wave-private slice: program order + lgkmcnt is all the synchronisation needed)
-    if (BN == 128 && d.epilogue == 1) {          // GEGLU: this wave's 64 columns are [a (32) | gate (32)] of output chunk q
+    if (BN == 128 && WN == 2 && WM == 2 && d.epilogue == 1) {          // GEGLU: this wave's 64 columns are [a (32) | gate (32)] of output chunk q
       const int q = (n0 + wn * 64) >> 6;
       const int gc = (lane & 7) * 4, grow = lane >> 3;          // 8 lanes x float4 = 32 output columns; 8 rows per instruction
       const float4 ba = d.bias ? *reinterpret_cast<const float4*>(d.bias + q * 64 + gc) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -623,17 +633,17 @@ __global__ void __launch_bounds__(BF_THREADS) gemm_conv_bf16_buf_kernel(const dd
       }
       return;
     }
-    const int lcol = (lane % LPR) * 4, lrow = lane / LPR;
-    const int col = n0 + wn * WTN + lcol;
-    if (col < d.N) {
-      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (!part && d.bias) bv = *reinterpret_cast<const float4*>(d.bias + col);
+    {
       float* pp = part ? part + (int64_t)blockIdx.y * d.M * d.N : nullptr;
 #pragma unroll
-      for (int it = 0; it < 64 / RPI; ++it) {
-        const int rr = it * RPI + lrow;
-        const int row = m0 + wm * 64 + rr;
-        if (row >= d.M) continue;
+      for (int it = 0; it < NIT; ++it) {
+        const int e = it * 64 + lane;            // float4 index inside the sub-tile: consecutive lanes, consecutive 16 bytes
+        const int rr = e / LPR, lcol = (e - rr * LPR) * 4;
+        const int row = m0 + wm * WTM + rr;
+        const int col = n0 + wn * WTN + lcol;
+        if (row >= d.M || col >= d.N) continue;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!part && d.bias) bv = *reinterpret_cast<const float4*>(d.bias + col);
         float4 v = *reinterpret_cast<const float4*>(cw + rr * WTN + lcol);
         if (part) {
           *reinterpret_cast<float4*>(pp + (int64_t)row * d.N + col) = v;
@@ -659,11 +669,11 @@ __global__ void __launch_bounds__(BF_THREADS) gemm_conv_bf16_buf_kernel(const dd
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const int col = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+        const int col = n0 + wn * WTN + j * 32 + (lane & 31);
         if (col >= d.N) continue;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+          const int row = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
           if (row < d.M) pp[(int64_t)row * d.N + col] = acc[i][j][r];
         }
       }
@@ -673,12 +683,12 @@ __global__ void __launch_bounds__(BF_THREADS) gemm_conv_bf16_buf_kernel(const dd
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const int col = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+      const int col = n0 + wn * WTN + j * 32 + (lane & 31);
       if (col >= d.N) continue;
       const float bv = d.bias ? d.bias[col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+        const int row = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
         if (row >= d.M) continue;
         if ((ABL & 16) && (r | i | j)) { if (acc[i][j][r] == 123.456f) d.out[0] = 1.f; continue; }
         float v = d.alpha * acc[i][j][r] + bv;
@@ -730,7 +740,7 @@ static bool buf_path_ok(const ddpo_gemm_desc& d, int ldw) {
 }
 extern "C" void ddpo_debug_force_generic_gemm(int on) { g_force_generic = on != 0; }
 
-template <int BM, int BN, int NPASS>
+template <int BM, int BN, int NPASS, int WM = 2, int WN = 2>
 static int launch_bf16(const ddpo_gemm_desc& d, const uint16_t* w_hi, const uint16_t* w_lo, int ldw, float* ws, size_t ws_bytes,
                        hipStream_t st) {
   const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;
@@ -757,12 +767,12 @@ static int launch_bf16(const ddpo_gemm_desc& d, const uint16_t* w_hi, const uint
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_bf16_kernel<BM, BN, NPASS, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_bf16_buf_kernel<BM, BN, NPASS>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_bf16_buf_kernel<BM, BN, NPASS, 0, WM, WN>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   if (buf_path_ok(d, ldw))
-    hipLaunchKernelGGL((gemm_conv_bf16_buf_kernel<BM, BN, NPASS>), dim3(nblk, splits), dim3(BF_THREADS), lds, st, d, w_hi, w_lo, ldw,
+    hipLaunchKernelGGL((gemm_conv_bf16_buf_kernel<BM, BN, NPASS, 0, WM, WN>), dim3(nblk, splits), dim3(64 * WM * WN), lds, st, d, w_hi, w_lo, ldw,
                        tiles_m, tiles_n, nblk, ktps, part);
   else if (d.upsample == 0)
     hipLaunchKernelGGL((gemm_conv_bf16_kernel<BM, BN, NPASS, true>), dim3(nblk, splits), dim3(BF_THREADS), lds, st, d, w_hi, w_lo, ldw,
@@ -780,6 +790,47 @@ static int launch_bf16(const ddpo_gemm_desc& d, const uint16_t* w_hi, const uint
   return DDPO_OK;
 }
 
+
+// 128x320 tiles, 8 waves (4 x 2), one workgroup per CU: buffer-addressed kernel only (caller checked buf_path_ok).
+// Tile counts of the U-Net layers are multiples of the 256 CUs at the 64x64 and 32x32 levels; below that the reduction is
+// split so that ~256 workgroups exist.
+template <int NPASS>
+static int launch_bf16_wide(const ddpo_gemm_desc& d, const uint16_t* w_hi, const uint16_t* w_lo, int ldw, float* ws, size_t ws_bytes,
+                            hipStream_t st) {
+  constexpr int BM = 128, BN = 320, WM = 4, WN = 2;
+  const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;
+  const int nblk = tiles_m * tiles_n;
+  const int nk_total = d.K / BF_BK;
+  int splits = 1;
+  if (ws && nblk <= 192 && nk_total >= 16) {
+    splits = (256 + nblk / 2) / nblk;
+    if (splits > 8) splits = 8;
+    if (splits > nk_total / 8) splits = nk_total / 8;
+    if (splits < 1) splits = 1;
+    while (splits > 1 && (size_t)splits * d.M * d.N * sizeof(float) > ws_bytes) --splits;
+  }
+  int ktps = (nk_total + splits - 1) / splits;
+  ktps = (ktps + 1) & ~1;
+  splits = (nk_total + ktps - 1) / ktps;
+  float* part = splits > 1 ? ws : nullptr;
+  const size_t lds = (size_t)BM * BN * 4;                  // epilogue image (160 KB) > 2 stages of operand tiles (112 KB)
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_bf16_buf_kernel<BM, BN, NPASS, 0, WM, WN>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_conv_bf16_buf_kernel<BM, BN, NPASS, 0, WM, WN>), dim3(nblk, splits), dim3(64 * WM * WN), lds, st, d, w_hi, w_lo,
+                     ldw, tiles_m, tiles_n, nblk, ktps, part);
+  DDPO_LAUNCH_CHECK();
+  if (splits > 1) {
+    int64_t blocks = ((int64_t)d.M * (d.N >> 2) + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)blocks), dim3(256), 0, st, d, part, splits);
+    DDPO_LAUNCH_CHECK();
+  }
+  return DDPO_OK;
+}
 
 // timing ablations of the 128x128 bf16x3 k-loop (results are WRONG for mode != 0); used by tools/ablate_gemm.py only
 template <int ABL>
@@ -838,10 +889,18 @@ extern "C" int ddpo_gemm_conv_fwd_bf16(const ddpo_gemm_desc* dp, const uint16_t*
     if ((d.ld_out & 3) || (reinterpret_cast<uintptr_t>(d.out) & 15) || (d.bias && (reinterpret_cast<uintptr_t>(d.bias) & 15))) return DDPO_EINVAL;
     return npass == 3 ? launch_bf16<128, 128, 3>(d, w_hi, w_lo, ldw, nullptr, 0, st) : launch_bf16<128, 128, 1>(d, w_hi, w_lo, ldw, nullptr, 0, st);
   }
+  float* wsf = (ws && !(reinterpret_cast<uintptr_t>(ws) & 15)) ? reinterpret_cast<float*>(ws) : nullptr;
+  static const int wide_mode = [] { const char* e = getenv("DDPO_GEMM_WIDE"); return e ? atoi(e) : 1; }();   // tuning knob: 0 disables 128x320
+  // 128x320 tiles unless the grid would be tiny with a short reduction (nothing to split) or the reduction is so short
+  // that the 160 KB epilogue image dominates a many-column GEMM (measured: K=320, N=2560 is better on 128x128)
+  const long tiles_w = (long)((d.M + 127) / 128) * (d.N / 320);
+  const int nk_w = d.K / BF_BK;
+  if (wide_mode && d.N % 320 == 0 && d.M >= 512 && buf_path_ok(d, ldw) && (tiles_w >= 64 || (tiles_w >= 16 && nk_w >= 128)) &&
+      !(nk_w < 16 && d.N > 1280))
+    return npass == 3 ? launch_bf16_wide<3>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st) : launch_bf16_wide<1>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st);
   const long t128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128);
   static const long big_min = [] { const char* e = getenv("DDPO_GEMM_BIG_MIN"); return e ? atol(e) : 256L; }();   // tuning knob (tools/)
   const bool big = (d.N % 128 == 0) && t128 >= big_min;
-  float* wsf = (ws && !(reinterpret_cast<uintptr_t>(ws) & 15)) ? reinterpret_cast<float*>(ws) : nullptr;
   if (npass == 3)
     return big ? launch_bf16<128, 128, 3>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st) : launch_bf16<128, 64, 3>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st);
   return big ? launch_bf16<128, 128, 1>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st) : launch_bf16<128, 64, 1>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st);

@@ -31,7 +31,8 @@ TOL = {"bf16x3": 5e-5, "bf16": 3e-2}
 
 
 @pytest.mark.parametrize("mode", ["bf16x3", "bf16"])
-@pytest.mark.parametrize("M,K,N", [(64, 32, 64), (154, 64, 128), (1000, 320, 320), (4096, 1280, 640), (16, 1280, 320), (2048, 320, 2560), (300, 768, 320), (256, 5120, 1280)])
+@pytest.mark.parametrize("M,K,N", [(64, 32, 64), (154, 64, 128), (1000, 320, 320), (4096, 1280, 640), (16, 1280, 320), (2048, 320, 2560), (300, 768, 320), (256, 5120, 1280),
+                                   (4096, 320, 320), (5000, 640, 960), (4096, 1280, 1280), (8192, 2560, 640)])   # last four: 128x320 tiles (+ split-K)
 def test_gemm_dense_bf16(datapath, mode, M, K, N):
     L.DATAPATH = mode
     g = torch.Generator().manual_seed(M + K + N)
@@ -51,7 +52,9 @@ def test_gemm_dense_bf16(datapath, mode, M, K, N):
 @pytest.mark.parametrize("B,H,W,Cin,Cout,ks,stride,ups", [
     (2, 8, 8, 32, 64, 3, 1, False), (2, 8, 8, 96, 64, 3, 1, False), (2, 8, 8, 64, 64, 3, 2, False), (2, 4, 4, 128, 128, 3, 1, True),
     (2, 8, 8, 64, 128, 1, 1, False), (1, 32, 32, 320, 320, 3, 1, False), (2, 16, 16, 640, 640, 3, 2, False), (3, 5, 7, 32, 64, 3, 1, False),
-    (2, 8, 8, 32, 8, 3, 1, False), (4, 8, 8, 1280, 1280, 3, 1, False), (1, 16, 16, 1280, 640, 3, 1, False)])   # last two: split-K
+    (2, 8, 8, 32, 8, 3, 1, False), (4, 8, 8, 1280, 1280, 3, 1, False), (1, 16, 16, 1280, 640, 3, 1, False),   # last two: split-K
+    (2, 64, 64, 320, 320, 3, 1, False), (4, 64, 64, 320, 640, 3, 2, False), (2, 32, 32, 640, 640, 3, 1, True),  # 128x320 tiles
+    (3, 40, 24, 64, 320, 3, 1, False), (16, 16, 16, 1280, 1280, 1, 1, False)])
 def test_conv_bf16(datapath, mode, B, H, W, Cin, Cout, ks, stride, ups):
     L.DATAPATH = mode
     g = torch.Generator().manual_seed(H + Cin + Cout)
