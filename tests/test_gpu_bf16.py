@@ -93,9 +93,9 @@ def test_linear_geglu_fused_epilogue(datapath, mode, M, K, F):
     fused = L.linear_geglu(x, w)
     unfused = L.geglu(L.linear(x, w, b))
     assert fused.shape == (M, F)
-    if M >= 256:
+    if M >= 4096:                                            # enough tiles that neither launch splits the reduction
         assert torch.equal(fused, unfused)
-    else:                                                    # few tiles: the unfused GEMM takes the split-K route (other summation order)
+    else:                                                    # few tiles: the unfused GEMM takes a split-K route (other summation order)
         assert _rel(fused, unfused) < 1e-5
     f64 = x.cpu().double() @ w.cpu().double() + b.cpu().double()
     ref = f64[:, :F] * TF.gelu(f64[:, F:], approximate="tanh")
