@@ -794,6 +794,20 @@ static int launch_bf16(const ddpo_gemm_desc& d, const uint16_t* w_hi, const uint
 // 128x320 tiles, 8 waves (4 x 2), one workgroup per CU: buffer-addressed kernel only (caller checked buf_path_ok).
 // Tile counts of the U-Net layers are multiples of the 256 CUs at the 64x64 and 32x32 levels; below that the reduction is
 // split so that ~256 workgroups exist.
+static int wide_splits(const ddpo_gemm_desc& d, bool have_ws, size_t ws_bytes) {
+  const int nblk = ((d.M + 127) / 128) * ((d.N + 319) / 320);
+  const int nk_total = d.K / BF_BK;
+  int splits = 1;
+  if (have_ws && nblk <= 192 && nk_total >= 16) {
+    splits = (256 + nblk / 2) / nblk;
+    if (splits > 8) splits = 8;
+    if (splits > nk_total / 8) splits = nk_total / 8;
+    if (splits < 1) splits = 1;
+    while (splits > 1 && (size_t)splits * d.M * d.N * sizeof(float) > ws_bytes) --splits;
+  }
+  return splits;
+}
+
 template <int NPASS>
 static int launch_bf16_wide(const ddpo_gemm_desc& d, const uint16_t* w_hi, const uint16_t* w_lo, int ldw, float* ws, size_t ws_bytes,
                             hipStream_t st) {
@@ -801,14 +815,7 @@ static int launch_bf16_wide(const ddpo_gemm_desc& d, const uint16_t* w_hi, const
   const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;
   const int nblk = tiles_m * tiles_n;
   const int nk_total = d.K / BF_BK;
-  int splits = 1;
-  if (ws && nblk <= 192 && nk_total >= 16) {
-    splits = (256 + nblk / 2) / nblk;
-    if (splits > 8) splits = 8;
-    if (splits > nk_total / 8) splits = nk_total / 8;
-    if (splits < 1) splits = 1;
-    while (splits > 1 && (size_t)splits * d.M * d.N * sizeof(float) > ws_bytes) --splits;
-  }
+  int splits = wide_splits(d, ws != nullptr, ws_bytes);
   int ktps = (nk_total + splits - 1) / splits;
   ktps = (ktps + 1) & ~1;
   splits = (nk_total + ktps - 1) / ktps;
@@ -891,12 +898,10 @@ extern "C" int ddpo_gemm_conv_fwd_bf16(const ddpo_gemm_desc* dp, const uint16_t*
   }
   float* wsf = (ws && !(reinterpret_cast<uintptr_t>(ws) & 15)) ? reinterpret_cast<float*>(ws) : nullptr;
   static const int wide_mode = [] { const char* e = getenv("DDPO_GEMM_WIDE"); return e ? atoi(e) : 1; }();   // tuning knob: 0 disables 128x320
-  // 128x320 tiles unless the grid would be tiny with a short reduction (nothing to split) or the reduction is so short
-  // that the 160 KB epilogue image dominates a many-column GEMM (measured: K=320, N=2560 is better on 128x128)
-  const long tiles_w = (long)((d.M + 127) / 128) * (d.N / 320);
-  const int nk_w = d.K / BF_BK;
-  if (wide_mode && d.N % 320 == 0 && d.M >= 512 && buf_path_ok(d, ldw) && (tiles_w >= 64 || (tiles_w >= 16 && nk_w >= 128)) &&
-      !(nk_w < 16 && d.N > 1280))
+  // 128x320 tiles (one workgroup per CU) when they, times the split of the reduction, give every CU a workgroup; a
+  // many-column GEMM with a very short reduction is better on 128x128 (measured: K=320, N=2560; the 160 KB epilogue image)
+  if (wide_mode && d.N % 320 == 0 && d.M >= 512 && buf_path_ok(d, ldw) && !(d.K / BF_BK < 16 && d.N > 1280) &&
+      (long)((d.M + 127) / 128) * (d.N / 320) * wide_splits(d, wsf != nullptr, ws_bytes) >= 200)
     return npass == 3 ? launch_bf16_wide<3>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st) : launch_bf16_wide<1>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st);
   const long t128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128);
   static const long big_min = [] { const char* e = getenv("DDPO_GEMM_BIG_MIN"); return e ? atol(e) : 256L; }();   // tuning knob (tools/)
