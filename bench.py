@@ -236,7 +236,7 @@ def main():
         passes = {"fp32": 1, "bf16": 1, "bf16x3": 3}[dom]
         peak = FP32_MFMA_PEAK_TFLOPS if dom == "fp32" else BF16_MFMA_PEAK_TFLOPS
         kname = "gemm_conv_kernel (v_mfma_f32_32x32x2_f32)" if dom == "fp32" else \
-            f"gemm_conv_bf16_buf_kernel<128,128|64,NPASS={passes}> (v_mfma_f32_32x32x16_bf16)"
+            f"gemm_conv_bf16_buf_kernel<128x320 | 128x128 | 128x64, NPASS={passes}> (v_mfma_f32_32x32x16_bf16)"
         traffic, traffic_note = None, None
         tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
         if os.path.exists(tpath):

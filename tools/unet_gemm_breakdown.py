@@ -19,6 +19,13 @@ def rec(src, w, *, M, N, K, conv=None, **kw):
     shapes.append((M, N, K, (conv or {}).get("ksize", 0), (conv or {}).get("stride", 1), (conv or {}).get("upsample", 0)))
     return orig(src, w, M=M, N=N, K=K, conv=conv, **kw)
 L.gemm_conv = rec
+orig_geglu = L.linear_geglu
+def rec_geglu(x, w, out=None):
+    r = orig_geglu(x, w, out=out)
+    if r is not None:
+        shapes.append((x.shape[0], w.shape[1], x.shape[1], -1, 1, 0))      # ks = -1 marks the fused FF1 + GEGLU launch
+    return r
+L.linear_geglu = rec_geglu
 unet(x, t, c); torch.cuda.synchronize()
 shapes.clear(); L.PROFILE = []
 unet(x, t, c); torch.cuda.synchronize()
