@@ -336,7 +336,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
 // WM x WN waves of (BM / WM) x (BN / WN) each: 2 x 2 waves for the 128x128 / 128x64 tiles (256 threads, 2-3 workgroups per
 // CU); 4 x 2 waves of 32 x 160 for the 128x320 tile (512 threads, one workgroup per CU), which moves 233 B from L2 per
 // MFMA instead of 341 (128x128) / 512 (128x64) and makes N = 320 / 640 / 1280 tile counts multiples of the 256 CUs.
-template <int BM, int BN, int NPASS, int ABL = 0, int WM = 2, int WN = 2>     // ABL: timing ablations (tools/ablate_gemm.py; wrong results)
+// DEEP: global loads run two k-tiles ahead of the MFMAs (two register stages) instead of one.  Measured on the 8-wave tile:
+// one-ahead frees 26 VGPRs (no spills) but is 4-18 % slower than two-ahead with its 14 spilled dwords, so DEEP stays on.
+template <int BM, int BN, int NPASS, int ABL = 0, int WM = 2, int WN = 2, bool DEEP = true>     // ABL: timing ablations (tools/ablate_gemm.py; wrong results)
 __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const ddpo_gemm_desc d, const uint16_t* __restrict__ w_hi,
                                                                        const uint16_t* __restrict__ w_lo, int ldw, int tiles_m,
                                                                        int tiles_n, int nblk, int kt_per_split,
@@ -553,7 +555,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
   } else {
     load_tile(0, s0);
     store_tile(0, s0);
-    load_tile(1, s0);
+    if (DEEP) load_tile(1, s0);
   }
   __syncthreads();
   ldfrag(0, 0, f0);
@@ -562,8 +564,8 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
   const int nk2 = nk & ~1;
 #pragma unroll 1
   for (int kt = 0; kt < nk2; kt += 2) {
-    // even step: MFMAs on LDS[0]; s0 holds tile kt+1, tile kt+2 starts loading into s1
-    if (!(ABL & 1)) load_tile(kt + 2, s1);
+    // even step: MFMAs on LDS[0]; DEEP: s0 holds tile kt+1 and tile kt+2 starts loading into s1; else tile kt+1 loads into s0 now
+    if (!(ABL & 1)) { if (DEEP) load_tile(kt + 2, s1); else load_tile(kt + 1, s0); }
     if (!(ABL & 8)) ldfrag(0, 1, f1);
     mma(f0, 0, TT);
     if (!(ABL & 2)) store_tile(1, s0);
@@ -574,11 +576,11 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
     if (!(ABL & 8)) ldfrag(1, 0, f0);
     __builtin_amdgcn_sched_barrier(0);
     mma(f1, TH, TT);
-    // odd step: MFMAs on LDS[1]; s1 holds tile kt+2, tile kt+3 starts loading into s0
-    if (!(ABL & 1)) load_tile(kt + 3, s0);
+    // odd step: MFMAs on LDS[1]
+    if (!(ABL & 1)) { if (DEEP) load_tile(kt + 3, s0); else load_tile(kt + 2, s0); }
     if (!(ABL & 8)) ldfrag(1, 1, f1);
     mma(f0, 0, TT);
-    if (!(ABL & 2)) store_tile(0, s1);
+    if (!(ABL & 2)) { if (DEEP) store_tile(0, s1); else store_tile(0, s0); }
     __builtin_amdgcn_sched_barrier(0);
     mma(f1, 0, TH);
     __builtin_amdgcn_sched_barrier(0);
@@ -823,11 +825,11 @@ static int launch_bf16_wide(const ddpo_gemm_desc& d, const uint16_t* w_hi, const
   const size_t lds = (size_t)BM * BN * 4;                  // epilogue image (160 KB) > 2 stages of operand tiles (112 KB)
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_bf16_buf_kernel<BM, BN, NPASS, 0, WM, WN>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_bf16_buf_kernel<BM, BN, NPASS, 0, WM, WN, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_conv_bf16_buf_kernel<BM, BN, NPASS, 0, WM, WN>), dim3(nblk, splits), dim3(64 * WM * WN), lds, st, d, w_hi, w_lo,
+  hipLaunchKernelGGL((gemm_conv_bf16_buf_kernel<BM, BN, NPASS, 0, WM, WN, true>), dim3(nblk, splits), dim3(64 * WM * WN), lds, st, d, w_hi, w_lo,
                      ldw, tiles_m, tiles_n, nblk, ktps, part);
   DDPO_LAUNCH_CHECK();
   if (splits > 1) {
