@@ -9,8 +9,6 @@ from ddpo_amd import lib as L
 L.DATAPATH = "bf16x3"
 dev = "cuda"
 lib = L.load()
-lib.ddpo_debug_gemm_ablate.restype = ctypes.c_int
-lib.ddpo_debug_gemm_ablate.argtypes = [ctypes.POINTER(L.GemmDesc), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
 
 
 MODES = (0, 16, 15, 31, 47, 63) if len(sys.argv) > 1 and sys.argv[1] == "short" else (0, 1, 2, 6, 7, 8, 15)
