@@ -122,7 +122,8 @@ def llava_bertscore(devices=None, jit=False, url="http://127.0.0.1:8085", batch_
 
 def llava_vqa_satisfaction(devices=None, jit=False, url="http://127.0.0.1:8085", batch_size=4, timeout=120):
     """VQA reward (reference :402-462): request {"images", "queries"} (questions from the prompt metadata), reply
-    {"outputs"}; the score of an image is the fraction of answers that contain the expected answer string."""
+    {"outputs"}; the score of an image is the fraction of answers that contain the expected answer string
+    (case-sensitive); info = {"answers": the server's outputs}."""
     sess = _llava_session()
 
     def _fn(images, prompts, metadata):
@@ -130,16 +131,17 @@ def llava_vqa_satisfaction(devices=None, jit=False, url="http://127.0.0.1:8085",
         images = (np.asarray(images) * 255).astype(np.uint8)
         nb = int(np.ceil(len(images) / batch_size))
         metadata = list(metadata)
-        scores, outputs = [], []
+        scores, answers = [], []
         for img_b, meta_b in zip(np.array_split(images, nb), np.array_split(np.arange(len(images)), nb)):
             metas = [metadata[i] for i in meta_b]
             payload = {"images": [_to_jpeg_bytes(im) for im in img_b], "queries": [m["questions"] for m in metas]}
             reply = pickle.loads(sess.post(url, data=pickle.dumps(payload), timeout=timeout).content)
             for m, outs in zip(metas, reply["outputs"]):
-                hits = [a.lower() in o.lower() for a, o in zip(m["answers"], outs)]
-                scores.append(float(np.mean(hits)))
-                outputs.append(list(outs))
-        return np.array(scores), {"outputs": np.array(outputs, dtype=object)}
+                assert len(outs) == len(m["answers"])
+                hits = [a in o for a, o in zip(m["answers"], outs)]          # case-sensitive substring test (:357-360)
+                scores.append(float(np.mean(np.array(hits, dtype=int))))
+            answers += reply["outputs"]
+        return np.array(scores), {"answers": np.array(answers)}
 
     return _fn
 

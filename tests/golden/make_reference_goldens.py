@@ -13,6 +13,9 @@ What runs from the reference, unmodified, loaded by file path:
   * encode_jpeg (ddpo/utils/hdf5.py) and jpeg_fn / neg_jpeg_fn (ddpo/training/callbacks.py), lifted with `ast` like the
     loaders below                                                              -> JPEG-size rewards of seeded images
     (byte counts depend on the PIL / libjpeg build: the fixture records PIL's version and the test skips on another)
+  * llava_bertscore / llava_vqa_satisfaction (+ single_satisfaction), lifted the same way, with requests.Session.post
+    intercepted: the REQUEST each batch would send (pickled dict: JPEG q=80 bytes, queries, answers; np.array_split
+    batching) and what the callback returns for a scripted reply                -> the LLaVA wire protocol
 The reference's `ddpo.utils` package cannot be imported here (jax / flax / gcsfs / h5py missing), so prompts.py gets a
 stand-in `ddpo.utils` whose `load_lines` / `load_general_prompts` are the reference's OWN function bodies, lifted out of
 ddpo/utils/serialization.py with `ast` and exec'd unchanged.  `inflect` is not installable offline: a three-call
@@ -195,6 +198,48 @@ def main():
         jcases.append({"seed": seed, "n": n, "hw": hw, "jpeg": np.asarray(s_jpeg).tolist(), "neg_jpeg": np.asarray(s_neg).tolist(),
                        "dtype": str(np.asarray(s_jpeg).dtype), "shape": list(np.asarray(s_jpeg).shape)})
     out["jpeg_rewards"] = {"pil_version": PIL.__version__, "cases": jcases}
+
+    # ---------------------------------------------------------------- LLaVA reward wire protocol
+    import hashlib
+    import pickle
+    import requests
+    cbl = lift_functions(os.path.join(REF, "ddpo/training/callbacks.py"), ["single_satisfaction", "llava_vqa_satisfaction", "llava_bertscore"],
+                         {"np": np, "Image": Image, "DEVICES": None})
+    cbl["llava_vqa_satisfaction"].__globals__["single_satisfaction"] = cbl["single_satisfaction"]
+    captured = []
+
+    def fake_post(self, url, data=None, timeout=None, **kw):
+        req = pickle.loads(data)
+        n = len(req["images"])
+        i0 = sum(len(c["images_sha256"]) for c in captured)
+        captured.append({"url": url, "timeout": timeout, "keys": sorted(req), "queries": req["queries"], "answers": req.get("answers"),
+                         "images_sha256": [hashlib.sha256(b).hexdigest() for b in req["images"]], "images_len": [len(b) for b in req["images"]]})
+        if "answers" in req:          # bertscore server
+            rep = {"recall": [[0.05 * (i0 + i) + 0.1] for i in range(n)], "precision": [[0.9 - 0.01 * (i0 + i)] for i in range(n)],
+                   "f1": [[0.5 + 0.002 * (i0 + i)] for i in range(n)], "outputs": [[f"a picture of thing {i0 + i}"] for i in range(n)]}
+        else:                         # vqa server: one answer string per question
+            rep = {"outputs": [[("It is a Cat." if (i0 + i + j) % 3 == 0 else "riding a bike") for j in range(len(req["queries"][i]))] for i in range(n)]}
+        return types.SimpleNamespace(content=pickle.dumps(rep), status_code=200)
+
+    real_post = requests.Session.post
+    requests.Session.post = fake_post
+    try:
+        imgs = jpeg_test_images(5, 20, 32)
+        prompts = np.array([f"a {w} riding a bike" for w in ("cat dog horse monkey rabbit spider bird sheep cow lion tiger bear raccoon fox wolf ant fish "
+                                                              "squirrel turtle frog").split()])
+        captured.clear()
+        sc, info = cbl["llava_bertscore"]()(imgs.copy(), prompts, None)
+        out["llava_bertscore"] = {"n": 20, "hw": 32, "seed": 5, "prompts": prompts.tolist(), "requests": list(captured),
+                                  "scores": np.asarray(sc).tolist(), "info": {k: np.asarray(v).tolist() for k, v in info.items()},
+                                  "info_dtypes": {k: str(np.asarray(v).dtype.kind) for k, v in info.items()}}
+        meta = [{"questions": ["what animal is this?", "what is it doing?"], "answers": ["Cat", "bike"], "prompt": str(p)} for p in prompts[:10]]
+        captured.clear()
+        sc, info = cbl["llava_vqa_satisfaction"]()(imgs[:10].copy(), None, meta)
+        out["llava_vqa"] = {"n": 10, "hw": 32, "seed": 5, "metadata": meta, "requests": list(captured), "scores": np.asarray(sc).tolist(),
+                            "info": {k: np.asarray(v).tolist() for k, v in info.items()},
+                            "info_shapes": {k: list(np.asarray(v).shape) for k, v in info.items()}}
+    finally:
+        requests.Session.post = real_post
 
     with open(OUT, "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)

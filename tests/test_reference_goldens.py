@@ -112,3 +112,48 @@ def test_jpeg_rewards_match_reference_functions():
             scores = np.asarray(scores)
             assert list(scores.shape) == case["shape"] and str(scores.dtype) == case["dtype"] and info == {}
             assert scores.tolist() == case[name]
+
+
+def _patched_post(captured, kind):
+    import hashlib
+    import pickle
+    import types
+
+    def fake_post(self, url, data=None, timeout=None, **kw):
+        req = pickle.loads(data)
+        n = len(req["images"])
+        i0 = sum(len(c["images_sha256"]) for c in captured)
+        captured.append({"url": url, "timeout": timeout, "keys": sorted(req), "queries": req["queries"], "answers": req.get("answers"),
+                         "images_sha256": [hashlib.sha256(b).hexdigest() for b in req["images"]], "images_len": [len(b) for b in req["images"]]})
+        if kind == "bertscore":
+            rep = {"recall": [[0.05 * (i0 + i) + 0.1] for i in range(n)], "precision": [[0.9 - 0.01 * (i0 + i)] for i in range(n)],
+                   "f1": [[0.5 + 0.002 * (i0 + i)] for i in range(n)], "outputs": [[f"a picture of thing {i0 + i}"] for i in range(n)]}
+        else:
+            rep = {"outputs": [[("It is a Cat." if (i0 + i + j) % 3 == 0 else "riding a bike") for j in range(len(req["queries"][i]))] for i in range(n)]}
+        return types.SimpleNamespace(content=pickle.dumps(rep), status_code=200)
+    return fake_post
+
+
+@pytest.mark.parametrize("kind", ["bertscore", "vqa"])
+def test_llava_wire_protocol_matches_reference_functions(kind, monkeypatch):
+    """The LLaVA reward callbacks against the reference's own functions (lifted + run by the fixture generator with
+    requests.Session.post intercepted): identical requests per batch (keys, queries, answers, JPEG q=80 bytes by sha256,
+    np.array_split batching, URL, timeout) and identical (scores, info) for the same scripted server replies."""
+    import PIL
+    import requests
+    from ddpo_amd.training import callbacks as CB
+    ref = GOLD["llava_bertscore" if kind == "bertscore" else "llava_vqa"]
+    if PIL.__version__ != GOLD["jpeg_rewards"]["pil_version"]:
+        pytest.skip("JPEG bytes depend on the PIL build the fixture was produced with")
+    captured = []
+    monkeypatch.setattr(requests.Session, "post", _patched_post(captured, kind))
+    images = _jpeg_test_images(ref["seed"], 20, ref["hw"])[:ref["n"]]
+    if kind == "bertscore":
+        scores, info = CB.callback_fns["llava_bertscore"]()(images, np.array(ref["prompts"]), None)
+    else:
+        scores, info = CB.callback_fns["llava_vqa"]()(images, None, ref["metadata"])
+    assert json.loads(json.dumps(captured)) == ref["requests"]
+    assert np.asarray(scores).tolist() == ref["scores"]
+    assert sorted(info) == sorted(ref["info"])
+    for k, v in ref["info"].items():
+        assert np.asarray(info[k]).tolist() == v
