@@ -902,8 +902,10 @@ extern "C" int ddpo_gemm_conv_fwd_bf16(const ddpo_gemm_desc* dp, const uint16_t*
   static const int wide_mode = [] { const char* e = getenv("DDPO_GEMM_WIDE"); return e ? atoi(e) : 1; }();   // tuning knob: 0 disables 128x320
   // 128x320 tiles (one workgroup per CU) when they, times the split of the reduction, give every CU a workgroup; a
   // many-column GEMM with a very short reduction is better on 128x128 (measured: K=320, N=2560; the 160 KB epilogue image)
+  const int wsplits = wide_splits(d, wsf != nullptr, ws_bytes);
   if (wide_mode && d.N % 320 == 0 && d.M >= 512 && buf_path_ok(d, ldw) && !(d.K / BF_BK < 16 && d.N > 1280) &&
-      (long)((d.M + 127) / 128) * (d.N / 320) * wide_splits(d, wsf != nullptr, ws_bytes) >= 200)
+      (long)((d.M + 127) / 128) * (d.N / 320) * wsplits >= 200 &&
+      !(wsplits > 1 && d.K / BF_BK < 64))       // a split short reduction only adds the reduce pass (measured equal to 128x128 unsplit)
     return npass == 3 ? launch_bf16_wide<3>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st) : launch_bf16_wide<1>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st);
   const long t128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128);
   static const long big_min = [] { const char* e = getenv("DDPO_GEMM_BIG_MIN"); return e ? atol(e) : 256L; }();   // tuning knob (tools/)
