@@ -1129,10 +1129,21 @@ extern "C" int ddpo_gemm_conv_wgrad_bf16x3(const ddpo_gemm_desc* dp, void* strea
   const int tiles_m = (d.K + 127) / 128, tiles_n = (d.N + 127) / 128, tiles = tiles_m * tiles_n;
   int splits = d.splits;
   if (splits <= 0) {
-    splits = (1024 + tiles - 1) / tiles;
+    // two workgroups fit a CU (74 KB LDS): pick the split of the pixel reduction whose tiles x splits fills whole rounds
+    // of the 512 slots best (1035 workgroups cost three rounds, 966 two); among near-equal fills prefer fewer splits
+    // (fewer atomic adds, longer k-loops).
     const int max_splits = (d.M + 255) / 256;
-    if (splits > max_splits) splits = max_splits;
-    if (splits < 1) splits = 1;
+    int best = 1;
+    double best_eff = 0.0;
+    for (int r = 1; r <= 4; ++r) {
+      int cand = (512 * r) / tiles;
+      if (cand > max_splits) cand = max_splits;
+      if (cand < 1) cand = 1;
+      const long wgs = (long)tiles * cand;
+      const double eff = (double)wgs / (double)(((wgs + 511) / 512) * 512);
+      if (eff > best_eff + 0.03 || (best_eff == 0.0)) { best_eff = eff; best = cand; }
+    }
+    splits = best;
   }
   int mps = (d.M + splits - 1) / splits;
   mps = (mps + 31) / 32 * 32;
