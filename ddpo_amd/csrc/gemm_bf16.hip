@@ -1002,15 +1002,20 @@ __global__ void __launch_bounds__(BF_THREADS) gemm_wgrad_bf16_kernel(const ddpo_
   }
   const int ng = n0 + arow;
   const bool nvalid = ng < d.N;
-  // the 4 pixels this thread stages per k-tile: m = m_begin + kt*32 + 16*p + 2*pp + e ; track (oy, ox) incrementally
-  int poy[2][2], pox[2][2];
+  // the 4 OUTPUT pixels this thread stages per k-tile: m = m_begin + kt*32 + 16*p + 2*pp + e ; (batch, oy, ox) are tracked
+  // incrementally.  Stride-1 "same" convolutions read input pixel m + a constant tap offset (`simple`); strided and
+  // nearest-2x-upsampled ones compute the source pixel of the tap from (oy, ox).
+  const bool simple = !conv || (d.stride == 1 && d.upsample == 0 && d.OH == d.H && d.OW == d.W);
+  const int VH = d.upsample ? 2 * d.H : d.H, VW = d.upsample ? 2 * d.W : d.W;
+  int pb[2][2], poy[2][2], pox[2][2];
 #pragma unroll
   for (int p = 0; p < 2; ++p)
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const int m = m_begin + 16 * p + 2 * pp + e;
-      poy[p][e] = conv ? (m / d.W) % d.H : 0;
-      pox[p][e] = conv ? m % d.W : 0;
+      pox[p][e] = conv ? m % d.OW : 0;
+      poy[p][e] = conv ? (m / d.OW) % d.OH : 0;
+      pb[p][e] = conv ? m / (d.OW * d.OH) : 0;
     }
   const int64_t tap_off = conv ? ((int64_t)dky * d.W + dkx) * d.ld_src + ci : kg;
 
@@ -1024,19 +1029,24 @@ __global__ void __launch_bounds__(BF_THREADS) gemm_wgrad_bf16_kernel(const ddpo_
         float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
         if (m < m_end) {
           bool ok = kvalid;
+          int64_t aoff = (int64_t)m * d.ld_src + tap_off;
           if (conv) {
-            const int iy = poy[p][e] + dky, ix = pox[p][e] + dkx;
-            ok = ok && iy >= 0 && iy < d.H && ix >= 0 && ix < d.W;
+            const int iy = poy[p][e] * d.stride + dky, ix = pox[p][e] * d.stride + dkx;       // virtual (upsampled) coordinates
+            ok = ok && iy >= 0 && iy < VH && ix >= 0 && ix < VW;
+            if (!simple) {
+              const int sy = d.upsample ? (iy >> 1) : iy, sx = d.upsample ? (ix >> 1) : ix;
+              aoff = ((int64_t)(pb[p][e] * d.H + sy) * d.W + sx) * d.ld_src + ci;
+            }
           }
-          if (ok) va = *reinterpret_cast<const float4*>(d.src + (int64_t)m * d.ld_src + tap_off);
+          if (ok) va = *reinterpret_cast<const float4*>(d.src + aoff);
           if (nvalid) vb = *reinterpret_cast<const float4*>(d.w + (int64_t)m * d.ld_w + ng);
         }
         ra[p][e] = va;
         rb[p][e] = vb;
         if (conv) {          // advance this pixel by BK
           pox[p][e] += BK;
-          while (pox[p][e] >= d.W) { pox[p][e] -= d.W; ++poy[p][e]; }
-          while (poy[p][e] >= d.H) poy[p][e] -= d.H;
+          while (pox[p][e] >= d.OW) { pox[p][e] -= d.OW; ++poy[p][e]; }
+          while (poy[p][e] >= d.OH) { poy[p][e] -= d.OH; ++pb[p][e]; }
         }
       }
   };
@@ -1124,7 +1134,8 @@ extern "C" int ddpo_gemm_conv_wgrad_bf16x3(const ddpo_gemm_desc* dp, void* strea
   if (d.ksize > 0) {
     if (d.ksize != 1 && d.ksize != 3) return DDPO_EINVAL;
     if ((d.Cin & 3) || d.K != d.ksize * d.ksize * d.Cin || d.M != d.B * d.OH * d.OW) return DDPO_EINVAL;
-    if (d.stride != 1 || d.upsample != 0 || d.pad != d.ksize / 2 || d.OH != d.H || d.OW != d.W) return DDPO_EINVAL;   // fast path only
+    if (d.stride < 1 || d.stride > 2 || d.upsample < 0 || d.upsample > 1 || d.pad != d.ksize / 2) return DDPO_EINVAL;
+    if ((int64_t)d.B * d.H * d.W * d.ld_src >= ((int64_t)1 << 40)) return DDPO_EINVAL;
   }
   const int tiles_m = (d.K + 127) / 128, tiles_n = (d.N + 127) / 128, tiles = tiles_m * tiles_n;
   int splits = d.splits;

@@ -549,7 +549,7 @@ def gemm_wgrad(src, dy, dw, *, M, N, K, conv=None, ld_src=None, ld_dy=None, accu
     if conv:
         for k in ("ksize", "stride", "pad", "upsample", "B", "H", "W", "Cin", "OH", "OW"):
             setattr(d, k, int(conv[k]))
-    fast = DATAPATH != "fp32" and accumulate and (conv is None or (conv["stride"] == 1 and not conv["upsample"] and
+    fast = DATAPATH != "fp32" and accumulate and (conv is None or (conv["stride"] in (1, 2) and conv["upsample"] in (0, 1) and
                                                                       conv["pad"] == conv["ksize"] // 2)) and K >= 64 and N >= 32
     if fast:
         _check(load().ddpo_gemm_conv_wgrad_bf16x3(byref(d), _stream()), "ddpo_gemm_conv_wgrad_bf16x3")

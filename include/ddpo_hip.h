@@ -159,8 +159,8 @@ int ddpo_gemm_conv_fwd_bf16(const ddpo_gemm_desc* d, const uint16_t* w_hi, const
 /* ws (optional, 16-byte aligned): scratch for a deterministic split-K of launches whose tile grid under-fills the chip
  * (partials + fixed-order reduce with the fused epilogue); pass NULL/0 to disable. */
 /* Weight gradient on the bf16x3 MFMA datapath (same arguments as ddpo_gemm_conv_wgrad; always accumulates with fp32
- * atomics).  Fast path only: dense, or convolutions with stride 1, pad = ksize/2 and no upsampling (returns
- * DDPO_EINVAL otherwise - callers fall back to ddpo_gemm_conv_wgrad). */
+ * atomics).  Dense, or convolutions with pad = ksize/2, stride 1 or 2, optionally over a nearest-2x upsampled input
+ * (returns DDPO_EINVAL otherwise - callers fall back to ddpo_gemm_conv_wgrad). */
 int ddpo_gemm_conv_wgrad_bf16x3(const ddpo_gemm_desc* d, void* stream);
 /* fp32 W (K,N) -> bf16 hi/lo planes: fwd_* (N, Kp) k-contiguous (Kp = K rounded up to 8, zero padded) and, if
  * bwd_hi != NULL, bwd_* (K, N).  Call after every optimizer update (weights only change there). */

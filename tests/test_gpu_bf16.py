@@ -186,6 +186,28 @@ def test_conv_wgrad_bf16x3(datapath, B, H, W, Cin, Cout, ks):
     assert _rel(dw, 2 * ref) < 5e-5
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride,ups", [(2, 16, 16, 64, 64, 2, False), (3, 12, 20, 96, 128, 2, False), (2, 8, 8, 64, 96, 1, True),
+                                                        (1, 32, 32, 320, 320, 2, False), (2, 16, 16, 640, 640, 1, True), (2, 6, 10, 64, 64, 1, True)])
+def test_conv_wgrad_bf16x3_strided_and_upsampled(datapath, B, H, W, Cin, Cout, stride, ups):
+    """Downsample (stride 2) and nearest-2x-upsample convolutions of the U-Net: weight gradients on the bf16x3 kernel
+    (source pixel of each tap computed from the output coordinate) against float64 autograd."""
+    L.DATAPATH = "bf16x3"
+    g = torch.Generator().manual_seed(H + Cin + Cout + stride + int(ups))
+    x = torch.randn(B, H, W, Cin, generator=g)
+    wd = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    xin = x.permute(0, 3, 1, 2).double()
+    if ups:
+        xin = TF.interpolate(xin, scale_factor=2, mode="nearest")
+    y = TF.conv2d(xin, wd, None, stride=stride, padding=1)
+    OH, OW = y.shape[2], y.shape[3]
+    dy = torch.randn(B, OH, OW, Cout, generator=g)
+    y.backward(dy.permute(0, 3, 1, 2).double())
+    ref = wd.grad.permute(2, 3, 1, 0)
+    dw = torch.zeros(3, 3, Cin, Cout, device=DEV)
+    L.conv2d_wgrad(x.reshape(-1, Cin).to(DEV), dy.reshape(-1, Cout).to(DEV), dw, B, H, W, Cin, Cout, 3, stride=stride, upsample=ups)
+    assert _rel(dw, ref) < 5e-5
+
+
 @pytest.mark.parametrize("M,K,N", [(300, 320, 640), (4096, 64, 128), (2048, 640, 5120), (154, 768, 320), (4, 1280, 320)])
 def test_linear_wgrad_bf16x3(datapath, M, K, N):
     L.DATAPATH = "bf16x3"
