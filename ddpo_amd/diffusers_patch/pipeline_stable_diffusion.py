@@ -78,14 +78,22 @@ class StableDiffusionPipeline:
         lat2 = torch.empty((2 * B,) + shape[1:], dtype=torch.float32, device=dev)
         # jit=True (the reference's pmapped/jitted path): replay the U-Net as a captured HIP graph
         unet_fwd = self.unet.forward_graphed if jit else self.unet
-        for s in range(T):
-            x = traj[s]
-            lat2[:B].copy_(x)                                       # jnp.concatenate([old_latents] * 2)
-            lat2[B:].copy_(x)
-            noise_pred = unet_fwd(lat2, ts_dev[s], context)
-            L.threefry_normal(step_keys[s], shape, out=z)
-            L.ddim_step_fwd(noise_pred[:B], noise_pred[B:], x, z, ts_dev[s, :B], guidance_scale, consts,
-                            x_next=traj[s + 1], logp=log_probs[s])
+        # the text context is the same for all T steps: project it through the cross-attention to_k / to_v once
+        cache_ctx = hasattr(self.unet, "precompute_context")
+        if cache_ctx:
+            self.unet.precompute_context(context)
+        try:
+            for s in range(T):
+                x = traj[s]
+                lat2[:B].copy_(x)                                   # jnp.concatenate([old_latents] * 2)
+                lat2[B:].copy_(x)
+                noise_pred = unet_fwd(lat2, ts_dev[s], context)
+                L.threefry_normal(step_keys[s], shape, out=z)
+                L.ddim_step_fwd(noise_pred[:B], noise_pred[B:], x, z, ts_dev[s, :B], guidance_scale, consts,
+                                x_next=traj[s + 1], logp=log_probs[s])
+        finally:
+            if cache_ctx:
+                self.unet.release_context()
         final_latents = traj[T]
         ts = ts_dev[:, :B].transpose(0, 1)                          # (B, T)
         return (final_latents, traj[:T].transpose(0, 1), traj[1:].transpose(0, 1), log_probs.transpose(0, 1), ts)

@@ -252,6 +252,8 @@ class UNet2DCondition:
         self.device = torch.device(device)
         self.params = ParamStore(unet_param_shapes(cfg), self.device)
         self.grads = None
+        self._ctx_kv = {}                 # cross-attention name -> (K, V) of the text context (precompute_context)
+        self._ctx_kv_active = False
 
     def ensure_grads(self):
         """Flat fp32 gradient-accumulation buffer with the parameter layout (AccumulatingTrainState.grad_acc)."""
@@ -263,9 +265,13 @@ class UNet2DCondition:
     def _attention(self, name, x, B, N, C, heads, ctx, ctx_len, rec=None):
         P = self.params
         q = L.linear(x, P[name + ".to_q.kernel"])
-        kv_src = x if ctx is None else ctx
-        k = L.linear(kv_src, P[name + ".to_k.kernel"])
-        v = L.linear(kv_src, P[name + ".to_v.kernel"])
+        cached = self._ctx_kv.get(name) if (ctx is not None and rec is None and self._ctx_kv_active) else None
+        if cached is not None:                     # text-context K / V were projected once for this sampling call
+            k, v = cached
+        else:
+            kv_src = x if ctx is None else ctx
+            k = L.linear(kv_src, P[name + ".to_k.kernel"])
+            v = L.linear(kv_src, P[name + ".to_v.kernel"])
         Nk = N if ctx is None else ctx_len
         if rec is None:
             return L.attention(q, k, v, B, heads, N, Nk, C // heads)
@@ -443,12 +449,37 @@ class UNet2DCondition:
     __call__ = forward
 
     # -------------------------------------------------------------------------------- HIP-graph replay
+    # -------------------------------------------------------------------------------- text-context K/V cache (sampling)
+    def cross_attention_names(self):
+        return [n[:-len(".to_k.kernel")] for n in self.params.views if n.endswith(".attn2.to_k.kernel")]
+
+    def precompute_context(self, context):
+        """Project the (constant) text context through every cross-attention to_k / to_v ONCE for a sampling call: the 50
+        DDIM steps then skip 32 small GEMMs each.  Results land in persistent buffers (same addresses across calls, so a
+        captured HIP graph keeps reading them); bit-identical to projecting per step.  Valid until `release_context()` or
+        the next parameter update — the sampler brackets its step loop with these two calls."""
+        B, Lc, D = context.shape
+        ctx = context.reshape(B * Lc, D).contiguous()
+        for name in self.cross_attention_names():
+            wk, wv = self.params[name + ".to_k.kernel"], self.params[name + ".to_v.kernel"]
+            ent = self._ctx_kv.get(name)
+            if ent is None or ent[0].shape != (B * Lc, wk.shape[1]):
+                ent = (torch.empty(B * Lc, wk.shape[1], dtype=torch.float32, device=self.device),
+                       torch.empty(B * Lc, wv.shape[1], dtype=torch.float32, device=self.device))
+                self._ctx_kv[name] = ent
+            L.linear(ctx, wk, out=ent[0])
+            L.linear(ctx, wv, out=ent[1])
+        self._ctx_kv_active = True
+
+    def release_context(self):
+        self._ctx_kv_active = False
+
     def forward_graphed(self, sample, timesteps, context):
         """Same as forward(), but the ~1000 kernel launches of one U-Net pass are captured once into a HIP graph (per
         input geometry) and replayed: the launch-bound host loop disappears from the sampling hot loop.  Inputs are copied
         into the graph's static buffers; the returned tensor is the graph's static output (valid until the next replay).
         Weights are read in place, so optimizer updates / re-packing are seen by later replays."""
-        key = (tuple(sample.shape), tuple(context.shape), L.DATAPATH)
+        key = (tuple(sample.shape), tuple(context.shape), L.DATAPATH, self._ctx_kv_active)
         if not hasattr(self, "_graphs"):
             self._graphs = {}
         ent = self._graphs.get(key)
