@@ -36,16 +36,30 @@ __global__ void __launch_bounds__(GN_THREADS) gn_stats_kernel(const float* __res
     ncol = (C4 - t + GN_THREADS - 1) / GN_THREADS;
   }
   const float* xb = x + (int64_t)b * HW * ldx;
-  for (int p = p0 + poff; p < p1; p += ppi) {
-    const float* row = xb + (int64_t)p * ldx;
+  // four pixel rows are requested before any is consumed (the loop is latency-bound otherwise); they are accumulated in
+  // the original pixel order, so the partial sums are bit-identical to a one-row-at-a-time loop
+  constexpr int UNR = 4;
+  for (int p = p0 + poff; p < p1; p += UNR * ppi) {
+    float4 v[UNR][GN_MAXCOL];
 #pragma unroll
-    for (int j = 0; j < GN_MAXCOL; ++j) {
-      if (j < ncol) {
-        const float4 v = *reinterpret_cast<const float4*>(row + ((col0 + j * GN_THREADS) << 2));
-        sum[j][0] += v.x; sq[j][0] += v.x * v.x;
-        sum[j][1] += v.y; sq[j][1] += v.y * v.y;
-        sum[j][2] += v.z; sq[j][2] += v.z * v.z;
-        sum[j][3] += v.w; sq[j][3] += v.w * v.w;
+    for (int u = 0; u < UNR; ++u) {
+      const int pu = p + u * ppi;
+      const float* row = xb + (int64_t)pu * ldx;
+#pragma unroll
+      for (int j = 0; j < GN_MAXCOL; ++j)
+        v[u][j] = (j < ncol && pu < p1) ? *reinterpret_cast<const float4*>(row + ((col0 + j * GN_THREADS) << 2)) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      if (p + u * ppi >= p1) break;
+#pragma unroll
+      for (int j = 0; j < GN_MAXCOL; ++j) {
+        if (j < ncol) {
+          sum[j][0] += v[u][j].x; sq[j][0] += v[u][j].x * v[u][j].x;
+          sum[j][1] += v[u][j].y; sq[j][1] += v[u][j].y * v[u][j].y;
+          sum[j][2] += v[u][j].z; sq[j][2] += v[u][j].z * v[u][j].z;
+          sum[j][3] += v[u][j].w; sq[j][3] += v[u][j].w * v[u][j].w;
+        }
       }
     }
   }
