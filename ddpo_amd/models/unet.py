@@ -5,7 +5,8 @@ Replaces the `self.unet.apply(...)` call sites of the reference:
   /root/reference/ddpo/training/policy_gradient.py:87-102                          (training, cond + uncond passes)
 Parameters keep the Flax tree naming / layouts (conv HWIO, dense (in,out)) so a Flax checkpoint dict loads as is;
 they live in ONE flat fp32 buffer (one RCCL all-reduce, one fused AdamW launch).
-Activations are NHWC rows (B*H*W, C) in fp32; every contraction runs on the exact-fp32 MFMA datapath.
+Activations are NHWC rows (B*H*W, C) in fp32; contractions run on the datapath selected by `lib.DATAPATH` (exact-fp32 MFMA, or
+bf16 MFMA with the fp32 operands split into hi + lo planes: weights registered by `ParamStore.pack_bf16`).
 """
 import math
 from collections import OrderedDict
