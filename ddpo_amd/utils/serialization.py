@@ -11,7 +11,8 @@ Weight sources, in order:
      checkpoints) — a warning is printed and `pipeline.synthetic_weights` is True.
 Checkpoints: the reference saves only the U-Net params every `save_freq` epochs and can never resume
 (/root/reference/pipeline/policy_gradient.py:97-103,457-464); here `save_checkpoint` writes the params as safetensors
-(weights-only, same content) plus an optional resume bundle (optimizer moments, step, RNG keys, stat tracker).
+(weights-only, same content) AND in the reference's own flax-msgpack file format (`checkpoint_<epoch>`, readable by its
+`flax:` load path; `utils/flax_msgpack.py`), plus an optional resume bundle (optimizer moments, step, RNG keys, stat tracker).
 """
 import os
 
@@ -60,7 +61,13 @@ def load_unet(loadpath=None, epoch="latest", pretrained_model="duongna/stable-di
               f"random-init {family} weights")
         unet.params.init_synthetic(seed)
         vae.params.init_synthetic(seed + 1)
-    if loadpath:
+    if loadpath and str(loadpath).startswith("flax:"):
+        # the reference's own checkpoint files (flax msgpack of the U-Net param tree), reference :357-362
+        from .flax_msgpack import load_flax_checkpoint
+        path = str(loadpath)[len("flax:"):]
+        print(f"[ utils/serialization ] Loading flax checkpoint from {path}")
+        unet.params.load_dict(load_flax_checkpoint(path))
+    elif loadpath:
         ck = latest_checkpoint(loadpath) if epoch == "latest" else os.path.join(loadpath, f"checkpoint_{epoch}.safetensors")
         if ck:
             print(f"[ utils/serialization ] loading fine-tuned U-Net from {ck}")
@@ -88,12 +95,18 @@ def latest_checkpoint(ckpt_dir):
     return os.path.join(ckpt_dir, f"checkpoint_{steps[-1]}.safetensors") if steps else None
 
 
-def save_checkpoint(ckpt_dir, params, step, resume_state=None):
-    """Rank-0 write of the U-Net params (Flax names / layouts) as `checkpoint_<step>.safetensors` (+ resume bundle)."""
+def save_checkpoint(ckpt_dir, params, step, resume_state=None, flax_format=True):
+    """Rank-0 write of the U-Net params (Flax names / layouts) as `checkpoint_<step>.safetensors` (+ resume bundle) and,
+    with `flax_format`, as `checkpoint_<step>` in flax's msgpack encoding — the file the reference's
+    `save_checkpoint_multiprocess(..., unreplicate(state.params), step=epoch)` writes and its `flax:` load path reads."""
     from safetensors.torch import save_file
     os.makedirs(ckpt_dir, exist_ok=True)
     path = os.path.join(ckpt_dir, f"checkpoint_{step}.safetensors")
-    save_file({n: v.detach().cpu().contiguous() for n, v in params.views.items()}, path)
+    host = {n: v.detach().cpu().contiguous() for n, v in params.views.items()}
+    save_file(host, path)
+    if flax_format:
+        from .flax_msgpack import save_flax_checkpoint
+        save_flax_checkpoint(ckpt_dir, {n: v.numpy() for n, v in host.items()}, step)
     if resume_state is not None:
         torch.save(resume_state, os.path.join(ckpt_dir, f"resume_{step}.pt"))
     return path

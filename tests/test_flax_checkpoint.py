@@ -1,0 +1,52 @@
+"""The reference's checkpoint file format (flax msgpack of the U-Net param tree): writer / reader round trip, the byte-level
+encoding of a leaf (ext type 1 = packb((shape, dtype name, C-order bytes))), chunked leaves, and the name mapping between
+this engine's flat parameter names and the Flax module tree.  (flax itself is not installable here: the format is restated
+from flax 0.6.9 `serialization.msgpack_serialize`, see ddpo_amd/utils/flax_msgpack.py.)"""
+import os
+
+import msgpack
+import numpy as np
+
+from ddpo_amd.utils import flax_msgpack as FM
+from ddpo_amd.models.unet import UNetConfig, unet_param_shapes
+
+
+def _tiny_params(seed=0):
+    rng = np.random.RandomState(seed)
+    return {n: rng.randn(*shp).astype(np.float32) for n, shp in unet_param_shapes(UNetConfig.named("tiny")).items()}
+
+
+def test_round_trip_and_tree_structure(tmp_path):
+    flat = _tiny_params()
+    path = FM.save_flax_checkpoint(str(tmp_path), flat, step=7)
+    assert os.path.basename(path) == "checkpoint_7"
+    back = FM.load_flax_checkpoint(path)
+    assert set(back) == set(flat)
+    assert all(back[n].dtype == np.float32 and np.array_equal(back[n], flat[n]) for n in flat)
+    assert FM.load_flax_checkpoint(str(tmp_path)).keys() == flat.keys()          # directory -> latest step
+    tree = FM.nest(flat)
+    assert {"conv_in", "time_embedding", "down_blocks_0", "mid_block", "up_blocks_3", "conv_norm_out", "conv_out"} <= set(tree)
+    assert set(tree["down_blocks_0"]["resnets_0"]["conv1"]) == {"kernel", "bias"}
+    assert tree["down_blocks_0"]["attentions_0"]["transformer_blocks_0"]["attn1"]["to_q"]["kernel"].shape == (32, 32)   # Dense (in, out), no bias
+    assert tree["conv_in"]["kernel"].shape == (3, 3, 4, 32)                                                            # conv HWIO
+
+
+def test_leaf_encoding_is_flax_ext_type_1():
+    arr = np.arange(12, dtype=np.float32).reshape(3, 4)
+    raw = msgpack.unpackb(FM.to_bytes({"a": {"kernel": arr}, "step": np.int32(5)}), raw=False, strict_map_key=False)
+    leaf = raw["a"]["kernel"]
+    assert isinstance(leaf, msgpack.ExtType) and leaf.code == 1
+    shape, dtype_name, buf = msgpack.unpackb(leaf.data, raw=True)
+    assert list(shape) == [3, 4] and dtype_name == b"float32" and buf == arr.tobytes("C")
+    assert raw["step"].code == 3                                                   # numpy scalar
+    back = FM.from_bytes(FM.to_bytes({"a": {"kernel": arr}, "step": np.int32(5)}))
+    assert back["step"] == 5 and np.array_equal(back["a"]["kernel"], arr)
+
+
+def test_chunked_leaf_is_reassembled(monkeypatch):
+    monkeypatch.setattr(FM, "_MAX_CHUNK_BYTES", 64)
+    arr = np.arange(100, dtype=np.float32).reshape(10, 10)
+    data = FM.to_bytes({"w": arr})
+    raw = msgpack.unpackb(data, ext_hook=FM._ext_unpack, raw=False, strict_map_key=False)
+    assert raw["w"]["__msgpack_chunked_array__"] is True and len(raw["w"]["chunks"]) == 7
+    assert np.array_equal(FM.from_bytes(data)["w"], arr)

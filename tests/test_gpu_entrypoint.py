@@ -41,6 +41,14 @@ def test_entrypoint_single_process(tmp_path, monkeypatch):
     w0, w1 = load_file(os.path.join(ck, "checkpoint_0.safetensors")), load_file(os.path.join(ck, "checkpoint_1.safetensors"))
     assert len(w0) == 686 or len(w0) > 100
     assert any(not torch.equal(w0[k], w1[k]) for k in w0)                            # the optimizer moved the weights
+    # the same parameters in the reference's own checkpoint format (flax msgpack, file `checkpoint_<epoch>`) ...
+    from ddpo_amd.utils.flax_msgpack import load_flax_checkpoint
+    fx = load_flax_checkpoint(os.path.join(ck, "checkpoint_1"))
+    assert set(fx) == set(w1) and all(np.array_equal(fx[k], w1[k].numpy()) for k in w1)
+    # ... and the reference's `flax:` load path restores them
+    from ddpo_amd.utils.serialization import load_unet
+    _, params = load_unet("flax:" + ck, pretrained_model="none", device="cuda")        # DDPO_MODEL_CONFIG=tiny is still set
+    assert all(torch.equal(params["unet"][k].cpu(), w1[k]) for k in w1)
 
 
 @pytest.mark.timeout(600)
