@@ -61,3 +61,20 @@ def test_param_inventory_matches_oracle():
     assert dict(vae_decoder_param_shapes(VAEConfig.named("sd"))) == dict(OU.vae_decoder_param_shapes(OU.VAE_SD))
     assert dict(vae_decoder_param_shapes(VAEConfig.named("tiny"))) == dict(OU.vae_decoder_param_shapes(OU.VAE_TINY))
     assert sum(int(np.prod(s)) for s in unet_param_shapes(UNetConfig.named("sd15")).values()) == 859520964
+
+
+def test_gemm_desc_field_order_matches_header():
+    """The ctypes mirror must list the fields of ddpo_gemm_desc in the header's order (equal sizes alone would not catch
+    two swapped ints)."""
+    hdr = open(os.path.join(ROOT, "include", "ddpo_hip.h")).read()
+    end = hdr.index("} ddpo_gemm_desc;")
+    body = hdr[hdr.rindex("typedef struct", 0, end):end]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for stmt in body.split("{", 1)[1].split(";"):
+        stmt = stmt.strip()
+        if not stmt:
+            continue
+        decl = re.sub(r"^(const\s+)?(float|int|int32_t|int64_t|size_t|void)\s*\*?\s*", "", stmt)
+        names += [n.strip().lstrip("*") for n in decl.split(",")]
+    assert names == [f[0] for f in L.GemmDesc._fields_]
