@@ -11,6 +11,8 @@ Trajectories never leave HBM: one (T+1, B, C, h, w) buffer holds x_T .. x_0; `la
 `next_latents` = buf[1:] are returned as (B, T, ...) views of it (the reference copies them to host numpy,
 /root/reference/pipeline/policy_gradient.py:292-295).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -80,6 +82,8 @@ class StableDiffusionPipeline:
         unet_fwd = self.unet.forward_graphed if jit else self.unet
         # the text context is the same for all T steps: project it through the cross-attention to_k / to_v once
         cache_ctx = hasattr(self.unet, "precompute_context")
+        # both CFG halves see the same latents and timestep: the layers in front of the first cross-attention run once
+        dedupe = cache_ctx and os.environ.get("DDPO_CFG_DUP", "1") != "0"
         if cache_ctx:
             self.unet.precompute_context(context)
         try:
@@ -87,7 +91,7 @@ class StableDiffusionPipeline:
                 x = traj[s]
                 lat2[:B].copy_(x)                                   # jnp.concatenate([old_latents] * 2)
                 lat2[B:].copy_(x)
-                noise_pred = unet_fwd(lat2, ts_dev[s], context)
+                noise_pred = unet_fwd(lat2, ts_dev[s], context, cfg_dup=True) if dedupe else unet_fwd(lat2, ts_dev[s], context)
                 L.threefry_normal(step_keys[s], shape, out=z)
                 L.ddim_step_fwd(noise_pred[:B], noise_pred[B:], x, z, ts_dev[s, :B], guidance_scale, consts,
                                 x_next=traj[s + 1], logp=log_probs[s])

@@ -375,9 +375,12 @@ class UNet2DCondition:
                                G[name + ".norm.scale"], G[name + ".norm.bias"], dx_add=d_out)
 
     # -------------------------------------------------------------------------------- forward
-    def forward(self, sample, timesteps, context, tape=None):
+    def forward(self, sample, timesteps, context, tape=None, cfg_dup=False):
         """sample (B,C,H,W) fp32 NCHW; timesteps (B,) int32; context (B,L,D) fp32 -> (B,C_out,H,W).
-        With `tape` (a list) every layer records what `backward` needs."""
+        With `tape` (a list) every layer records what `backward` needs.
+        `cfg_dup`: the caller guarantees that the second half of `sample` / `timesteps` repeats the first (classifier-free
+        guidance feeds [x; x]): everything in front of the first cross-attention (conv_in, the first ResBlock) is then
+        computed on one half and its rows duplicated — bit-identical, because no kernel depends on batch composition."""
         P, cfg = self.params, self.cfg
         B, Cin, H, W = sample.shape
         boc = cfg.block_out_channels
@@ -398,15 +401,23 @@ class UNet2DCondition:
         temb = L.linear(s1, P["time_embedding.linear_2.kernel"], P["time_embedding.linear_2.bias"])
         temb_act = L.silu(temb)          # every ResBlock applies SiLU before its time_emb_proj
 
-        x = L.nchw_to_nhwc(sample.contiguous())
-        t, _, _ = L.conv2d(x, P["conv_in.kernel"], P["conv_in.bias"], B, H, W, Cin, boc[0], 3)
+        dup = bool(cfg_dup) and tape is None and B % 2 == 0 and cfg.cross_attn_down[0]
+        Bh = B // 2 if dup else B
+        twice = (lambda a: torch.cat([a, a])) if dup else (lambda a: a)
+        x = L.nchw_to_nhwc(sample[:Bh].contiguous())
+        t, _, _ = L.conv2d(x, P["conv_in.kernel"], P["conv_in.bias"], Bh, H, W, Cin, boc[0], 3)
         if tape is not None:
             tape.append(("head", dict(emb=emb, t1=t1, s1=s1, temb=temb, temb_act=temb_act, x=Act(x, B, H, W, Cin))))
-        h = Act(t, B, H, W, boc[0])
+        h_half = Act(t, Bh, H, W, boc[0])
+        h = Act(twice(t), B, H, W, boc[0])
         skips = [h]
         for i in range(nlev):
             for j in range(cfg.layers_per_block):
-                h = resnet_forward(P, f"down_blocks_{i}.resnets_{j}", h, temb_act, G, 1e-5, tape)
+                if dup and i == 0 and j == 0:      # still in front of the first cross-attention: half the batch, then duplicate
+                    r = resnet_forward(P, "down_blocks_0.resnets_0", h_half, temb_act[:Bh], G, 1e-5, None)
+                    h = Act(twice(r.t), B, r.H, r.W, r.C)
+                else:
+                    h = resnet_forward(P, f"down_blocks_{i}.resnets_{j}", h, temb_act, G, 1e-5, tape)
                 if cfg.cross_attn_down[i]:
                     h = self._transformer(f"down_blocks_{i}.attentions_{j}", h, ctx, Lc, cfg.num_heads[i], tape)
                 skips.append(h)
@@ -475,17 +486,17 @@ class UNet2DCondition:
     def release_context(self):
         self._ctx_kv_active = False
 
-    def forward_graphed(self, sample, timesteps, context):
+    def forward_graphed(self, sample, timesteps, context, cfg_dup=False):
         """Same as forward(), but the ~1000 kernel launches of one U-Net pass are captured once into a HIP graph (per
         input geometry) and replayed: the launch-bound host loop disappears from the sampling hot loop.  Inputs are copied
         into the graph's static buffers; the returned tensor is the graph's static output (valid until the next replay).
         Weights are read in place, so optimizer updates / re-packing are seen by later replays."""
-        key = (tuple(sample.shape), tuple(context.shape), L.DATAPATH, self._ctx_kv_active)
+        key = (tuple(sample.shape), tuple(context.shape), L.DATAPATH, self._ctx_kv_active, bool(cfg_dup))
         if not hasattr(self, "_graphs"):
             self._graphs = {}
         ent = self._graphs.get(key)
         if ent == "eager":
-            return self.forward(sample, timesteps, context)
+            return self.forward(sample, timesteps, context, cfg_dup=cfg_dup)
         if ent is None:
             s_in = sample.clone().contiguous()
             t_in = timesteps.to(torch.int32).clone().contiguous()
@@ -494,18 +505,18 @@ class UNet2DCondition:
             side.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(side):
                 for _ in range(2):                      # warm-up: first-call attribute setup, scratch allocation
-                    self.forward(s_in, t_in, c_in)
+                    self.forward(s_in, t_in, c_in, cfg_dup=cfg_dup)
             torch.cuda.current_stream(self.device).wait_stream(side)
             try:
                 graph = torch.cuda.CUDAGraph()
                 # thread_local: other host threads (RCCL watchdog, reward callbacks) may touch the device during capture
                 with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                    out = self.forward(s_in, t_in, c_in)
+                    out = self.forward(s_in, t_in, c_in, cfg_dup=cfg_dup)
             except Exception as exc:          # capture is an optimisation only: fall back to eager launches, loudly
                 print(f"[ ddpo_amd ] WARNING: HIP-graph capture of the U-Net failed ({type(exc).__name__}: {exc}); launching eagerly")
                 torch.cuda.synchronize(self.device)
                 self._graphs[key] = "eager"
-                return self.forward(sample, timesteps, context)
+                return self.forward(sample, timesteps, context, cfg_dup=cfg_dup)
             ent = (graph, s_in, t_in, c_in, out)
             self._graphs[key] = ent
         graph, s_in, t_in, c_in, out = ent
