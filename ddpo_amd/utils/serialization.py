@@ -101,10 +101,14 @@ def save_checkpoint(ckpt_dir, params, step, resume_state=None, flax_format=True)
     `save_checkpoint_multiprocess(..., unreplicate(state.params), step=epoch)` writes and its `flax:` load path reads."""
     from safetensors.torch import save_file
     os.makedirs(ckpt_dir, exist_ok=True)
+    formats = os.environ.get("DDPO_CKPT_FORMATS", "flax,safetensors").split(",")     # e.g. "flax" alone halves the disk use
     path = os.path.join(ckpt_dir, f"checkpoint_{step}.safetensors")
     host = {n: v.detach().cpu().contiguous() for n, v in params.views.items()}
-    save_file(host, path)
-    if flax_format:
+    if "safetensors" in formats:
+        save_file(host, path)
+    else:
+        path = os.path.join(ckpt_dir, f"checkpoint_{step}")
+    if flax_format and "flax" in formats:
         from .flax_msgpack import save_flax_checkpoint
         save_flax_checkpoint(ckpt_dir, {n: v.numpy() for n, v in host.items()}, step)
     if resume_state is not None:
