@@ -69,9 +69,14 @@ def load_unet(loadpath=None, epoch="latest", pretrained_model="duongna/stable-di
         unet.params.load_dict(load_flax_checkpoint(path))
     elif loadpath:
         ck = latest_checkpoint(loadpath) if epoch == "latest" else os.path.join(loadpath, f"checkpoint_{epoch}.safetensors")
-        if ck:
+        if ck and os.path.exists(ck):
             print(f"[ utils/serialization ] loading fine-tuned U-Net from {ck}")
             _load_safetensors_into(unet.params, ck)
+        else:                      # only the flax-format file was written (DDPO_CKPT_FORMATS=flax), or a reference run's directory
+            from .flax_msgpack import load_flax_checkpoint
+            fx = loadpath if epoch == "latest" else os.path.join(loadpath, f"checkpoint_{epoch}")
+            print(f"[ utils/serialization ] loading fine-tuned U-Net from flax checkpoint {fx}")
+            unet.params.load_dict(load_flax_checkpoint(fx))
     from .. import lib as L
     if L.DATAPATH != "fp32":          # bf16-split MFMA datapath: pre-split the contraction weights once
         unet.params.pack_bf16()
