@@ -44,7 +44,7 @@ def _ext_unpack(code, data):
     if code in (_EXT_NDARRAY, _EXT_NPSCALAR):
         shape, dtype_name, buf = msgpack.unpackb(data, raw=True)
         dtype_name = dtype_name.decode() if isinstance(dtype_name, bytes) else dtype_name
-        arr = np.frombuffer(buf, dtype=np.dtype(dtype_name)).reshape(shape)
+        arr = np.frombuffer(buf, dtype=np.dtype(dtype_name)).reshape(shape).copy()      # own, writable memory
         return arr[()] if code == _EXT_NPSCALAR else arr
     if code == _EXT_COMPLEX:
         re, im = msgpack.unpackb(data)

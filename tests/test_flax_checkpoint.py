@@ -50,3 +50,24 @@ def test_chunked_leaf_is_reassembled(monkeypatch):
     raw = msgpack.unpackb(data, ext_hook=FM._ext_unpack, raw=False, strict_map_key=False)
     assert raw["w"]["__msgpack_chunked_array__"] is True and len(raw["w"]["chunks"]) == 7
     assert np.array_equal(FM.from_bytes(data)["w"], arr)
+
+
+def test_save_checkpoint_formats_and_load_unet_paths(tmp_path, monkeypatch):
+    """save_checkpoint writes the reference's `checkpoint_<step>` (flax msgpack) by default next to the safetensors copy;
+    with DDPO_CKPT_FORMATS=flax only that file; load_unet restores from either (host-side logic only: device="cpu")."""
+    import torch
+    from ddpo_amd.models.unet import ParamStore
+    from ddpo_amd.utils.serialization import load_unet, save_checkpoint
+    monkeypatch.setenv("DDPO_MODEL_CONFIG", "tiny")
+    store = ParamStore(unet_param_shapes(UNetConfig.named("tiny")), "cpu")
+    g = torch.Generator().manual_seed(3)
+    store.flat.copy_(torch.randn(store.flat.shape, generator=g))
+    d1 = str(tmp_path / "both")
+    save_checkpoint(d1, store, 4)
+    assert sorted(os.listdir(d1)) == ["checkpoint_4", "checkpoint_4.safetensors"]
+    monkeypatch.setenv("DDPO_CKPT_FORMATS", "flax")
+    d2 = str(tmp_path / "flax_only")
+    assert save_checkpoint(d2, store, 9).endswith("checkpoint_9") and os.listdir(d2) == ["checkpoint_9"]
+    for loadpath in (d1, d2, "flax:" + d2, "flax:" + os.path.join(d2, "checkpoint_9")):
+        _, params = load_unet(loadpath, pretrained_model="none", device="cpu")
+        assert all(torch.equal(params["unet"][n], store[n]) for n in store.views), loadpath
