@@ -45,6 +45,8 @@ def parse():
                     help="sample (headline): images/sec of the sampling hot path; train: PPO sample-timesteps/sec of train_step "
                          "(U-Net fwd cond+uncond, log-prob, PPO-clip, backward, one AdamW update per step group)")
     ap.add_argument("--train-batch-size", type=int, default=2)
+    ap.add_argument("--train-fuse", type=int, default=int(os.environ.get("DDPO_TRAIN_FUSE", "1")),
+                    help="--mode train: micro-steps per U-Net forward/backward (train_steps_fused); 1 = one launch per micro-step")
     ap.add_argument("--no-graph", action="store_true", help="launch the U-Net kernels eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -89,7 +91,7 @@ def bench_train(args, world, rank, dev, dist, unet, sched, state, emb, neg):
     """Secondary metric: one "step" = `train_batch_size` sample-timesteps through train_step with train_cfg=True, every
     4th step applying the optimizer (grad all-reduce over ranks + fused AdamW), as at the reference defaults scaled down."""
     from ddpo_amd import lib as L
-    from ddpo_amd.training.policy_gradient import AccumulatingTrainState, AdamWConfig, train_step
+    from ddpo_amd.training.policy_gradient import AccumulatingTrainState, AdamWConfig, train_step, train_steps_fused
     if L.DATAPATH != "fp32":
         unet.params.pack_bf16(bwd=True)
     b = args.train_batch_size
@@ -104,10 +106,15 @@ def bench_train(args, world, rank, dev, dist, unet, sched, state, emb, neg):
     tstate = AccumulatingTrainState(unet, AdamWConfig())
     k = 0
 
-    def one():
+    fuse = max(1, args.train_fuse)
+
+    def one():              # one "step" = `fuse` micro-steps of b sample-timesteps; the optimizer steps after every 4th micro-step group
         nonlocal k
         k += 1
-        train_step(tstate, batch, st, sched, True, 5.0, 1.0, 1e-4, do_opt_update=(k % 4 == 0))
+        if fuse == 1:
+            train_step(tstate, batch, st, sched, True, 5.0, 1.0, 1e-4, do_opt_update=(k % 4 == 0))
+        else:
+            train_steps_fused(tstate, [batch] * fuse, st, sched, True, 5.0, 1.0, 1e-4, do_opt_update=(k % 4 == 0))
 
     def sync():
         if dist is not None:
@@ -125,13 +132,14 @@ def bench_train(args, world, rank, dev, dist, unet, sched, state, emb, neg):
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    value = world * b * args.steps / dt
+    value = world * b * fuse * args.steps / dt
     if rank == 0:
         tf = value * 6 * UNET_FWD_TFLOP["sd15"] if (args.model == "sd15" and args.resolution == 512) else None
         print(json.dumps({"metric": "PPO train sample-timesteps/sec (train_cfg, 512^2)", "value": value, "unit": "sample-timesteps/sec",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.datapath, "data": "synthetic",
-                          "config": {"workload": f"train_step, {args.model}, train_batch_size {b}/GPU, train_cfg, optimizer update every 4 steps",
+                          "config": {"workload": f"train_step, {args.model}, train_batch_size {b}/GPU, train_cfg, {fuse} micro-step(s) per U-Net "
+                                                 f"forward/backward, optimizer update every 4 steps",
                                      "parallelism": f"dp{world}"},
                           "end_to_end_tflops": tf}), flush=True)
     if dist is not None:

@@ -5,7 +5,7 @@
 #include "common.h"
 #include <math.h>
 
-extern "C" int ddpo_abi_version(void) { return 2; }
+extern "C" int ddpo_abi_version(void) { return 3; }
 extern "C" size_t ddpo_sizeof_gemm_desc(void) { return sizeof(ddpo_gemm_desc); }
 extern "C" size_t ddpo_sizeof_ddim_consts(void) { return sizeof(ddpo_ddim_consts); }
 
@@ -202,7 +202,7 @@ __global__ void __launch_bounds__(1024) ppo_fwd_bwd_kernel(const float* __restri
                                                           const float* __restrict__ adv_in, float g, float clip, int train_cfg,
                                                           ddpo_ddim_consts c, float* __restrict__ d_eps_c,
                                                           float* __restrict__ d_eps_u, float* __restrict__ per_sample,
-                                                          int B, int chw) {
+                                                          int group, int chw) {
   __shared__ float red[16];
   __shared__ float s_dl;
   const int b = blockIdx.x;
@@ -233,7 +233,7 @@ __global__ void __launch_bounds__(1024) ppo_fwd_bwd_kernel(const float* __restri
     const float unclipped = -A * ratio;
     const float clipped = -A * fminf(fmaxf(ratio, 1.0f - clip), 1.0f + clip);
     const bool use_unclipped = unclipped >= clipped;
-    s_dl = use_unclipped ? (-A * ratio / (float)B) : 0.0f;
+    s_dl = use_unclipped ? (-A * ratio / (float)group) : 0.0f;      // loss = mean over the micro-batch of `group` rows
     per_sample[b * 4 + 0] = lp;
     per_sample[b * 4 + 1] = ratio;
     per_sample[b * 4 + 2] = fmaxf(unclipped, clipped);
@@ -268,10 +268,12 @@ __global__ void __launch_bounds__(1024) ppo_fwd_bwd_kernel(const float* __restri
   }
 }
 
+// one block per micro-batch (`group` consecutive rows): info[blockIdx.x] = {approx_kl, clipfrac, loss} of that micro-batch
 __global__ void ppo_info_kernel(const float* __restrict__ per_sample, const float* __restrict__ old_logp,
-                                float* __restrict__ info, int B) {
+                                float* __restrict__ info, int group) {
+  const int b0 = blockIdx.x * group;
   float kl = 0.f, cf = 0.f, ls = 0.f;
-  for (int b = threadIdx.x; b < B; b += 64) {
+  for (int b = b0 + threadIdx.x; b < b0 + group; b += 64) {
     const float d = per_sample[b * 4] - old_logp[b];
     kl += d * d;
     cf += per_sample[b * 4 + 3];
@@ -279,10 +281,26 @@ __global__ void ppo_info_kernel(const float* __restrict__ per_sample, const floa
   }
   kl = wave_sum(kl); cf = wave_sum(cf); ls = wave_sum(ls);
   if (threadIdx.x == 0) {
-    info[0] = 0.5f * kl / (float)B;
-    info[1] = cf / (float)B;
-    info[2] = ls / (float)B;
+    info[blockIdx.x * 3 + 0] = 0.5f * kl / (float)group;
+    info[blockIdx.x * 3 + 1] = cf / (float)group;
+    info[blockIdx.x * 3 + 2] = ls / (float)group;
   }
+}
+
+extern "C" int ddpo_ddim_logprob_ppo_fwd_bwd_grouped(const float* eps_c, const float* eps_u, const float* x, const float* x_next,
+                                                     const int32_t* ts, const float* old_logp, const float* advantages,
+                                                     float guidance_scale, float clip_range, int train_cfg,
+                                                     const ddpo_ddim_consts* c, float* d_eps_c, float* d_eps_u, float* per_sample,
+                                                     float* info, int B, int group, int chw, void* stream) {
+  if (!eps_c || !x || !x_next || !ts || !old_logp || !advantages || !c || !d_eps_c || !per_sample || !info) return DDPO_EINVAL;
+  if (train_cfg && (!eps_u || !d_eps_u)) return DDPO_EINVAL;
+  if (B <= 0 || group <= 0 || B % group || chw <= 0 || (chw & 3)) return DDPO_EINVAL;
+  hipLaunchKernelGGL(ppo_fwd_bwd_kernel, dim3(B), dim3(1024), 0, as_stream(stream), eps_c, eps_u, x, x_next, ts, old_logp,
+                     advantages, guidance_scale, clip_range, train_cfg, *c, d_eps_c, d_eps_u, per_sample, group, chw);
+  DDPO_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ppo_info_kernel, dim3(B / group), dim3(64), 0, as_stream(stream), per_sample, old_logp, info, group);
+  DDPO_LAUNCH_CHECK();
+  return DDPO_OK;
 }
 
 extern "C" int ddpo_ddim_logprob_ppo_fwd_bwd(const float* eps_c, const float* eps_u, const float* x, const float* x_next,
@@ -290,15 +308,8 @@ extern "C" int ddpo_ddim_logprob_ppo_fwd_bwd(const float* eps_c, const float* ep
                                              float guidance_scale, float clip_range, int train_cfg,
                                              const ddpo_ddim_consts* c, float* d_eps_c, float* d_eps_u, float* per_sample,
                                              float* info, int B, int chw, void* stream) {
-  if (!eps_c || !x || !x_next || !ts || !old_logp || !advantages || !c || !d_eps_c || !per_sample || !info) return DDPO_EINVAL;
-  if (train_cfg && (!eps_u || !d_eps_u)) return DDPO_EINVAL;
-  if (B <= 0 || chw <= 0 || (chw & 3)) return DDPO_EINVAL;
-  hipLaunchKernelGGL(ppo_fwd_bwd_kernel, dim3(B), dim3(1024), 0, as_stream(stream), eps_c, eps_u, x, x_next, ts, old_logp,
-                     advantages, guidance_scale, clip_range, train_cfg, *c, d_eps_c, d_eps_u, per_sample, B, chw);
-  DDPO_LAUNCH_CHECK();
-  hipLaunchKernelGGL(ppo_info_kernel, dim3(1), dim3(64), 0, as_stream(stream), per_sample, old_logp, info, B);
-  DDPO_LAUNCH_CHECK();
-  return DDPO_OK;
+  return ddpo_ddim_logprob_ppo_fwd_bwd_grouped(eps_c, eps_u, x, x_next, ts, old_logp, advantages, guidance_scale, clip_range,
+                                               train_cfg, c, d_eps_c, d_eps_u, per_sample, info, B, B, chw, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

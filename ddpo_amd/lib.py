@@ -36,7 +36,7 @@ class GemmDesc(ctypes.Structure):
                 ("w_dgrad", c_int), ("ld_w", c_int), ("splits", c_int), ("accumulate", c_int), ("epilogue", c_int)]
 
 
-ABI_VERSION = 2          # must equal ddpo_abi_version() of the loaded library (include/ddpo_hip.h)
+ABI_VERSION = 3          # must equal ddpo_abi_version() of the loaded library (include/ddpo_hip.h)
 
 _SIGS = {
     "ddpo_abi_version": (c_int, []),
@@ -49,6 +49,9 @@ _SIGS = {
     "ddpo_ddim_logprob_ppo_fwd_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                               c_float, c_float, c_int, POINTER(DdimConsts), c_void_p, c_void_p,
                                               c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "ddpo_ddim_logprob_ppo_fwd_bwd_grouped": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                      c_float, c_float, c_int, POINTER(DdimConsts), c_void_p, c_void_p,
+                                                      c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ddpo_grad_sqnorm": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_void_p]),
     "ddpo_adamw_bf16mu_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_double, c_double,
                                        c_double, c_double, c_double, c_double, c_double, c_int, c_int, c_int, c_void_p]),
@@ -209,17 +212,30 @@ def ddim_step_fwd(eps_u, eps_c, x, z, ts, guidance_scale, consts, x_next=None, l
     return x_next, logp
 
 
-def ddim_logprob_ppo_fwd_bwd(eps_c, eps_u, x, x_next, ts, old_logp, advantages, guidance_scale, clip_range, train_cfg, consts):
+def ddim_logprob_ppo_fwd_bwd(eps_c, eps_u, x, x_next, ts, old_logp, advantages, guidance_scale, clip_range, train_cfg, consts,
+                             group=None):
+    """`group` (default: the whole batch) = rows per PPO micro-batch when several micro-batches are scored in one call:
+    rows [j*group, (j+1)*group) are micro-batch j, each with its own mean loss; info comes back as (B // group, 3)."""
     B = x.shape[0]
     chw = x.numel() // B
     d_c = torch.empty_like(eps_c)
     d_u = torch.empty_like(eps_c) if train_cfg else None
     per_sample = torch.empty(B, 4, dtype=torch.float32, device=x.device)
-    info = torch.empty(3, dtype=torch.float32, device=x.device)
-    _check(load().ddpo_ddim_logprob_ppo_fwd_bwd(_p(eps_c), _p(eps_u), _p(x), _p(x_next), _p(ts), _p(old_logp), _p(advantages),
-                                                float(guidance_scale), float(clip_range), int(bool(train_cfg)), byref(consts),
-                                                _p(d_c), _p(d_u), _p(per_sample), _p(info), B, chw, _stream()),
-           "ddpo_ddim_logprob_ppo_fwd_bwd")
+    if group is None:
+        info = torch.empty(3, dtype=torch.float32, device=x.device)
+        _check(load().ddpo_ddim_logprob_ppo_fwd_bwd(_p(eps_c), _p(eps_u), _p(x), _p(x_next), _p(ts), _p(old_logp), _p(advantages),
+                                                    float(guidance_scale), float(clip_range), int(bool(train_cfg)), byref(consts),
+                                                    _p(d_c), _p(d_u), _p(per_sample), _p(info), B, chw, _stream()),
+               "ddpo_ddim_logprob_ppo_fwd_bwd")
+    else:
+        if group <= 0 or B % group:
+            raise ValueError(f"batch of {B} rows is not a whole number of micro-batches of {group}")
+        info = torch.empty(B // group, 3, dtype=torch.float32, device=x.device)
+        _check(load().ddpo_ddim_logprob_ppo_fwd_bwd_grouped(_p(eps_c), _p(eps_u), _p(x), _p(x_next), _p(ts), _p(old_logp),
+                                                            _p(advantages), float(guidance_scale), float(clip_range),
+                                                            int(bool(train_cfg)), byref(consts), _p(d_c), _p(d_u), _p(per_sample),
+                                                            _p(info), B, int(group), chw, _stream()),
+               "ddpo_ddim_logprob_ppo_fwd_bwd_grouped")
     return d_c, d_u, per_sample, info
 
 

@@ -87,9 +87,10 @@ class AccumulatingTrainState:
         return self
 
 
-def _fwd_bwd(state, batch, noise_scheduler_state, noise_scheduler, train_cfg, guidance_scale, eta, clip_range):
+def _fwd_bwd(state, batch, noise_scheduler_state, noise_scheduler, train_cfg, guidance_scale, eta, clip_range, group=None):
     """U-Net forward (cond + uncond as one batch), scoring-mode log-prob + PPO-clip forward/backward, U-Net backward
-    (parameter gradients accumulate in place).  Pure device work: capturable into a HIP graph."""
+    (parameter gradients accumulate in place).  Pure device work: capturable into a HIP graph.
+    `group`: rows per PPO micro-batch when the batch holds several micro-batches (train_steps_fused); info is then (k, 3)."""
     unet = state.unet
     lat = batch["latents"]
     b = lat.shape[0]
@@ -105,7 +106,8 @@ def _fwd_bwd(state, batch, noise_scheduler_state, noise_scheduler, train_cfg, gu
         eps_u, eps_c = None, out
     consts = noise_scheduler.kernel_consts(noise_scheduler_state, eta)
     d_c, d_u, per_sample, info = L.ddim_logprob_ppo_fwd_bwd(eps_c, eps_u, lat, batch["next_latents"], ts, batch["log_probs"],
-                                                            batch["advantages"], guidance_scale, clip_range, train_cfg, consts)
+                                                            batch["advantages"], guidance_scale, clip_range, train_cfg, consts,
+                                                            group=group)
     d_out = torch.cat([d_u, d_c]) if train_cfg else d_c
     unet.backward(tape, d_out)
     return info, per_sample
@@ -114,15 +116,15 @@ def _fwd_bwd(state, batch, noise_scheduler_state, noise_scheduler, train_cfg, gu
 _KEYS = ("latents", "next_latents", "ts", "log_probs", "advantages", "prompt_embeds", "uncond_embeds")
 
 
-def _graphed_fwd_bwd(state, batch, sched_state, sched, train_cfg, guidance_scale, eta, clip_range):
+def _graphed_fwd_bwd(state, batch, sched_state, sched, train_cfg, guidance_scale, eta, clip_range, group=None):
     """Replay of _fwd_bwd as a captured HIP graph (one per batch geometry / hyper-parameter set): ~3000 kernel launches per
     micro-step become one graph launch.  Gradients still accumulate into the same flat buffer."""
     key = (tuple(batch["latents"].shape), tuple(batch["prompt_embeds"].shape), bool(train_cfg), float(guidance_scale), float(eta),
-           float(clip_range), sched_state.num_inference_steps, L.DATAPATH)
+           float(clip_range), sched_state.num_inference_steps, L.DATAPATH, group)
     cache = state.__dict__.setdefault("_graphs", {})
     ent = cache.get(key)
     if ent == "eager":
-        return _fwd_bwd(state, batch, sched_state, sched, train_cfg, guidance_scale, eta, clip_range)
+        return _fwd_bwd(state, batch, sched_state, sched, train_cfg, guidance_scale, eta, clip_range, group)
     if ent is None:
         static = {k: batch[k].clone() for k in _KEYS}
         gflat = state.grad_acc.flat
@@ -130,18 +132,18 @@ def _graphed_fwd_bwd(state, batch, sched_state, sched, train_cfg, guidance_scale
         side = torch.cuda.Stream(gflat.device)
         side.wait_stream(torch.cuda.current_stream(gflat.device))
         with torch.cuda.stream(side):
-            _fwd_bwd(state, static, sched_state, sched, train_cfg, guidance_scale, eta, clip_range)      # warm-up (allocations, attrs)
+            _fwd_bwd(state, static, sched_state, sched, train_cfg, guidance_scale, eta, clip_range, group)      # warm-up (allocations, attrs)
         torch.cuda.current_stream(gflat.device).wait_stream(side)
         try:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                info, per_sample = _fwd_bwd(state, static, sched_state, sched, train_cfg, guidance_scale, eta, clip_range)
+                info, per_sample = _fwd_bwd(state, static, sched_state, sched, train_cfg, guidance_scale, eta, clip_range, group)
         except Exception as exc:                # capture is an optimisation only: fall back to eager launches, loudly
             print(f"[ ddpo_amd ] WARNING: HIP-graph capture of train_step failed ({type(exc).__name__}: {exc}); launching eagerly")
             torch.cuda.synchronize(gflat.device)
             gflat.copy_(saved)
             cache[key] = "eager"
-            return _fwd_bwd(state, batch, sched_state, sched, train_cfg, guidance_scale, eta, clip_range)
+            return _fwd_bwd(state, batch, sched_state, sched, train_cfg, guidance_scale, eta, clip_range, group)
         gflat.copy_(saved)                      # warm-up passes must not leak into the accumulated gradients
         ent = (graph, static, info, per_sample)
         cache[key] = ent
@@ -170,3 +172,39 @@ def train_step(state: AccumulatingTrainState, batch, noise_scheduler_state, nois
         info, per_sample = _fwd_bwd(state, dbatch, noise_scheduler_state, noise_scheduler, train_cfg, guidance_scale, eta, clip_range)
     state = state.apply_gradients(do_update=do_opt_update)
     return state, {"approx_kl": info[0], "clipfrac": info[1], "loss": info[2], "log_prob": per_sample[:, 0]}
+
+
+def train_steps_fused(state: AccumulatingTrainState, batches, noise_scheduler_state, noise_scheduler, train_cfg, guidance_scale,
+                      eta, clip_range, do_opt_update, jit=True):
+    """k consecutive PPO micro-steps that see the SAME parameters — no optimizer update between them, i.e. any run of
+    `train_step(..., do_opt_update=False)` calls optionally closed by one with `do_opt_update=True` — executed as ONE U-Net
+    forward/backward over the concatenated rows.  The reference runs them one by one and sums their gradients in
+    `AccumulatingTrainState.apply_gradients` (/root/reference/ddpo/training/policy_gradient.py:32-48; the entrypoint loop
+    /root/reference/pipeline/policy_gradient.py:407-441 updates only at the last timestep of a mini-batch); summing inside
+    one launch is the same arithmetic up to fp32 summation order, with 4x..16x more rows per GEMM (a micro-batch of 2
+    samples x CFG is a U-Net batch of 4 — too small to fill 256 CUs).  Each micro-batch keeps its own mean loss
+    (`ddpo_ddim_logprob_ppo_fwd_bwd_grouped`) and its own info row, and n_acc advances by k.
+
+    batches: list of k dicts as for `train_step`, all with the same shapes.  `do_opt_update` applies after the LAST one.
+    Returns (state, [info_0, ..., info_{k-1}])."""
+    assert isinstance(state, AccumulatingTrainState)
+    k = len(batches)
+    assert k >= 1
+    if k == 1:
+        state, info = train_step(state, batches[0], noise_scheduler_state, noise_scheduler, train_cfg, guidance_scale, eta,
+                                 clip_range, do_opt_update, jit=jit)
+        return state, [info]
+    b = batches[0]["latents"].shape[0]
+    for bt in batches:
+        assert bt["latents"].shape == batches[0]["latents"].shape and bt["ts"].shape[0] == b
+    if not train_cfg:
+        batches = [dict(bt, uncond_embeds=bt.get("uncond_embeds", bt["prompt_embeds"])) for bt in batches]
+    dbatch = {key: torch.cat([bt[key] for bt in batches]).contiguous() for key in _KEYS}
+    dbatch["ts"] = dbatch["ts"].to(torch.int32)
+    fn = _graphed_fwd_bwd if jit else _fwd_bwd
+    info, per_sample = fn(state, dbatch, noise_scheduler_state, noise_scheduler, train_cfg, guidance_scale, eta, clip_range, b)
+    for _ in range(k - 1):
+        state = state.apply_gradients(do_update=False)
+    state = state.apply_gradients(do_update=do_opt_update)
+    return state, [{"approx_kl": info[j, 0], "clipfrac": info[j, 1], "loss": info[j, 2], "log_prob": per_sample[j * b:(j + 1) * b, 0]}
+                   for j in range(k)]

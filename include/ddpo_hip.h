@@ -67,6 +67,16 @@ int ddpo_ddim_logprob_ppo_fwd_bwd(const float* eps_c, const float* eps_u, const 
                                   int train_cfg, const ddpo_ddim_consts* c, float* d_eps_c,
                                   float* d_eps_u, float* per_sample, float* info, int B, int chw,
                                   void* stream);
+/* The same over k micro-batches at once: rows [j*group, (j+1)*group) form micro-batch j (B % group == 0).  Each
+ * micro-batch's loss is the mean over ITS `group` rows, so the gradients written are exactly those k separate calls
+ * would write (AccumulatingTrainState sums them anyway, ddpo/training/policy_gradient.py:32-48), and
+ * info is (B/group, 3): one {approx_kl, clipfrac, loss} per micro-batch.  group == B is the call above. */
+int ddpo_ddim_logprob_ppo_fwd_bwd_grouped(const float* eps_c, const float* eps_u, const float* x,
+                                          const float* x_next, const int32_t* ts, const float* old_logp,
+                                          const float* advantages, float guidance_scale, float clip_range,
+                                          int train_cfg, const ddpo_ddim_consts* c, float* d_eps_c,
+                                          float* d_eps_u, float* per_sample, float* info, int B, int group,
+                                          int chw, void* stream);
 
 /* ---- optimizer: optax.chain(clip_by_global_norm, adamw(mu_dtype=bf16)) + AccumulatingTrainState ----
  * pipeline/policy_gradient.py:130-150; ddpo/training/policy_gradient.py:32-48. */

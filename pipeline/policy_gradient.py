@@ -32,7 +32,7 @@ import torch
 
 from ddpo_amd import training, utils
 from ddpo_amd.training import distributed as D
-from ddpo_amd.training.policy_gradient import AccumulatingTrainState, AdamWConfig, train_step
+from ddpo_amd.training.policy_gradient import AccumulatingTrainState, AdamWConfig, train_step, train_steps_fused
 from ddpo_amd.utils import prng
 from ddpo_amd.utils.serialization import load_unet, save_checkpoint
 from ddpo_amd.utils.stat_tracking import PerPromptStatTracker
@@ -192,10 +192,25 @@ def main(argv=None):
             n_mini = total_batch_size // (n_devices * args.train_batch_size)
             all_infos = []
             do_opt_update = False
+            train_fuse = int(os.environ.get("DDPO_TRAIN_FUSE", "1"))
             t_train = time.time()
             for i in range(n_mini):
                 sl = slice(i * args.train_batch_size, (i + 1) * args.train_batch_size)
-                for j in range(num_train_ts):
+                for j0 in (range(0, num_train_ts, train_fuse) if train_fuse > 1 else ()):
+                    # DDPO_TRAIN_FUSE=k: k consecutive timesteps of this mini-batch (same parameters: the optimizer only
+                    # steps at the last timestep) as one U-Net forward/backward over k micro-batches (train_steps_fused)
+                    js = range(j0, min(j0 + train_fuse, num_train_ts))
+                    batches = [{"prompt_embeds": devs["embeds"][sl], "uncond_embeds": train_uncond_prompt_embeds,
+                                "advantages": devs["advantages"][sl], "latents": devs["latents"][sl, j],
+                                "next_latents": devs["next_latents"][sl, j], "log_probs": devs["log_probs"][sl, j],
+                                "ts": devs["ts"][sl, j]} for j in js]
+                    do_opt_update = (js[-1] == num_train_ts - 1) and ((i + 1) % args.train_accumulation_steps == 0)
+                    if do_opt_update:
+                        print(f"opt update at {i}, {js[-1]}")
+                    state, infos_k = train_steps_fused(state, batches, noise_scheduler_state, pipeline.scheduler, args.train_cfg,
+                                                       args.guidance_scale, args.eta, args.ppo_clip_range, do_opt_update)
+                    all_infos += [torch.stack([info["approx_kl"], info["clipfrac"], info["loss"]]) for info in infos_k]
+                for j in (range(num_train_ts) if train_fuse <= 1 else ()):
                     batch = {"prompt_embeds": devs["embeds"][sl], "uncond_embeds": train_uncond_prompt_embeds,
                              "advantages": devs["advantages"][sl], "latents": devs["latents"][sl, j],
                              "next_latents": devs["next_latents"][sl, j], "log_probs": devs["log_probs"][sl, j],
