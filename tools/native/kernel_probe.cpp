@@ -1,0 +1,338 @@
+// kernel_probe — torch-free micro-benchmark + spot-check of libddpo_hip.so through its C ABI (include/ddpo_hip.h).
+//
+// Starts in milliseconds (no Python, no `import torch`), so a whole A/B sweep of the GEMM tuning knobs fits into a minute
+// of GPU-box time.  Inputs are a counter-based hash evaluated identically on host and device: nothing is copied to the
+// device, and the host reference (double precision) is evaluated only on a few hundred sampled outputs per case.
+//
+//   kernel_probe gemm [batch=16] [iters=10]     bf16x3 implicit-GEMM conv / dense shapes of one SD-1.5 U-Net forward
+//   kernel_probe attn [batch=16] [iters=10]     bf16x3 / fp32 flash-attention shapes of the same forward
+//   kernel_probe ppo                            scoring-mode log-prob + PPO-clip + grouped micro-batches vs a host loop
+//
+// Build: make -C tools/native   (hipcc --offload-arch=gfx950; links ../../ddpo_amd/libddpo_hip.so)
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "../../include/ddpo_hip.h"
+
+#define HIP_OK(x)                                                                      \
+  do {                                                                                 \
+    hipError_t e_ = (x);                                                               \
+    if (e_ != hipSuccess) {                                                            \
+      fprintf(stderr, "%s:%d %s -> %s\n", __FILE__, __LINE__, #x, hipGetErrorString(e_)); \
+      exit(2);                                                                         \
+    }                                                                                  \
+  } while (0)
+#define ABI_OK(x)                                                       \
+  do {                                                                  \
+    int r_ = (x);                                                       \
+    if (r_ != DDPO_OK) {                                                \
+      fprintf(stderr, "%s:%d %s -> %d\n", __FILE__, __LINE__, #x, r_);  \
+      exit(3);                                                          \
+    }                                                                   \
+  } while (0)
+
+// value i of stream `seed`, uniform in [-1, 1): the same bits on host and device
+__host__ __device__ inline float hval(uint32_t seed, uint64_t i) {
+  uint32_t x = (uint32_t)i * 2654435761u ^ seed ^ ((uint32_t)(i >> 32) * 0x9E3779B9u);
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return (float)(int32_t)x * (1.0f / 2147483648.0f);
+}
+__global__ void fill_kernel(float* p, int64_t n, uint32_t seed, float scale) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    p[i] = scale * hval(seed, (uint64_t)i);
+}
+
+struct Dev {                      // device buffer filled with scale * hval(seed, i)
+  float* p = nullptr;
+  int64_t n = 0;
+  uint32_t seed = 0;
+  float scale = 1.f;
+  Dev() {}
+  Dev(int64_t n_, uint32_t seed_, float scale_) : n(n_), seed(seed_), scale(scale_) {
+    HIP_OK(hipMalloc(&p, std::max<int64_t>(n, 4) * sizeof(float)));
+    hipLaunchKernelGGL(fill_kernel, dim3(1024), dim3(256), 0, 0, p, n, seed, scale);
+    HIP_OK(hipGetLastError());
+  }
+  float at(int64_t i) const { return scale * hval(seed, (uint64_t)i); }
+  void release() { if (p) HIP_OK(hipFree(p)); p = nullptr; }
+};
+static void* dalloc(size_t bytes) { void* p; HIP_OK(hipMalloc(&p, std::max<size_t>(bytes, 16))); HIP_OK(hipMemset(p, 0, std::max<size_t>(bytes, 16))); return p; }
+
+static float time_ms(int iters, const std::function<void()>& fn) {
+  hipEvent_t e0, e1;
+  HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+  for (int i = 0; i < 2; ++i) fn();
+  HIP_OK(hipDeviceSynchronize());
+  HIP_OK(hipEventRecord(e0, 0));
+  for (int i = 0; i < iters; ++i) fn();
+  HIP_OK(hipEventRecord(e1, 0));
+  HIP_OK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+  HIP_OK(hipEventDestroy(e0)); HIP_OK(hipEventDestroy(e1));
+  return ms / iters;
+}
+
+// ------------------------------------------------------------------------------------------------ gemm / conv
+struct ConvCase { int H, Cin, Cout, ks, stride, ups; };      // square H x H source, pad = ks / 2; ks == 0: dense with M = B*H rows
+static int g_fail = 0;
+
+static void run_gemm(int B, int H, int Cin, int Cout, int ks, int stride, int ups, int iters, void* ws, size_t ws_bytes) {
+  const bool conv = ks > 0;
+  const int pad = ks / 2;
+  const int VH = ups ? 2 * H : H;
+  const int OH = conv ? (VH + 2 * pad - ks) / stride + 1 : 0;
+  const int64_t M = conv ? (int64_t)B * OH * OH : (int64_t)B * H;
+  const int K = conv ? ks * ks * Cin : Cin, N = Cout, Kp = (K + 7) / 8 * 8;
+  Dev src(conv ? (int64_t)B * H * H * Cin : M * K, 11, 1.0f), w((int64_t)K * N, 12, 1.0f / sqrtf((float)K)), bias(N, 13, 0.5f);
+  float* out = (float*)dalloc((size_t)M * N * 4);
+  uint16_t* hi = (uint16_t*)dalloc((size_t)N * Kp * 2);
+  uint16_t* lo = (uint16_t*)dalloc((size_t)N * Kp * 2);
+  ABI_OK(ddpo_pack_weights_bf16(w.p, K, N, Kp, hi, lo, nullptr, nullptr, nullptr));
+  ddpo_gemm_desc d;
+  memset(&d, 0, sizeof(d));
+  d.src = src.p; d.ld_src = conv ? Cin : K;
+  d.bias = bias.p; d.out = out; d.ld_out = N; d.alpha = 1.f;
+  d.M = (int)M; d.N = N; d.K = K;
+  if (conv) { d.ksize = ks; d.stride = stride; d.pad = pad; d.upsample = ups; d.B = B; d.H = H; d.W = H; d.Cin = Cin; d.OH = OH; d.OW = OH; }
+  const float ms = time_ms(iters, [&] { ABI_OK(ddpo_gemm_conv_fwd_bf16(&d, hi, lo, Kp, 3, ws, ws_bytes, nullptr)); });
+  // spot check: 96 sampled outputs against a double-precision host evaluation of the same hashed inputs
+  const int NS = 96;
+  std::vector<float> got(NS);
+  std::vector<int64_t> ms_(NS);
+  std::vector<int> ns_(NS);
+  double max_err = 0.0, ref_sq = 0.0;
+  for (int s = 0; s < NS; ++s) {
+    const int64_t m = (s < 8) ? (s < 4 ? s : M - 1 - (s - 4)) : (int64_t)((hval(77, s) * 0.5 + 0.5) * (double)M) % M;   // corners + random
+    const int n = (s < 8) ? (s & 1 ? N - 1 - s : s) % N : (int)((hval(78, s) * 0.5 + 0.5) * N) % N;
+    ms_[s] = m; ns_[s] = n;
+    HIP_OK(hipMemcpy(&got[s], out + m * N + n, 4, hipMemcpyDeviceToHost));
+    double acc = 0.0;
+    if (conv) {
+      const int64_t b = m / ((int64_t)OH * OH), rem = m % ((int64_t)OH * OH);
+      const int oy = (int)(rem / OH), ox = (int)(rem % OH);
+      for (int ky = 0; ky < ks; ++ky)
+        for (int kx = 0; kx < ks; ++kx) {
+          const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
+          if (iy < 0 || iy >= VH || ix < 0 || ix >= VH) continue;
+          const int sy = ups ? iy >> 1 : iy, sx = ups ? ix >> 1 : ix;
+          const int64_t pix = (b * H + sy) * H + sx;
+          for (int ci = 0; ci < Cin; ++ci)
+            acc += (double)src.at(pix * Cin + ci) * (double)w.at((int64_t)((ky * ks + kx) * Cin + ci) * N + n);
+        }
+    } else {
+      for (int k = 0; k < K; ++k) acc += (double)src.at(m * K + k) * (double)w.at((int64_t)k * N + n);
+    }
+    acc += bias.at(n);
+    max_err = std::max(max_err, fabs(acc - (double)got[s]));
+    ref_sq += acc * acc;
+  }
+  const double rms = sqrt(ref_sq / NS), rel = max_err / (rms + 1e-30);
+  const double tf = 2.0 * (double)M * N * K / (ms * 1e-3) / 1e12;
+  const bool ok = rel < 2e-4;                       // bf16x3: ~1e-5 of the output scale
+  if (!ok) ++g_fail;
+  if (conv) printf("conv %dx%d s%d up%d %5d->%5d @%3d^2 B%-3d: %8.3f ms %7.1f TF  err/rms %.1e %s\n", ks, ks, stride, ups, Cin, Cout, H, B, ms, tf, rel, ok ? "" : "FAIL");
+  else printf("gemm M=%7lld K=%5d N=%5d       : %8.3f ms %7.1f TF  err/rms %.1e %s\n", (long long)M, K, N, ms, tf, rel, ok ? "" : "FAIL");
+  fflush(stdout);
+  src.release(); w.release(); bias.release();
+  HIP_OK(hipFree(out)); HIP_OK(hipFree(hi)); HIP_OK(hipFree(lo));
+}
+
+static int probe_gemm(int B, int iters) {
+  const size_t ws_bytes = 64u << 20;
+  void* ws = dalloc(ws_bytes);
+  // the convolutions of an SD-1.5 U-Net forward at 64x64 latents (ResBlock convs per level, skip-concat inputs, down / up samplers)
+  const ConvCase convs[] = {{64, 320, 320, 3, 1, 0},  {32, 640, 640, 3, 1, 0},   {16, 1280, 1280, 3, 1, 0}, {8, 1280, 1280, 3, 1, 0},
+                            {64, 960, 320, 3, 1, 0},  {64, 640, 320, 3, 1, 0},   {32, 1920, 640, 3, 1, 0},  {32, 1280, 640, 3, 1, 0},
+                            {32, 960, 640, 3, 1, 0},  {16, 2560, 1280, 3, 1, 0}, {16, 1920, 1280, 3, 1, 0}, {8, 2560, 1280, 3, 1, 0},
+                            {32, 320, 640, 3, 1, 0},  {16, 640, 1280, 3, 1, 0},  {32, 640, 640, 3, 1, 1},   {16, 1280, 1280, 3, 1, 1},
+                            {8, 1280, 1280, 3, 1, 1}, {64, 320, 320, 3, 2, 0},   {32, 640, 640, 3, 2, 0},   {16, 1280, 1280, 3, 2, 0},
+                            {64, 320, 320, 1, 1, 0},  {64, 960, 320, 1, 1, 0},   {32, 1920, 640, 1, 1, 0},  {16, 2560, 1280, 1, 1, 0}};
+  for (const ConvCase& c : convs) run_gemm(B, c.H, c.Cin, c.Cout, c.ks, c.stride, c.ups, iters, ws, ws_bytes);
+  // dense layers: rows per sample x K x N (q/k/v/out projections, FF1 (unfused shape), FF2, cross-attention k/v, time embedding)
+  const int dense[][3] = {{4096, 320, 320}, {4096, 320, 2560}, {4096, 1280, 320}, {1024, 640, 640}, {1024, 640, 5120}, {1024, 2560, 640},
+                          {256, 1280, 1280}, {256, 1280, 10240}, {256, 5120, 1280}, {64, 1280, 1280}, {64, 1280, 10240}, {64, 5120, 1280},
+                          {77, 768, 320}, {77, 768, 640}, {77, 768, 1280}, {1, 1280, 1280}};
+  for (auto& g : dense) run_gemm(B, g[0], g[1], g[2], 0, 1, 0, iters, ws, ws_bytes);
+  HIP_OK(hipFree(ws));
+  return g_fail;
+}
+
+// ------------------------------------------------------------------------------------------------ attention
+static void run_attn(int B, int heads, int Nq, int Nk, int d, int iters) {
+  const int C = heads * d;
+  Dev q((int64_t)B * Nq * C, 21, 1.0f), k((int64_t)B * Nk * C, 22, 1.0f), v((int64_t)B * Nk * C, 23, 1.0f);
+  float* o = (float*)dalloc((size_t)B * Nq * C * 4);
+  const float scale = 1.0f / sqrtf((float)d);
+  const bool bf = (d == 8 || d == 16 || d == 40 || d == 64 || d == 80);
+  const size_t wsb = bf ? ddpo_attention_fwd_bf16x3_ws_bytes(B, heads, Nk, d) : 0;
+  void* ws = wsb ? dalloc(wsb) : nullptr;
+  const float ms = time_ms(iters, [&] {
+    if (bf) ABI_OK(ddpo_attention_fwd_bf16x3(q.p, C, k.p, C, v.p, C, o, C, nullptr, B, heads, Nq, Nk, d, scale, ws, wsb, nullptr));
+    else ABI_OK(ddpo_attention_fwd(q.p, C, k.p, C, v.p, C, o, C, nullptr, B, heads, Nq, Nk, d, scale, nullptr));
+  });
+  double max_err = 0.0;
+  std::vector<double> p(Nk);
+  std::vector<float> got(d);
+  for (int s = 0; s < 12; ++s) {
+    const int b = s % B, h = (s * 3) % heads, iq = (s < 2) ? (s ? Nq - 1 : 0) : (int)((hval(31, s) * 0.5 + 0.5) * Nq) % Nq;
+    const int64_t qo = ((int64_t)b * Nq + iq) * C + h * d;
+    double mx = -1e300;
+    for (int j = 0; j < Nk; ++j) {
+      double sc = 0.0;
+      const int64_t ko = ((int64_t)b * Nk + j) * C + h * d;
+      for (int e = 0; e < d; ++e) sc += (double)q.at(qo + e) * (double)k.at(ko + e);
+      p[j] = sc * scale;
+      mx = std::max(mx, p[j]);
+    }
+    double den = 0.0;
+    for (int j = 0; j < Nk; ++j) { p[j] = exp(p[j] - mx); den += p[j]; }
+    HIP_OK(hipMemcpy(got.data(), o + qo, d * 4, hipMemcpyDeviceToHost));
+    for (int e = 0; e < d; ++e) {
+      double acc = 0.0;
+      for (int j = 0; j < Nk; ++j) acc += p[j] * (double)v.at(((int64_t)b * Nk + j) * C + h * d + e);
+      max_err = std::max(max_err, fabs(acc / den - (double)got[e]));
+    }
+  }
+  const bool ok = max_err < 2e-4;
+  if (!ok) ++g_fail;
+  printf("attn B%-3d h%d Nq=%5d Nk=%5d d=%3d %s: %8.3f ms %7.1f TF  max abs err %.1e %s\n", B, heads, Nq, Nk, d, bf ? "bf16x3" : "fp32  ", ms,
+         4.0 * B * heads * (double)Nq * Nk * d / (ms * 1e-3) / 1e12, max_err, ok ? "" : "FAIL");
+  fflush(stdout);
+  q.release(); k.release(); v.release();
+  HIP_OK(hipFree(o));
+  if (ws) HIP_OK(hipFree(ws));
+}
+
+static int probe_attn(int B, int iters) {
+  const int cases[][3] = {{4096, 4096, 40}, {4096, 77, 40}, {1024, 1024, 80}, {1024, 77, 80}, {256, 256, 160}, {256, 77, 160}, {64, 64, 160}, {64, 77, 160}};
+  for (auto& c : cases) run_attn(B, 8, c[0], c[1], c[2], iters);
+  return g_fail;
+}
+
+// ------------------------------------------------------------------------------------------------ log-prob + PPO (grouped)
+static int probe_ppo() {
+  const int k = 4, b = 2, B = k * b, chw = 4 * 64 * 64;
+  // scaled-linear SD schedule, float32 sequential cumprod (scheduling_ddim_flax.py create_state)
+  std::vector<float> ac(1000);
+  {
+    const float s0 = sqrtf(0.00085f), s1 = sqrtf(0.012f);
+    float c = 1.f;
+    for (int i = 0; i < 1000; ++i) {
+      const float sb = s0 + (s1 - s0) * (float)i / 999.0f;
+      c *= 1.0f - sb * sb;
+      ac[i] = c;
+    }
+  }
+  float* d_ac = (float*)dalloc(4000);
+  HIP_OK(hipMemcpy(d_ac, ac.data(), 4000, hipMemcpyHostToDevice));
+  ddpo_ddim_consts c;
+  c.alphas_cumprod = d_ac; c.num_train_timesteps = 1000; c.step_ratio = 20; c.final_alpha_cumprod = ac[0]; c.eta = 1.0f; c.pred_type = DDPO_PRED_EPSILON;
+  const int ts_h[B] = {981, 481, 1, 21, 701, 241, 961, 501};
+  const float adv_h[B] = {1.5f, -0.7f, 12.0f, -20.0f, 0.3f, -0.2f, 0.9f, -1.4f};
+  Dev ec((int64_t)B * chw, 41, 1.f), eu((int64_t)B * chw, 42, 1.f), x((int64_t)B * chw, 43, 1.f), z((int64_t)B * chw, 44, 1.f);
+  int32_t* d_ts = (int32_t*)dalloc(B * 4);
+  float *d_adv = (float*)dalloc(B * 4), *d_old = (float*)dalloc(B * 4), *xn = (float*)dalloc((size_t)B * chw * 4), *lp0 = (float*)dalloc(B * 4);
+  HIP_OK(hipMemcpy(d_ts, ts_h, B * 4, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(d_adv, adv_h, B * 4, hipMemcpyHostToDevice));
+  const float g = 5.0f, clip = 1e-4f;
+  ABI_OK(ddpo_ddim_step_fwd(eu.p, ec.p, x.p, z.p, d_ts, g, &c, xn, lp0, B, chw, nullptr));
+  std::vector<float> lp0_h(B), old_h(B);
+  HIP_OK(hipMemcpy(lp0_h.data(), lp0, B * 4, hipMemcpyDeviceToHost));
+  const float doff[B] = {0.f, 5e-5f, -3e-4f, 3e-4f, 3e-4f, -3e-4f, 2e-5f, -8e-5f};
+  for (int i = 0; i < B; ++i) old_h[i] = lp0_h[i] + doff[i];
+  HIP_OK(hipMemcpy(d_old, old_h.data(), B * 4, hipMemcpyHostToDevice));
+  float *dc = (float*)dalloc((size_t)B * chw * 4), *du = (float*)dalloc((size_t)B * chw * 4), *per = (float*)dalloc(B * 16), *info = (float*)dalloc(k * 12);
+  ABI_OK(ddpo_ddim_logprob_ppo_fwd_bwd_grouped(ec.p, eu.p, x.p, xn, d_ts, d_old, d_adv, g, clip, 1, &c, dc, du, per, info, B, b, chw, nullptr));
+  std::vector<float> dc_h((size_t)B * chw), du_h((size_t)B * chw), per_h(B * 4), info_h(k * 3), xn_h((size_t)B * chw);
+  HIP_OK(hipMemcpy(dc_h.data(), dc, dc_h.size() * 4, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(du_h.data(), du, du_h.size() * 4, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(per_h.data(), per, B * 16, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(info_h.data(), info, k * 12, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(xn_h.data(), xn, xn_h.size() * 4, hipMemcpyDeviceToHost));
+  // (1) the grouped call equals k ungrouped calls on the row slices, bit for bit
+  int fails = 0;
+  for (int j = 0; j < k; ++j) {
+    const int64_t off = (int64_t)j * b * chw;
+    float *dc2 = (float*)dalloc((size_t)b * chw * 4), *du2 = (float*)dalloc((size_t)b * chw * 4), *per2 = (float*)dalloc(b * 16), *info2 = (float*)dalloc(12);
+    ABI_OK(ddpo_ddim_logprob_ppo_fwd_bwd(ec.p + off, eu.p + off, x.p + off, xn + off, d_ts + j * b, d_old + j * b, d_adv + j * b, g, clip, 1, &c,
+                                         dc2, du2, per2, info2, b, chw, nullptr));
+    std::vector<float> a((size_t)b * chw), bb((size_t)b * chw), p2(b * 4), i2(3);
+    HIP_OK(hipMemcpy(a.data(), dc2, a.size() * 4, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(bb.data(), du2, bb.size() * 4, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(p2.data(), per2, b * 16, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(i2.data(), info2, 12, hipMemcpyDeviceToHost));
+    if (memcmp(a.data(), dc_h.data() + off, a.size() * 4) || memcmp(bb.data(), du_h.data() + off, bb.size() * 4) ||
+        memcmp(p2.data(), per_h.data() + j * b * 4, b * 16) || memcmp(i2.data(), info_h.data() + j * 3, 12)) {
+      printf("ppo grouped: micro-batch %d differs from the ungrouped call FAIL\n", j);
+      ++fails;
+    }
+    HIP_OK(hipFree(dc2)); HIP_OK(hipFree(du2)); HIP_OK(hipFree(per2)); HIP_OK(hipFree(info2));
+  }
+  // (2) host evaluation in double of ddpo/training/policy_gradient.py:95-134 per micro-batch
+  double worst_lp = 0, worst_g = 0, worst_info = 0;
+  for (int j = 0; j < k; ++j) {
+    double kl = 0, cf = 0, ls = 0;
+    for (int r = 0; r < b; ++r) {
+      const int i = j * b + r, t = ts_h[i], p = t - 20;
+      const double a_t = ac[t], a_p = p >= 0 ? ac[p] : ac[0];
+      const double var = (1 - a_p) / (1 - a_t) * (1 - a_t / a_p), sd = sqrt(var), sdc = std::max(sd, 1e-6);
+      const double dirc = sqrt(1 - a_p - sd * sd), dmu = dirc - sqrt(a_p) * sqrt(1 - a_t) / sqrt(a_t);
+      double acc = 0;
+      std::vector<double> diff(chw);
+      for (int e = 0; e < chw; ++e) {
+        const int64_t ix = (int64_t)i * chw + e;
+        const double ee = eu.at(ix) + (double)g * ((double)ec.at(ix) - (double)eu.at(ix));
+        const double mu = sqrt(a_p) * ((double)x.at(ix) - sqrt(1 - a_t) * ee) / sqrt(a_t) + dirc * ee;
+        diff[e] = (double)xn_h[ix] - mu;
+        acc += -(diff[e] * diff[e]) / (2 * sdc * sdc) - log(sdc) - 0.9189385332046727;
+      }
+      const double lp = acc / chw, A = std::min(std::max((double)adv_h[i], -10.0), 10.0), ratio = exp(lp - (double)old_h[i]);
+      const double un = -A * ratio, cl = -A * std::min(std::max(ratio, 1.0 - clip), 1.0 + clip);
+      const double dl = (un >= cl) ? -A * ratio / b : 0.0;
+      worst_lp = std::max(worst_lp, fabs(lp - per_h[i * 4]));
+      kl += (lp - old_h[i]) * (lp - old_h[i]); cf += fabs(ratio - 1.0) > clip ? 1 : 0; ls += std::max(un, cl);
+      double gmax = 1e-30, emax = 0;
+      for (int e = 0; e < chw; ++e) {
+        const double de = dl * diff[e] / (sdc * sdc * chw) * dmu;
+        gmax = std::max(gmax, fabs(g * de));
+        emax = std::max(emax, std::max(fabs(g * de - dc_h[(int64_t)i * chw + e]), fabs((1 - g) * de - du_h[(int64_t)i * chw + e])));
+      }
+      // the clip decision sits on |ratio - 1| ~ 1e-4: rows whose fp32 / fp64 log-probs land on opposite sides are skipped
+      if (fabs(fabs(ratio - 1.0) - clip) > 2e-5) worst_g = std::max(worst_g, emax / gmax);
+    }
+    worst_info = std::max(worst_info, fabs(ls / b - info_h[j * 3 + 2]));
+    (void)kl; (void)cf;
+  }
+  const bool ok = fails == 0 && worst_lp < 1e-4 && worst_g < 5e-3 && worst_info < 1e-3;
+  printf("ppo grouped (k=%d micro-batches of %d): log-prob abs err %.1e, grad rel err %.1e, loss abs err %.1e %s\n", k, b, worst_lp, worst_g, worst_info,
+         ok ? "OK" : "FAIL");
+  return ok ? 0 : 1;
+}
+
+int main(int argc, char** argv) {
+  const std::string mode = argc > 1 ? argv[1] : "gemm";
+  const int B = argc > 2 ? atoi(argv[2]) : 16, iters = argc > 3 ? atoi(argv[3]) : 10;
+  hipDeviceProp_t prop;
+  HIP_OK(hipGetDeviceProperties(&prop, 0));
+  printf("# %s (%s, %d CUs), libddpo_hip ABI v%d, mode %s, batch %d, DDPO_GEMM_WIDE=%s DDPO_GEMM_BIG_MIN=%s\n", prop.name, prop.gcnArchName,
+         prop.multiProcessorCount, ddpo_abi_version(), mode.c_str(), B, getenv("DDPO_GEMM_WIDE") ? getenv("DDPO_GEMM_WIDE") : "-",
+         getenv("DDPO_GEMM_BIG_MIN") ? getenv("DDPO_GEMM_BIG_MIN") : "-");
+  int rc;
+  if (mode == "gemm") rc = probe_gemm(B, iters);
+  else if (mode == "attn") rc = probe_attn(B, iters);
+  else if (mode == "ppo") rc = probe_ppo();
+  else { fprintf(stderr, "usage: kernel_probe gemm|attn|ppo [batch] [iters]\n"); return 64; }
+  HIP_OK(hipDeviceSynchronize());
+  printf("# %s: %s\n", mode.c_str(), rc ? "FAILURES" : "all spot checks passed");
+  return rc ? 1 : 0;
+}
