@@ -45,8 +45,9 @@ def parse():
                     help="sample (headline): images/sec of the sampling hot path; train: PPO sample-timesteps/sec of train_step "
                          "(U-Net fwd cond+uncond, log-prob, PPO-clip, backward, one AdamW update per step group)")
     ap.add_argument("--train-batch-size", type=int, default=2)
-    ap.add_argument("--train-fuse", type=int, default=int(os.environ.get("DDPO_TRAIN_FUSE", "1")),
-                    help="--mode train: micro-steps per U-Net forward/backward (train_steps_fused); 1 = one launch per micro-step")
+    ap.add_argument("--train-fuse", type=int, default=int(os.environ.get("DDPO_TRAIN_FUSE", "10")),
+                    help="--mode train: micro-steps per U-Net forward/backward (train_steps_fused, the entrypoint's default is 10); "
+                         "1 = one launch per micro-step")
     ap.add_argument("--no-graph", action="store_true", help="launch the U-Net kernels eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")

@@ -19,6 +19,15 @@ import torch
 from .. import lib as L
 
 ADV_CLIP_MAX = 10.0
+# PPO micro-steps per U-Net forward/backward in the entrypoint's training loop (train_steps_fused).  10 divides the default
+# 50 timesteps and turns the U-Net batch of 4 (2 samples x CFG) into 40 rows-of-latents: 28 -> 42 sample-timesteps/s on one
+# MI355X (profiles/r01_train_fuse.md).  DDPO_TRAIN_FUSE=1 restores one launch per micro-step.
+DEFAULT_TRAIN_FUSE = 10
+
+
+def train_fuse_default():
+    import os
+    return max(1, int(os.environ.get("DDPO_TRAIN_FUSE", str(DEFAULT_TRAIN_FUSE))))
 
 
 class AdamWConfig:

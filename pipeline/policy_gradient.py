@@ -32,7 +32,8 @@ import torch
 
 from ddpo_amd import training, utils
 from ddpo_amd.training import distributed as D
-from ddpo_amd.training.policy_gradient import AccumulatingTrainState, AdamWConfig, train_step, train_steps_fused
+from ddpo_amd.training.policy_gradient import (AccumulatingTrainState, AdamWConfig, train_fuse_default, train_step,
+                                               train_steps_fused)
 from ddpo_amd.utils import prng
 from ddpo_amd.utils.serialization import load_unet, save_checkpoint
 from ddpo_amd.utils.stat_tracking import PerPromptStatTracker
@@ -192,12 +193,12 @@ def main(argv=None):
             n_mini = total_batch_size // (n_devices * args.train_batch_size)
             all_infos = []
             do_opt_update = False
-            train_fuse = int(os.environ.get("DDPO_TRAIN_FUSE", "1"))
+            train_fuse = train_fuse_default()
             t_train = time.time()
             for i in range(n_mini):
                 sl = slice(i * args.train_batch_size, (i + 1) * args.train_batch_size)
                 for j0 in (range(0, num_train_ts, train_fuse) if train_fuse > 1 else ()):
-                    # DDPO_TRAIN_FUSE=k: k consecutive timesteps of this mini-batch (same parameters: the optimizer only
+                    # DDPO_TRAIN_FUSE=k (default 10): k consecutive timesteps of this mini-batch (same parameters: the optimizer only
                     # steps at the last timestep) as one U-Net forward/backward over k micro-batches (train_steps_fused)
                     js = range(j0, min(j0 + train_fuse, num_train_ts))
                     batches = [{"prompt_embeds": devs["embeds"][sl], "uncond_embeds": train_uncond_prompt_embeds,

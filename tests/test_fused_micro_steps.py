@@ -6,11 +6,8 @@ The CPU test pins the identity the fused path relies on with the ORACLE (sum of 
 the grouped loss over the concatenated rows); the GPU tests hold the grouped kernel and `train_steps_fused` to k separate
 `train_step` calls.
 
-The GPU tests need DDPO_EXPERIMENTAL=1: the fused path was written after this round's GPU budget was spent and is off by
-default (DDPO_TRAIN_FUSE=1) until it has been run on hardware (tools/validate_fused.sh).
+The entrypoint fuses DDPO_TRAIN_FUSE (default 10) timesteps of a mini-batch per launch.
 """
-import os
-
 import numpy as np
 import pytest
 import torch
@@ -18,8 +15,6 @@ import torch
 from oracle import ppo as OPPO
 from oracle.ddim import DDIMOracle
 
-EXPERIMENTAL = os.environ.get("DDPO_EXPERIMENTAL") == "1"
-needs_experimental = pytest.mark.skipif(not EXPERIMENTAL, reason="fused micro-steps not yet validated on hardware: set DDPO_EXPERIMENTAL=1")
 
 
 def _case(k, b, seed=0, pred="epsilon"):
@@ -31,7 +26,8 @@ def _case(k, b, seed=0, pred="epsilon"):
     ts = rng.choice(np.asarray(ost.timesteps), size=B).astype(np.int32)
     guided = (eu + np.float32(5.0) * (ec - eu)).astype(np.float32)
     xn, lp0 = dd.step(ost, guided, ts, x, noise=z, eta=1.0)
-    old = (lp0 + rng.uniform(-3e-4, 3e-4, size=B).astype(np.float32)).astype(np.float32)
+    # old log-probs well inside (3e-5) or well outside (3e-4) the 1e-4 clip range: no fp32-vs-fp64 flips of the clip decision
+    old = (lp0 + rng.choice(np.asarray([3e-5, -3e-5, 3e-4, -3e-4], dtype=np.float32), size=B)).astype(np.float32)
     adv = (rng.standard_normal(B) * 2).astype(np.float32)
     adv[0] = 14.0                                                   # exercises ADV_CLIP_MAX
     return dd, ost, ec, eu, x, xn, ts, old, adv
@@ -72,7 +68,6 @@ def test_oracle_grouped_loss_is_sum_of_micro_batch_losses(k, b):
 
 
 @pytest.mark.gpu
-@needs_experimental
 @pytest.mark.parametrize("pred", ["epsilon", "v_prediction"])
 @pytest.mark.parametrize("k,b,train_cfg", [(4, 2, True), (5, 1, True), (3, 4, False), (1, 6, True)])
 def test_grouped_ppo_kernel_matches_separate_micro_batches(pred, k, b, train_cfg):
@@ -81,7 +76,7 @@ def test_grouped_ppo_kernel_matches_separate_micro_batches(pred, k, b, train_cfg
     dd, ost, ec, eu, x, xn, ts, old, adv = _case(k, b, seed=3, pred=pred)
     if not train_cfg:                                               # next_latents must come from the unguided prediction then
         xn, lp0 = dd.step(ost, ec, ts, x, noise=np.random.default_rng(9).standard_normal(x.shape, dtype=np.float32), eta=1.0)
-        old = (lp0 + np.float32(1e-4)).astype(np.float32)
+        old = (lp0 + np.tile(np.asarray([3e-5, -3e-4, 3e-4, -3e-5], dtype=np.float32), x.shape[0])[:x.shape[0]]).astype(np.float32)
     s = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", set_alpha_to_one=False, steps_offset=1,
                       prediction_type=pred)
     st = s.set_timesteps(s.create_state(device="cuda"), 50)
@@ -108,7 +103,6 @@ def test_grouped_ppo_kernel_matches_separate_micro_batches(pred, k, b, train_cfg
 
 
 @pytest.mark.gpu
-@needs_experimental
 @pytest.mark.parametrize("datapath", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("jit", [False, True])
 def test_train_steps_fused_matches_separate_train_steps(datapath, jit):
@@ -162,8 +156,13 @@ def test_train_steps_fused_matches_separate_train_steps(datapath, jit):
         if closing_update:
             assert float(gb.abs().max()) == 0.0 and float(ga.abs().max()) == 0.0
             assert float(sb.last_grad_norm) == pytest.approx(float(sa.last_grad_norm), rel=1e-4)
+            # Adam's first step is ~lr * sign(g) whatever |g| is, so entries whose gradient is round-off noise move by
+            # +-lr at random: compare the applied update only where the accumulated gradient is well resolved
             upd = max(float((unet_a.params[n].cpu() - op[n]).abs().max()) for n in op)       # size of the applied update
-            assert float((unet_a.params.flat - unet_b.params.flat).abs().max()) <= 2e-2 * upd + 1e-9
+            diff = (unet_a.params.flat - unet_b.params.flat).abs()
+            assert int(resolved.sum()) > 1000
+            assert float(diff[resolved].max()) <= 2e-2 * upd + 1e-9
         else:
             gn = float(ga.double().norm())
+            resolved = ga.abs() > 1e-3 * ga.abs().max()           # used by the closing-update pass below (same batches)
             assert float((ga - gb).double().norm()) <= 2e-5 * gn, (float((ga - gb).double().norm()), gn)
