@@ -11,6 +11,7 @@
 // ds_read_b128 / ds_write of a 16-lane group touches 16 distinct 16-byte slots (conflict-free).
 #include "common.h"
 #include <cstdlib>
+#include <type_traits>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -338,7 +339,14 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
 // MFMA instead of 341 (128x128) / 512 (128x64) and makes N = 320 / 640 / 1280 tile counts multiples of the 256 CUs.
 // DEEP: global loads run two k-tiles ahead of the MFMAs (two register stages) instead of one.  Measured on the 8-wave tile:
 // one-ahead frees 26 VGPRs (no spills) but is 4-18 % slower than two-ahead with its 14 spilled dwords, so DEEP stays on.
-template <int BM, int BN, int NPASS, int ABL = 0, int WM = 2, int WN = 2, bool DEEP = true>     // ABL: timing ablations (tools/ablate_gemm.py; wrong results)
+//
+// APL ("A planes"): the activation operand arrives ALREADY split into bf16 hi / lo planes ([rows][ld] bf16, k contiguous;
+// d.src = hi plane, d.w = lo plane, d.ld_src = row stride in ELEMENTS) written by the producing kernel (GroupNorm / LayerNorm
+// apply, ddpo_split_planes_bf16).  Both operands then go global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds): no staging
+// VGPRs, no v_cvt / v_sub split, no ds_write.  A wave instruction fills 16 rows x 64 B lane-linearly, so the XOR swizzle of
+// swz_off() is applied to the SOURCE chunk each lane fetches.  Same tiles, same k order, same three MFMA passes as the
+// register-staged path: results are bit-identical to it.
+template <int BM, int BN, int NPASS, int ABL = 0, int WM = 2, int WN = 2, bool DEEP = true, bool APL = false>     // ABL: timing ablations (tools/ablate_gemm.py; wrong results)
 __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const ddpo_gemm_desc d, const uint16_t* __restrict__ w_hi,
                                                                        const uint16_t* __restrict__ w_lo, int ldw, int tiles_m,
                                                                        int tiles_n, int nblk, int kt_per_split,
@@ -378,118 +386,6 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
   const bool zins = d.upsample == 2;
   const int cin = conv ? d.Cin : d.K;            // reduction channels per tap (dense: one "tap" spanning K)
   const int ntaps = conv ? d.ksize * d.ksize : 1;
-
-  const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(d.src);
-  const __amdgpu_buffer_rsrc_t rs_wh = make_rsrc(w_hi);
-  const __amdgpu_buffer_rsrc_t rs_wl = make_rsrc(NPASS == 3 ? w_lo : w_hi);
-
-  // ---- A rows of this thread: (t>>3) + 32*i, float4 index kq inside the 32-wide k-tile
-  const int kq = t & 7;
-  int aiy0[AROWS], aix0[AROWS], apix[AROWS];    // top-left input coordinate and batch pixel base; invalid rows get iy0 << 0
-  uint32_t avoff[AROWS];                        // byte offset of the CURRENT tap's pixel (+ kq*16), or BUF_OOB
-#pragma unroll
-  for (int i = 0; i < AROWS; ++i) {
-    const int m = m0 + (t >> 3) + AR * i;
-    const bool valid = m < d.M;
-    if (conv) {
-      const int ohw = d.OH * d.OW;
-      const int mm = valid ? m : 0;
-      const int b = mm / ohw, rem = mm - b * ohw;
-      const int oy = rem / d.OW, ox = rem - oy * d.OW;
-      aiy0[i] = valid ? oy * d.stride - d.pad : -(1 << 24);
-      aix0[i] = ox * d.stride - d.pad;
-      apix[i] = b * d.H * d.W;
-      avoff[i] = BUF_OOB;
-    } else {
-      aiy0[i] = aix0[i] = apix[i] = 0;
-      avoff[i] = valid ? (uint32_t)m * (uint32_t)d.ld_src * 4u + kq * 16u : BUF_OOB;
-    }
-  }
-  auto set_tap = [&](int tap) {                 // conv only; wave-uniform tap
-    const int ky = d.ksize == 3 ? (tap * 11) >> 5 : 0;
-    const int kx = d.ksize == 3 ? tap - ky * 3 : 0;
-#pragma unroll
-    for (int i = 0; i < AROWS; ++i) {
-      const int iy = aiy0[i] + ky, ix = aix0[i] + kx;
-      const bool ok = (unsigned)iy < (unsigned)VH && (unsigned)ix < (unsigned)VW && !(zins && ((iy | ix) & 1));
-      const int sy = d.upsample ? (iy >> 1) : iy, sx = d.upsample ? (ix >> 1) : ix;
-      const uint32_t off = (uint32_t)(apix[i] + sy * d.W + sx) * (uint32_t)d.ld_src * 4u + kq * 16u;
-      avoff[i] = ok ? off : BUF_OOB;
-    }
-  };
-
-  // ---- W rows of this thread: (t>>2) + 64*i, 16-byte chunk bc of the k-tile
-  const int bc = t & 3;
-  uint32_t bvoff[BCH];
-#pragma unroll
-  for (int i = 0; i < BCH; ++i) {
-    const int br = (t >> 2) + BR * i;
-    const int n = n0 + br;
-    const uint32_t row_bytes = d.w_dgrad ? (uint32_t)d.Cin * 2u : (uint32_t)ldw * 2u;
-    bvoff[i] = (n < d.N && (BFULL || br < BN)) ? (uint32_t)n * row_bytes + bc * 16u : BUF_OOB;
-  }
-
-  const int nk_total = d.K / BK;
-  const int kt0 = blockIdx.y * kt_per_split;
-  const int nk = min(kt_per_split, nk_total - kt0);
-  // wave-uniform running position of the NEXT k-tile to load: tap index and channel base inside the tap
-  int tap = (kt0 * BK) / cin, cib = kt0 * BK - tap * cin;
-  if (conv) set_tap(tap);
-
-  struct Stage { float4 a[AROWS]; uint4 bh[BCH], bl[BCH]; };
-  Stage s0, s1;
-
-  // Loads are unconditional (a branch around them would make the compiler's s_waitcnt placement conservative and
-  // collapse the prefetch distance): requests past this split's last k-tile re-fetch the last tile and are never consumed.
-  auto load_tile = [&](int ktr, Stage& sg) {
-    const int so_a = cib * 4;
-    const int so_w = d.w_dgrad ? ((ntaps - 1 - tap) * d.N * d.Cin + cib) * 2 : (kt0 + min(ktr, nk - 1)) * (BK * 2);
-#pragma unroll
-    for (int i = 0; i < AROWS; ++i) {
-      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_a, avoff[i], so_a, 0);
-      sg.a[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-    }
-#pragma unroll
-    for (int i = 0; i < BCH; ++i) {
-      const u32x4 h = __builtin_amdgcn_raw_buffer_load_b128(rs_wh, bvoff[i], so_w, 0);
-      sg.bh[i] = make_uint4(h.x, h.y, h.z, h.w);
-      if (NPASS == 3) {
-        const u32x4 l = __builtin_amdgcn_raw_buffer_load_b128(rs_wl, bvoff[i], so_w, 0);
-        sg.bl[i] = make_uint4(l.x, l.y, l.z, l.w);
-      }
-    }
-    if (ktr < nk - 1) {                         // uniform; no memory operations inside
-      cib += BK;
-      if (cib >= cin) {                         // next k-tile starts a new tap
-        cib = 0; ++tap;
-        if (conv) set_tap(tap);
-      }
-    }
-  };
-
-  int a_st[AROWS], b_st[BCH];
-#pragma unroll
-  for (int i = 0; i < AROWS; ++i) a_st[i] = swz_off((t >> 3) + AR * i, kq >> 1) + (kq & 1) * 8;
-#pragma unroll
-  for (int i = 0; i < BCH; ++i) b_st[i] = swz_off((t >> 2) + BR * i, bc);
-
-  auto store_tile = [&](int buf, const Stage& sg) {
-    char* st = smem + buf * STAGE;
-#pragma unroll
-    for (int i = 0; i < AROWS; ++i) {
-      uint2 hi, lo;
-      split4(sg.a[i], hi, lo);
-      *reinterpret_cast<uint2*>(st + a_st[i]) = hi;
-      if (NPASS == 3) *reinterpret_cast<uint2*>(st + A_BYTES + a_st[i]) = lo;
-    }
-    char* sb = st + NPL * A_BYTES;
-#pragma unroll
-    for (int i = 0; i < BCH; ++i) {
-      if (!BFULL && (t >> 2) + BR * i >= BN) continue;
-      *reinterpret_cast<uint4*>(sb + b_st[i]) = sg.bh[i];
-      if (NPASS == 3) *reinterpret_cast<uint4*>(sb + B_BYTES + b_st[i]) = sg.bl[i];
-    }
-  };
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -541,58 +437,279 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
       }
     }
   };
-  Frag f0, f1;
-  constexpr int TT = TM * TN, TH = TT / 2;          // all blocks / the part issued in front of the barrier
 
-  // prologue: tile 0 -> LDS[0]; tile 1 in flight in s0.  The loop consumes k-tiles in pairs; an odd last tile is
-  // computed after it (it already sits in LDS[0] with its ks=0 fragments in f0).
-  if (ABL & 32) {
+  if constexpr (APL) {
+    // ---------------- LDS-DMA path: A planes + W planes straight into the swizzled LDS image ----------------
+    static_assert(NPASS == 3, "the plane-fed path is the bf16x3 datapath");
+    constexpr int NW = WM * WN, PAIRS = NW / 2;          // even waves move hi planes, odd waves lo planes
+    constexpr int GA = BM / 16, GB = BN / 16;            // 16-row groups = 1 KiB LDS-DMA pieces per plane
+    static_assert(NW % 2 == 0 && GA % PAIRS == 0 && GB % PAIRS == 0, "pieces must divide evenly over the wave pairs");
+    constexpr int NA = GA / PAIRS, NB = GB / PAIRS;
+    const int wv = __builtin_amdgcn_readfirstlane(wid);
+    const int plane = wv & 1, pr = wv >> 1;
+    const int lr = lane >> 2;                            // row inside the 16-row piece
+    const uint32_t lc16 = (uint32_t)((lane & 3) ^ ((lane >> 4) & 3)) * 16u;     // source chunk whose lane-linear slot equals swz_off()
+    const uint64_t a_ptr = reinterpret_cast<uint64_t>(plane ? reinterpret_cast<const void*>(d.w) : reinterpret_cast<const void*>(d.src));
+    const uint64_t w_ptr = reinterpret_cast<uint64_t>(plane ? w_lo : w_hi);
+    const u32x4 rs_a = {(uint32_t)a_ptr, (uint32_t)(a_ptr >> 32) & 0xFFFFu, 0x7FFFFFFFu, 0x00020000u};
+    const u32x4 rs_w = {(uint32_t)w_ptr, (uint32_t)(w_ptr >> 32) & 0xFFFFu, 0x7FFFFFFFu, 0x00020000u};
+    const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
+    const uint32_t lds_a = lds0 + plane * A_BYTES + pr * 1024;                       // + stage * STAGE + i * PAIRS * 1024
+    const uint32_t lds_w = lds0 + NPL * A_BYTES + plane * B_BYTES + pr * 1024;
+
+    int aiy0[NA], aix0[NA], apix[NA];
+    uint32_t avoff[NA], bvoff[NB];
 #pragma unroll
-    for (int i = 0; i < AROWS; ++i) s0.a[i] = make_float4(1.f, 1.f, 1.f, 1.f);
+    for (int i = 0; i < NA; ++i) {
+      const int m = m0 + 16 * (pr + PAIRS * i) + lr;
+      const bool valid = m < d.M;
+      if (conv) {
+        const int ohw = d.OH * d.OW;
+        const int mm = valid ? m : 0;
+        const int b = mm / ohw, rem = mm - b * ohw;
+        const int oy = rem / d.OW, ox = rem - oy * d.OW;
+        aiy0[i] = valid ? oy * d.stride - d.pad : -(1 << 24);
+        aix0[i] = ox * d.stride - d.pad;
+        apix[i] = b * d.H * d.W;
+        avoff[i] = BUF_OOB;
+      } else {
+        aiy0[i] = aix0[i] = apix[i] = 0;
+        avoff[i] = valid ? (uint32_t)m * (uint32_t)d.ld_src * 2u + lc16 : BUF_OOB;
+      }
+    }
+    auto set_tap = [&](int tap) {
+      const int ky = d.ksize == 3 ? (tap * 11) >> 5 : 0;
+      const int kx = d.ksize == 3 ? tap - ky * 3 : 0;
 #pragma unroll
-    for (int i = 0; i < BCH; ++i) s0.bh[i] = s0.bl[i] = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
-    store_tile(0, s0);
-  } else {
-    load_tile(0, s0);
-    store_tile(0, s0);
-    if (DEEP) load_tile(1, s0);
-  }
-  __syncthreads();
-  ldfrag(0, 0, f0);
-  if (ABL & 8) ldfrag(0, 1, f1);
-  if (ABL & 1) s1 = s0;
-  const int nk2 = nk & ~1;
+      for (int i = 0; i < NA; ++i) {
+        const int iy = aiy0[i] + ky, ix = aix0[i] + kx;
+        const bool ok = (unsigned)iy < (unsigned)VH && (unsigned)ix < (unsigned)VW && !(zins && ((iy | ix) & 1));
+        const int sy = d.upsample ? (iy >> 1) : iy, sx = d.upsample ? (ix >> 1) : ix;
+        const uint32_t off = (uint32_t)(apix[i] + sy * d.W + sx) * (uint32_t)d.ld_src * 2u + lc16;
+        avoff[i] = ok ? off : BUF_OOB;
+      }
+    };
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int n = n0 + 16 * (pr + PAIRS * i) + lr;
+      bvoff[i] = n < d.N ? (uint32_t)n * (uint32_t)ldw * 2u + lc16 : BUF_OOB;
+    }
+    const int nk_total = d.K / BK;
+    const int kt0 = blockIdx.y * kt_per_split;
+    const int nk = min(kt_per_split, nk_total - kt0);
+    int tap = (kt0 * BK) / cin, cib = kt0 * BK - tap * cin;        // position of the NEXT k-tile to request
+    if (conv) set_tap(tap);
+    int kt_next = kt0;
+
+    // one k-tile = NA + NB LDS-DMA pieces per wave (issued back to back; nothing of it touches a VGPR besides the offsets)
+    auto fill = [&](int stage) {
+      const uint32_t so_a = (uint32_t)cib * 2u, so_w = (uint32_t)kt_next * (BK * 2);
+      const uint32_t la = lds_a + stage * STAGE, lw = lds_w + stage * STAGE;
+#pragma unroll
+      for (int i = 0; i < NA; ++i)
+        asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                     :: "s"(la + i * (PAIRS * 1024)), "v"(avoff[i]), "s"(rs_a), "s"(so_a) : "memory");
+#pragma unroll
+      for (int i = 0; i < NB; ++i)
+        asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                     :: "s"(lw + i * (PAIRS * 1024)), "v"(bvoff[i]), "s"(rs_w), "s"(so_w) : "memory");
+      ++kt_next;
+      cib += BK;
+      if (cib >= cin) {
+        cib = 0; ++tap;
+        if (conv && tap < ntaps) set_tap(tap);
+      }
+    };
+    // Two LDS stages.  Per k-tile: wait for my pieces of tile kt, barrier (everybody's pieces landed AND everybody has finished
+    // reading the other stage), request tile kt + 1 into the other stage, then run the MFMAs of tile kt under that request.
+    auto step = [&](int kt, auto cur_c) {
+      constexpr int cur = decltype(cur_c)::value;
+      // vmcnt(0): my LDS-DMA pieces of tile kt are in LDS.  lgkmcnt(0): my fragment reads of the OTHER stage (tile kt - 1) have
+      // returned, so no wave can start overwriting that stage (below, after the barrier) while a read of it is in flight.
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (kt + 1 < nk) fill(cur ^ 1);
+      Frag g0, g1;
+      ldfrag(cur, 0, g0);
+      ldfrag(cur, 1, g1);
+      mma(g0, 0, TM * TN);
+      mma(g1, 0, TM * TN);
+    };
+    fill(0);
+    int kt = 0;
 #pragma unroll 1
-  for (int kt = 0; kt < nk2; kt += 2) {
-    // even step: MFMAs on LDS[0]; DEEP: s0 holds tile kt+1 and tile kt+2 starts loading into s1; else tile kt+1 loads into s0 now
-    if (!(ABL & 1)) { if (DEEP) load_tile(kt + 2, s1); else load_tile(kt + 1, s0); }
-    if (!(ABL & 8)) ldfrag(0, 1, f1);
-    mma(f0, 0, TT);
-    if (!(ABL & 2)) store_tile(1, s0);
-    __builtin_amdgcn_sched_barrier(0);          // LDS stores retire under the next MFMAs, not in front of the barrier
-    mma(f1, 0, TH);
-    __builtin_amdgcn_sched_barrier(0);
-    if (!(ABL & 4)) __syncthreads();
-    if (!(ABL & 8)) ldfrag(1, 0, f0);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(f1, TH, TT);
-    // odd step: MFMAs on LDS[1]
-    if (!(ABL & 1)) { if (DEEP) load_tile(kt + 3, s0); else load_tile(kt + 2, s0); }
-    if (!(ABL & 8)) ldfrag(1, 1, f1);
-    mma(f0, 0, TT);
-    if (!(ABL & 2)) { if (DEEP) store_tile(0, s1); else store_tile(0, s0); }
-    __builtin_amdgcn_sched_barrier(0);
-    mma(f1, 0, TH);
-    __builtin_amdgcn_sched_barrier(0);
-    if (!(ABL & 4)) __syncthreads();
-    if (!(ABL & 8)) ldfrag(0, 0, f0);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(f1, TH, TT);
-  }
-  if (nk & 1) {
-    ldfrag(0, 1, f1);
-    mma(f0, 0, TT);
-    mma(f1, 0, TT);
+    for (; kt + 1 < nk; kt += 2) {
+      step(kt, std::integral_constant<int, 0>{});
+      step(kt + 1, std::integral_constant<int, 1>{});
+    }
+    if (kt < nk) step(kt, std::integral_constant<int, 0>{});
+  } else {
+    const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(d.src);
+    const __amdgpu_buffer_rsrc_t rs_wh = make_rsrc(w_hi);
+    const __amdgpu_buffer_rsrc_t rs_wl = make_rsrc(NPASS == 3 ? w_lo : w_hi);
+
+    // ---- A rows of this thread: (t>>3) + 32*i, float4 index kq inside the 32-wide k-tile
+    const int kq = t & 7;
+    int aiy0[AROWS], aix0[AROWS], apix[AROWS];    // top-left input coordinate and batch pixel base; invalid rows get iy0 << 0
+    uint32_t avoff[AROWS];                        // byte offset of the CURRENT tap's pixel (+ kq*16), or BUF_OOB
+#pragma unroll
+    for (int i = 0; i < AROWS; ++i) {
+      const int m = m0 + (t >> 3) + AR * i;
+      const bool valid = m < d.M;
+      if (conv) {
+        const int ohw = d.OH * d.OW;
+        const int mm = valid ? m : 0;
+        const int b = mm / ohw, rem = mm - b * ohw;
+        const int oy = rem / d.OW, ox = rem - oy * d.OW;
+        aiy0[i] = valid ? oy * d.stride - d.pad : -(1 << 24);
+        aix0[i] = ox * d.stride - d.pad;
+        apix[i] = b * d.H * d.W;
+        avoff[i] = BUF_OOB;
+      } else {
+        aiy0[i] = aix0[i] = apix[i] = 0;
+        avoff[i] = valid ? (uint32_t)m * (uint32_t)d.ld_src * 4u + kq * 16u : BUF_OOB;
+      }
+    }
+    auto set_tap = [&](int tap) {                 // conv only; wave-uniform tap
+      const int ky = d.ksize == 3 ? (tap * 11) >> 5 : 0;
+      const int kx = d.ksize == 3 ? tap - ky * 3 : 0;
+#pragma unroll
+      for (int i = 0; i < AROWS; ++i) {
+        const int iy = aiy0[i] + ky, ix = aix0[i] + kx;
+        const bool ok = (unsigned)iy < (unsigned)VH && (unsigned)ix < (unsigned)VW && !(zins && ((iy | ix) & 1));
+        const int sy = d.upsample ? (iy >> 1) : iy, sx = d.upsample ? (ix >> 1) : ix;
+        const uint32_t off = (uint32_t)(apix[i] + sy * d.W + sx) * (uint32_t)d.ld_src * 4u + kq * 16u;
+        avoff[i] = ok ? off : BUF_OOB;
+      }
+    };
+
+    // ---- W rows of this thread: (t>>2) + 64*i, 16-byte chunk bc of the k-tile
+    const int bc = t & 3;
+    uint32_t bvoff[BCH];
+#pragma unroll
+    for (int i = 0; i < BCH; ++i) {
+      const int br = (t >> 2) + BR * i;
+      const int n = n0 + br;
+      const uint32_t row_bytes = d.w_dgrad ? (uint32_t)d.Cin * 2u : (uint32_t)ldw * 2u;
+      bvoff[i] = (n < d.N && (BFULL || br < BN)) ? (uint32_t)n * row_bytes + bc * 16u : BUF_OOB;
+    }
+
+    const int nk_total = d.K / BK;
+    const int kt0 = blockIdx.y * kt_per_split;
+    const int nk = min(kt_per_split, nk_total - kt0);
+    // wave-uniform running position of the NEXT k-tile to load: tap index and channel base inside the tap
+    int tap = (kt0 * BK) / cin, cib = kt0 * BK - tap * cin;
+    if (conv) set_tap(tap);
+
+    struct Stage { float4 a[AROWS]; uint4 bh[BCH], bl[BCH]; };
+    Stage s0, s1;
+
+    // Loads are unconditional (a branch around them would make the compiler's s_waitcnt placement conservative and
+    // collapse the prefetch distance): requests past this split's last k-tile re-fetch the last tile and are never consumed.
+    auto load_tile = [&](int ktr, Stage& sg) {
+      const int so_a = cib * 4;
+      const int so_w = d.w_dgrad ? ((ntaps - 1 - tap) * d.N * d.Cin + cib) * 2 : (kt0 + min(ktr, nk - 1)) * (BK * 2);
+#pragma unroll
+      for (int i = 0; i < AROWS; ++i) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_a, avoff[i], so_a, 0);
+        sg.a[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+      }
+#pragma unroll
+      for (int i = 0; i < BCH; ++i) {
+        const u32x4 h = __builtin_amdgcn_raw_buffer_load_b128(rs_wh, bvoff[i], so_w, 0);
+        sg.bh[i] = make_uint4(h.x, h.y, h.z, h.w);
+        if (NPASS == 3) {
+          const u32x4 l = __builtin_amdgcn_raw_buffer_load_b128(rs_wl, bvoff[i], so_w, 0);
+          sg.bl[i] = make_uint4(l.x, l.y, l.z, l.w);
+        }
+      }
+      if (ktr < nk - 1) {                         // uniform; no memory operations inside
+        cib += BK;
+        if (cib >= cin) {                         // next k-tile starts a new tap
+          cib = 0; ++tap;
+          if (conv) set_tap(tap);
+        }
+      }
+    };
+
+    int a_st[AROWS], b_st[BCH];
+#pragma unroll
+    for (int i = 0; i < AROWS; ++i) a_st[i] = swz_off((t >> 3) + AR * i, kq >> 1) + (kq & 1) * 8;
+#pragma unroll
+    for (int i = 0; i < BCH; ++i) b_st[i] = swz_off((t >> 2) + BR * i, bc);
+
+    auto store_tile = [&](int buf, const Stage& sg) {
+      char* st = smem + buf * STAGE;
+#pragma unroll
+      for (int i = 0; i < AROWS; ++i) {
+        uint2 hi, lo;
+        split4(sg.a[i], hi, lo);
+        *reinterpret_cast<uint2*>(st + a_st[i]) = hi;
+        if (NPASS == 3) *reinterpret_cast<uint2*>(st + A_BYTES + a_st[i]) = lo;
+      }
+      char* sb = st + NPL * A_BYTES;
+#pragma unroll
+      for (int i = 0; i < BCH; ++i) {
+        if (!BFULL && (t >> 2) + BR * i >= BN) continue;
+        *reinterpret_cast<uint4*>(sb + b_st[i]) = sg.bh[i];
+        if (NPASS == 3) *reinterpret_cast<uint4*>(sb + B_BYTES + b_st[i]) = sg.bl[i];
+      }
+    };
+
+    Frag f0, f1;
+    constexpr int TT = TM * TN, TH = TT / 2;          // all blocks / the part issued in front of the barrier
+
+    // prologue: tile 0 -> LDS[0]; tile 1 in flight in s0.  The loop consumes k-tiles in pairs; an odd last tile is
+    // computed after it (it already sits in LDS[0] with its ks=0 fragments in f0).
+    if (ABL & 32) {
+#pragma unroll
+      for (int i = 0; i < AROWS; ++i) s0.a[i] = make_float4(1.f, 1.f, 1.f, 1.f);
+#pragma unroll
+      for (int i = 0; i < BCH; ++i) s0.bh[i] = s0.bl[i] = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+      store_tile(0, s0);
+    } else {
+      load_tile(0, s0);
+      store_tile(0, s0);
+      if (DEEP) load_tile(1, s0);
+    }
+    __syncthreads();
+    ldfrag(0, 0, f0);
+    if (ABL & 8) ldfrag(0, 1, f1);
+    if (ABL & 1) s1 = s0;
+    const int nk2 = nk & ~1;
+#pragma unroll 1
+    for (int kt = 0; kt < nk2; kt += 2) {
+      // even step: MFMAs on LDS[0]; DEEP: s0 holds tile kt+1 and tile kt+2 starts loading into s1; else tile kt+1 loads into s0 now
+      if (!(ABL & 1)) { if (DEEP) load_tile(kt + 2, s1); else load_tile(kt + 1, s0); }
+      if (!(ABL & 8)) ldfrag(0, 1, f1);
+      mma(f0, 0, TT);
+      if (!(ABL & 2)) store_tile(1, s0);
+      __builtin_amdgcn_sched_barrier(0);          // LDS stores retire under the next MFMAs, not in front of the barrier
+      mma(f1, 0, TH);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(ABL & 4)) __syncthreads();
+      if (!(ABL & 8)) ldfrag(1, 0, f0);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(f1, TH, TT);
+      // odd step: MFMAs on LDS[1]
+      if (!(ABL & 1)) { if (DEEP) load_tile(kt + 3, s0); else load_tile(kt + 2, s0); }
+      if (!(ABL & 8)) ldfrag(1, 1, f1);
+      mma(f0, 0, TT);
+      if (!(ABL & 2)) { if (DEEP) store_tile(0, s1); else store_tile(0, s0); }
+      __builtin_amdgcn_sched_barrier(0);
+      mma(f1, 0, TH);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(ABL & 4)) __syncthreads();
+      if (!(ABL & 8)) ldfrag(0, 0, f0);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(f1, TH, TT);
+    }
+    if (nk & 1) {
+      ldfrag(0, 1, f1);
+      mma(f0, 0, TT);
+      mma(f1, 0, TT);
+    }
+
   }
 
   // ---- epilogue.  The C fragment gives a lane one column and 16 scattered rows (dword stores, 2 x 128 B per wave
@@ -742,7 +859,7 @@ static bool buf_path_ok(const ddpo_gemm_desc& d, int ldw) {
 }
 extern "C" void ddpo_debug_force_generic_gemm(int on) { g_force_generic = on != 0; }
 
-template <int BM, int BN, int NPASS, int WM = 2, int WN = 2>
+template <int BM, int BN, int NPASS, int WM = 2, int WN = 2, bool APL = false>
 static int launch_bf16(const ddpo_gemm_desc& d, const uint16_t* w_hi, const uint16_t* w_lo, int ldw, float* ws, size_t ws_bytes,
                        hipStream_t st) {
   const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;
@@ -769,13 +886,13 @@ static int launch_bf16(const ddpo_gemm_desc& d, const uint16_t* w_hi, const uint
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_bf16_kernel<BM, BN, NPASS, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_bf16_buf_kernel<BM, BN, NPASS, 0, WM, WN>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_bf16_buf_kernel<BM, BN, NPASS, 0, WM, WN, true, APL>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  if (buf_path_ok(d, ldw))
-    hipLaunchKernelGGL((gemm_conv_bf16_buf_kernel<BM, BN, NPASS, 0, WM, WN>), dim3(nblk, splits), dim3(64 * WM * WN), lds, st, d, w_hi, w_lo, ldw,
-                       tiles_m, tiles_n, nblk, ktps, part);
+  if (APL || buf_path_ok(d, ldw))       // the plane-fed entry point has already checked buf_path_ok
+    hipLaunchKernelGGL((gemm_conv_bf16_buf_kernel<BM, BN, NPASS, 0, WM, WN, true, APL>), dim3(nblk, splits), dim3(64 * WM * WN), lds, st, d, w_hi,
+                       w_lo, ldw, tiles_m, tiles_n, nblk, ktps, part);
   else if (d.upsample == 0)
     hipLaunchKernelGGL((gemm_conv_bf16_kernel<BM, BN, NPASS, true>), dim3(nblk, splits), dim3(BF_THREADS), lds, st, d, w_hi, w_lo, ldw,
                        tiles_m, tiles_n, nblk, ktps, part);
@@ -810,7 +927,7 @@ static int wide_splits(const ddpo_gemm_desc& d, bool have_ws, size_t ws_bytes) {
   return splits;
 }
 
-template <int NPASS>
+template <int NPASS, bool APL = false>
 static int launch_bf16_wide(const ddpo_gemm_desc& d, const uint16_t* w_hi, const uint16_t* w_lo, int ldw, float* ws, size_t ws_bytes,
                             hipStream_t st) {
   constexpr int BM = 128, BN = 320, WM = 4, WN = 2;
@@ -825,12 +942,12 @@ static int launch_bf16_wide(const ddpo_gemm_desc& d, const uint16_t* w_hi, const
   const size_t lds = (size_t)BM * BN * 4;                  // epilogue image (160 KB) > 2 stages of operand tiles (112 KB)
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_bf16_buf_kernel<BM, BN, NPASS, 0, WM, WN, true>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_bf16_buf_kernel<BM, BN, NPASS, 0, WM, WN, true, APL>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_conv_bf16_buf_kernel<BM, BN, NPASS, 0, WM, WN, true>), dim3(nblk, splits), dim3(64 * WM * WN), lds, st, d, w_hi, w_lo,
-                     ldw, tiles_m, tiles_n, nblk, ktps, part);
+  hipLaunchKernelGGL((gemm_conv_bf16_buf_kernel<BM, BN, NPASS, 0, WM, WN, true, APL>), dim3(nblk, splits), dim3(64 * WM * WN), lds, st, d, w_hi,
+                     w_lo, ldw, tiles_m, tiles_n, nblk, ktps, part);
   DDPO_LAUNCH_CHECK();
   if (splits > 1) {
     int64_t blocks = ((int64_t)d.M * (d.N >> 2) + 255) / 256;
@@ -872,6 +989,33 @@ extern "C" int ddpo_debug_gemm_ablate(const ddpo_gemm_desc* dp, const uint16_t* 
   return DDPO_OK;
 }
 
+// Tile-shape / split-K selection shared by the fp32-fed and the plane-fed entry points: the SAME rules, so both produce
+// bit-identical results for the same layer (APL is only instantiated for npass == 3).
+template <bool APL>
+static int dispatch_bf16(const ddpo_gemm_desc& d, const uint16_t* w_hi, const uint16_t* w_lo, int ldw, int npass, void* ws, size_t ws_bytes,
+                         hipStream_t st) {
+  if (d.epilogue != 0) {       // GEGLU output stage: 128-wide tiles of the buffer-addressed kernel, vector epilogue only
+    if (d.epilogue != 1 || (d.N & 127) || !buf_path_ok(d, ldw) || d.rowbias || d.residual || d.alpha != 1.0f || d.w_dgrad) return DDPO_EINVAL;
+    if ((d.ld_out & 3) || (reinterpret_cast<uintptr_t>(d.out) & 15) || (d.bias && (reinterpret_cast<uintptr_t>(d.bias) & 15))) return DDPO_EINVAL;
+    return npass == 3 ? launch_bf16<128, 128, 3, 2, 2, APL>(d, w_hi, w_lo, ldw, nullptr, 0, st) : launch_bf16<128, 128, 1>(d, w_hi, w_lo, ldw, nullptr, 0, st);
+  }
+  float* wsf = (ws && !(reinterpret_cast<uintptr_t>(ws) & 15)) ? reinterpret_cast<float*>(ws) : nullptr;
+  static const int wide_mode = [] { const char* e = getenv("DDPO_GEMM_WIDE"); return e ? atoi(e) : 1; }();   // tuning knob: 0 disables 128x320
+  // 128x320 tiles (one workgroup per CU) when they, times the split of the reduction, give every CU a workgroup; a
+  // many-column GEMM with a very short reduction is better on 128x128 (measured: K=320, N=2560; the 160 KB epilogue image)
+  const int wsplits = wide_splits(d, wsf != nullptr, ws_bytes);
+  if (wide_mode && d.N % 320 == 0 && d.M >= 512 && buf_path_ok(d, ldw) && !(d.K / BF_BK < 16 && d.N > 1280) &&
+      (long)((d.M + 127) / 128) * (d.N / 320) * wsplits >= 200 &&
+      !(wsplits > 1 && d.K / BF_BK < 64))       // a split short reduction only adds the reduce pass (measured equal to 128x128 unsplit)
+    return npass == 3 ? launch_bf16_wide<3, APL>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st) : launch_bf16_wide<1>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st);
+  const long t128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128);
+  static const long big_min = [] { const char* e = getenv("DDPO_GEMM_BIG_MIN"); return e ? atol(e) : 256L; }();   // tuning knob (tools/)
+  const bool big = (d.N % 128 == 0) && t128 >= big_min;
+  if (npass == 3)
+    return big ? launch_bf16<128, 128, 3, 2, 2, APL>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st) : launch_bf16<128, 64, 3, 2, 2, APL>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st);
+  return big ? launch_bf16<128, 128, 1>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st) : launch_bf16<128, 64, 1>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st);
+}
+
 extern "C" int ddpo_gemm_conv_fwd_bf16(const ddpo_gemm_desc* dp, const uint16_t* w_hi, const uint16_t* w_lo, int ldw, int npass,
                                        void* ws, size_t ws_bytes, void* stream) {
   if (!dp || !w_hi) return DDPO_EINVAL;
@@ -892,27 +1036,29 @@ extern "C" int ddpo_gemm_conv_fwd_bf16(const ddpo_gemm_desc* dp, const uint16_t*
   } else if (ldw < d.K || (ldw & 7)) {
     return DDPO_EINVAL;
   }
-  hipStream_t st = as_stream(stream);
-  if (d.epilogue != 0) {       // GEGLU output stage: 128-wide tiles of the buffer-addressed kernel, vector epilogue only
-    if (d.epilogue != 1 || (d.N & 127) || !buf_path_ok(d, ldw) || d.rowbias || d.residual || d.alpha != 1.0f || d.w_dgrad) return DDPO_EINVAL;
-    if ((d.ld_out & 3) || (reinterpret_cast<uintptr_t>(d.out) & 15) || (d.bias && (reinterpret_cast<uintptr_t>(d.bias) & 15))) return DDPO_EINVAL;
-    return npass == 3 ? launch_bf16<128, 128, 3>(d, w_hi, w_lo, ldw, nullptr, 0, st) : launch_bf16<128, 128, 1>(d, w_hi, w_lo, ldw, nullptr, 0, st);
+  return dispatch_bf16<false>(d, w_hi, w_lo, ldw, npass, ws, ws_bytes, as_stream(stream));
+}
+
+/* Plane-fed variant: the activation operand comes as bf16 hi / lo planes (see the APL note on gemm_conv_bf16_buf_kernel). */
+extern "C" int ddpo_gemm_conv_fwd_bf16_planes(const ddpo_gemm_desc* dp, const uint16_t* a_hi, const uint16_t* a_lo, int lda,
+                                              const uint16_t* w_hi, const uint16_t* w_lo, int ldw, void* ws, size_t ws_bytes,
+                                              void* stream) {
+  if (!dp || !a_hi || !a_lo || !w_hi || !w_lo) return DDPO_EINVAL;
+  ddpo_gemm_desc d = *dp;
+  if (!d.out || d.M <= 0 || d.N <= 0 || d.K <= 0 || lda <= 0 || (lda & 7) || d.w_dgrad) return DDPO_EINVAL;
+  if (((reinterpret_cast<uintptr_t>(a_hi) | reinterpret_cast<uintptr_t>(a_lo) | reinterpret_cast<uintptr_t>(w_hi) |
+        reinterpret_cast<uintptr_t>(w_lo)) & 15) || ldw < d.K || (ldw & 7)) return DDPO_EINVAL;
+  if (d.ksize > 0) {
+    if (d.ksize != 1 && d.ksize != 3) return DDPO_EINVAL;
+    if (d.K != d.ksize * d.ksize * d.Cin || d.M != d.B * d.OH * d.OW || d.upsample < 0 || d.upsample > 2 || lda < d.Cin) return DDPO_EINVAL;
+  } else if (lda < d.K) {
+    return DDPO_EINVAL;
   }
-  float* wsf = (ws && !(reinterpret_cast<uintptr_t>(ws) & 15)) ? reinterpret_cast<float*>(ws) : nullptr;
-  static const int wide_mode = [] { const char* e = getenv("DDPO_GEMM_WIDE"); return e ? atoi(e) : 1; }();   // tuning knob: 0 disables 128x320
-  // 128x320 tiles (one workgroup per CU) when they, times the split of the reduction, give every CU a workgroup; a
-  // many-column GEMM with a very short reduction is better on 128x128 (measured: K=320, N=2560; the 160 KB epilogue image)
-  const int wsplits = wide_splits(d, wsf != nullptr, ws_bytes);
-  if (wide_mode && d.N % 320 == 0 && d.M >= 512 && buf_path_ok(d, ldw) && !(d.K / BF_BK < 16 && d.N > 1280) &&
-      (long)((d.M + 127) / 128) * (d.N / 320) * wsplits >= 200 &&
-      !(wsplits > 1 && d.K / BF_BK < 64))       // a split short reduction only adds the reduce pass (measured equal to 128x128 unsplit)
-    return npass == 3 ? launch_bf16_wide<3>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st) : launch_bf16_wide<1>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st);
-  const long t128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128);
-  static const long big_min = [] { const char* e = getenv("DDPO_GEMM_BIG_MIN"); return e ? atol(e) : 256L; }();   // tuning knob (tools/)
-  const bool big = (d.N % 128 == 0) && t128 >= big_min;
-  if (npass == 3)
-    return big ? launch_bf16<128, 128, 3>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st) : launch_bf16<128, 64, 3>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st);
-  return big ? launch_bf16<128, 128, 1>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st) : launch_bf16<128, 64, 1>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st);
+  d.src = reinterpret_cast<const float*>(a_hi);      // the kernel reads d.src / d.w as the two planes and d.ld_src in elements
+  d.w = reinterpret_cast<const float*>(a_lo);
+  d.ld_src = lda;
+  if (!buf_path_ok(d, ldw)) return DDPO_EINVAL;      // Cin (K) % 32 == 0 and 31-bit byte offsets: callers keep such layers on the fp32-fed entry
+  return dispatch_bf16<true>(d, w_hi, w_lo, ldw, 3, ws, ws_bytes, as_stream(stream));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -954,6 +1100,34 @@ extern "C" int ddpo_pack_weights_bf16(const float* w, int K, int N, int Kp, uint
   if (!w || !fwd_hi || !fwd_lo || K <= 0 || N <= 0 || Kp < K || (Kp & 7) || (bwd_hi && !bwd_lo)) return DDPO_EINVAL;
   dim3 grid((N + 31) / 32, (Kp + 31) / 32);
   hipLaunchKernelGGL(pack_weights_kernel, grid, dim3(256), 0, as_stream(stream), w, K, N, Kp, fwd_hi, fwd_lo, bwd_hi, bwd_lo);
+  DDPO_LAUNCH_CHECK();
+  return DDPO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp32 activations (rows, cols) with row stride ldx -> bf16 hi / lo planes (rows, ld_out): the operand format of
+// ddpo_gemm_conv_fwd_bf16_planes.  Stand-alone form of what the normalisation kernels do in their output stage
+// (same v_cvt_pk_bf16_f32 split as the GEMM loader: the planes hold exactly the bits the loader would have produced).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) split_planes_kernel(const float* __restrict__ x, int ldx, uint16_t* __restrict__ hi,
+                                                           uint16_t* __restrict__ lo, int ld_out, int64_t rows, int cols4) {
+  const int64_t total = rows * cols4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cols4;
+    const int c = (int)(i - r * cols4) << 2;
+    uint2 h, l;
+    split4(*reinterpret_cast<const float4*>(x + r * ldx + c), h, l);
+    *reinterpret_cast<uint2*>(hi + r * ld_out + c) = h;
+    *reinterpret_cast<uint2*>(lo + r * ld_out + c) = l;
+  }
+}
+
+extern "C" int ddpo_split_planes_bf16(const float* x, int ldx, uint16_t* hi, uint16_t* lo, int ld_out, int64_t rows, int cols, void* stream) {
+  if (!x || !hi || !lo || rows <= 0 || cols <= 0 || (cols & 3) || (ldx & 3) || (ld_out & 3) || ldx < cols || ld_out < cols) return DDPO_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(x) & 15) || ((reinterpret_cast<uintptr_t>(hi) | reinterpret_cast<uintptr_t>(lo)) & 7)) return DDPO_EINVAL;
+  int64_t blocks = (rows * (cols >> 2) + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(split_planes_kernel, dim3((int)blocks), dim3(256), 0, as_stream(stream), x, ldx, hi, lo, ld_out, rows, cols >> 2);
   DDPO_LAUNCH_CHECK();
   return DDPO_OK;
 }

@@ -63,6 +63,9 @@ _SIGS = {
     "ddpo_gemm_conv_wgrad": (c_int, [POINTER(GemmDesc), c_void_p]),
     "ddpo_gemm_conv_fwd_bf16": (c_int, [POINTER(GemmDesc), c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "ddpo_gemm_conv_wgrad_bf16x3": (c_int, [POINTER(GemmDesc), c_void_p]),
+    "ddpo_gemm_conv_fwd_bf16_planes": (c_int, [POINTER(GemmDesc), c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_size_t,
+                                               c_void_p]),
+    "ddpo_split_planes_bf16": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p]),
     "ddpo_pack_weights_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ddpo_attention_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int,
                                    c_int, c_int, c_int, c_float, c_void_p]),

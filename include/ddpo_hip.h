@@ -166,6 +166,18 @@ int ddpo_gemm_conv_wgrad(const ddpo_gemm_desc* d, void* stream);
  * d->w_dgrad = 1 for data gradients.  d->w / d->w_trans are ignored.  Requires Cin % 8 == 0 (K % 8 == 0 if dense). */
 int ddpo_gemm_conv_fwd_bf16(const ddpo_gemm_desc* d, const uint16_t* w_hi, const uint16_t* w_lo, int ldw, int npass,
                             void* ws, size_t ws_bytes, void* stream);
+/* Plane-fed variant (bf16x3 only): the activation operand is given ALREADY split into bf16 hi / lo planes a_hi / a_lo,
+ * (rows, lda) bf16 with lda in elements (% 8 == 0), rows = B*H*W source pixels (conv) or M (dense), as written by
+ * ddpo_split_planes_bf16 or by the plane-emitting output stage of a normalisation kernel.  d->src / d->ld_src / d->w are
+ * ignored.  Both operands reach LDS by LDS-DMA (no register staging, no split in the loader).  Same tiles, k order and
+ * MFMA passes as ddpo_gemm_conv_fwd_bf16 on the fp32 tensor the planes were split from: bit-identical results.
+ * Requires Cin % 32 == 0 (K % 32 == 0 if dense), no w_dgrad; returns DDPO_EINVAL otherwise (use the fp32-fed entry). */
+int ddpo_gemm_conv_fwd_bf16_planes(const ddpo_gemm_desc* d, const uint16_t* a_hi, const uint16_t* a_lo, int lda,
+                                   const uint16_t* w_hi, const uint16_t* w_lo, int ldw, void* ws, size_t ws_bytes,
+                                   void* stream);
+/* x:(rows, cols) fp32, row stride ldx -> hi / lo bf16 planes (rows, ld_out): hi = bf16(x), lo = bf16(x - hi). */
+int ddpo_split_planes_bf16(const float* x, int ldx, uint16_t* hi, uint16_t* lo, int ld_out, int64_t rows, int cols,
+                           void* stream);
 /* ws (optional, 16-byte aligned): scratch for a deterministic split-K of launches whose tile grid under-fills the chip
  * (partials + fixed-order reduce with the fused epilogue); pass NULL/0 to disable. */
 /* Weight gradient on the bf16x3 MFMA datapath (same arguments as ddpo_gemm_conv_wgrad; always accumulates with fp32

@@ -5,6 +5,7 @@
 // device, and the host reference (double precision) is evaluated only on a few hundred sampled outputs per case.
 //
 //   kernel_probe gemm [batch=16] [iters=10]     bf16x3 implicit-GEMM conv / dense shapes of one SD-1.5 U-Net forward
+//   kernel_probe gemm2 [batch=16] [iters=10]    plane-fed (LDS-DMA) kernel vs the fp32-fed one: timing + bitwise comparison
 //   kernel_probe attn [batch=16] [iters=10]     bf16x3 / fp32 flash-attention shapes of the same forward
 //   kernel_probe ppo                            scoring-mode log-prob + PPO-clip + grouped micro-batches vs a host loop
 //
@@ -163,6 +164,80 @@ static int probe_gemm(int B, int iters) {
                           {256, 1280, 1280}, {256, 1280, 10240}, {256, 5120, 1280}, {64, 1280, 1280}, {64, 1280, 10240}, {64, 5120, 1280},
                           {77, 768, 320}, {77, 768, 640}, {77, 768, 1280}, {1, 1280, 1280}};
   for (auto& g : dense) run_gemm(B, g[0], g[1], g[2], 0, 1, 0, iters, ws, ws_bytes);
+  HIP_OK(hipFree(ws));
+  return g_fail;
+}
+
+// ------------------------------------------------------------------------------------------------ plane-fed gemm / conv (LDS-DMA)
+__global__ void diff_kernel(const float* a, const float* b, int64_t n, unsigned long long* cnt, float* maxabs) {
+  unsigned long long c = 0;
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    if (__float_as_uint(a[i]) != __float_as_uint(b[i])) { ++c; m = fmaxf(m, fabsf(a[i] - b[i])); }
+  }
+  if (c) { atomicAdd(cnt, c); atomicMax(reinterpret_cast<unsigned int*>(maxabs), __float_as_uint(m)); }
+}
+
+// fp32-fed kernel vs plane-fed kernel on the same layer: timing of both, bitwise comparison of the two outputs
+static void run_gemm2(int B, int H, int Cin, int Cout, int ks, int stride, int ups, int iters, void* ws, size_t ws_bytes) {
+  const bool conv = ks > 0;
+  const int pad = ks / 2;
+  const int VH = ups ? 2 * H : H;
+  const int OH = conv ? (VH + 2 * pad - ks) / stride + 1 : 0;
+  const int64_t M = conv ? (int64_t)B * OH * OH : (int64_t)B * H;
+  const int K = conv ? ks * ks * Cin : Cin, N = Cout, Kp = (K + 7) / 8 * 8;
+  const int64_t arows = conv ? (int64_t)B * H * H : M;
+  const int acols = conv ? Cin : K;
+  Dev src(arows * acols, 11, 1.0f), w((int64_t)K * N, 12, 1.0f / sqrtf((float)K)), bias(N, 13, 0.5f), res(M * N, 14, 1.0f);
+  float* out1 = (float*)dalloc((size_t)M * N * 4);
+  float* out2 = (float*)dalloc((size_t)M * N * 4);
+  uint16_t *hi = (uint16_t*)dalloc((size_t)N * Kp * 2), *lo = (uint16_t*)dalloc((size_t)N * Kp * 2);
+  uint16_t *ah = (uint16_t*)dalloc((size_t)arows * acols * 2), *al = (uint16_t*)dalloc((size_t)arows * acols * 2);
+  ABI_OK(ddpo_pack_weights_bf16(w.p, K, N, Kp, hi, lo, nullptr, nullptr, nullptr));
+  ABI_OK(ddpo_split_planes_bf16(src.p, acols, ah, al, acols, arows, acols, nullptr));
+  ddpo_gemm_desc d;
+  memset(&d, 0, sizeof(d));
+  d.src = src.p; d.ld_src = acols;
+  d.bias = bias.p; d.residual = res.p; d.ld_res = N; d.ld_out = N; d.alpha = 1.f;
+  d.M = (int)M; d.N = N; d.K = K;
+  if (conv) { d.ksize = ks; d.stride = stride; d.pad = pad; d.upsample = ups; d.B = B; d.H = H; d.W = H; d.Cin = Cin; d.OH = OH; d.OW = OH; }
+  ddpo_gemm_desc d1 = d, d2 = d;
+  d1.out = out1; d2.out = out2;
+  const float ms1 = time_ms(iters, [&] { ABI_OK(ddpo_gemm_conv_fwd_bf16(&d1, hi, lo, Kp, 3, ws, ws_bytes, nullptr)); });
+  const int rc = ddpo_gemm_conv_fwd_bf16_planes(&d2, ah, al, acols, hi, lo, Kp, ws, ws_bytes, nullptr);
+  if (rc != DDPO_OK) {
+    printf("%s K=%d N=%d: plane-fed entry returned %d (layer stays on the fp32-fed kernel)\n", conv ? "conv" : "gemm", K, N, rc);
+  } else {
+    const float ms2 = time_ms(iters, [&] { ABI_OK(ddpo_gemm_conv_fwd_bf16_planes(&d2, ah, al, acols, hi, lo, Kp, ws, ws_bytes, nullptr)); });
+    unsigned long long* cnt = (unsigned long long*)dalloc(8);
+    float* mx = (float*)dalloc(4);
+    hipLaunchKernelGGL(diff_kernel, dim3(1024), dim3(256), 0, 0, out1, out2, M * N, cnt, mx);
+    unsigned long long cnt_h = 0; float mx_h = 0.f;
+    HIP_OK(hipMemcpy(&cnt_h, cnt, 8, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(&mx_h, mx, 4, hipMemcpyDeviceToHost));
+    const double fl = 2.0 * (double)M * N * K;
+    if (cnt_h) ++g_fail;
+    if (conv) printf("conv %dx%d s%d up%d %5d->%5d @%3d^2 B%-3d:", ks, ks, stride, ups, Cin, Cout, H, B);
+    else printf("gemm M=%7lld K=%5d N=%5d       :", (long long)M, K, N);
+    printf(" fp32-fed %7.3f ms %6.1f TF | planes %7.3f ms %6.1f TF (x%.2f) | %llu of %lld outputs differ (max %.2e) %s\n", ms1, fl / ms1 / 1e9, ms2,
+           fl / ms2 / 1e9, ms1 / ms2, cnt_h, (long long)(M * N), mx_h, cnt_h ? "FAIL" : "bit-identical");
+    HIP_OK(hipFree(cnt)); HIP_OK(hipFree(mx));
+  }
+  fflush(stdout);
+  src.release(); w.release(); bias.release(); res.release();
+  HIP_OK(hipFree(out1)); HIP_OK(hipFree(out2)); HIP_OK(hipFree(hi)); HIP_OK(hipFree(lo)); HIP_OK(hipFree(ah)); HIP_OK(hipFree(al));
+}
+
+static int probe_gemm2(int B, int iters) {
+  const size_t ws_bytes = 64u << 20;
+  void* ws = dalloc(ws_bytes);
+  const ConvCase convs[] = {{64, 320, 320, 3, 1, 0}, {32, 640, 640, 3, 1, 0}, {16, 1280, 1280, 3, 1, 0}, {8, 1280, 1280, 3, 1, 0},
+                            {64, 960, 320, 3, 1, 0}, {32, 1920, 640, 3, 1, 0}, {16, 2560, 1280, 3, 1, 0}, {32, 320, 640, 3, 1, 0},
+                            {32, 640, 640, 3, 1, 1}, {64, 320, 320, 3, 2, 0},  {64, 320, 320, 1, 1, 0},   {20, 64, 96, 3, 1, 0}};
+  for (const ConvCase& c : convs) run_gemm2(B, c.H, c.Cin, c.Cout, c.ks, c.stride, c.ups, iters, ws, ws_bytes);
+  const int dense[][3] = {{4096, 320, 320}, {4096, 320, 2560}, {4096, 1280, 320}, {1024, 640, 5120}, {1024, 2560, 640},
+                          {256, 1280, 10240}, {256, 5120, 1280}, {64, 1280, 1280}, {77, 768, 320}, {1, 1280, 1280}, {37, 96, 72}};
+  for (auto& g : dense) run_gemm2(B, g[0], g[1], g[2], 0, 1, 0, iters, ws, ws_bytes);
   HIP_OK(hipFree(ws));
   return g_fail;
 }
@@ -329,9 +404,10 @@ int main(int argc, char** argv) {
          getenv("DDPO_GEMM_BIG_MIN") ? getenv("DDPO_GEMM_BIG_MIN") : "-");
   int rc;
   if (mode == "gemm") rc = probe_gemm(B, iters);
+  else if (mode == "gemm2") rc = probe_gemm2(B, iters);
   else if (mode == "attn") rc = probe_attn(B, iters);
   else if (mode == "ppo") rc = probe_ppo();
-  else { fprintf(stderr, "usage: kernel_probe gemm|attn|ppo [batch] [iters]\n"); return 64; }
+  else { fprintf(stderr, "usage: kernel_probe gemm|gemm2|attn|ppo [batch] [iters]\n"); return 64; }
   HIP_OK(hipDeviceSynchronize());
   printf("# %s: %s\n", mode.c_str(), rc ? "FAILURES" : "all spot checks passed");
   return rc ? 1 : 0;
