@@ -346,7 +346,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
 // VGPRs, no v_cvt / v_sub split, no ds_write.  A wave instruction fills 16 rows x 64 B lane-linearly, so the XOR swizzle of
 // swz_off() is applied to the SOURCE chunk each lane fetches.  Same tiles, same k order, same three MFMA passes as the
 // register-staged path: results are bit-identical to it.
-template <int BM, int BN, int NPASS, int ABL = 0, int WM = 2, int WN = 2, bool DEEP = true, bool APL = false>     // ABL: timing ablations (tools/ablate_gemm.py; wrong results)
+template <int BM, int BN, int NPASS, int ABL = 0, int WM = 2, int WN = 2, bool DEEP = true, int APL = 0>     // ABL: timing ablations (tools/ablate_gemm.py; wrong results)
 __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const ddpo_gemm_desc d, const uint16_t* __restrict__ w_hi,
                                                                        const uint16_t* __restrict__ w_lo, int ldw, int tiles_m,
                                                                        int tiles_n, int nblk, int kt_per_split,
@@ -438,7 +438,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
     }
   };
 
-  if constexpr (APL) {
+  if constexpr (APL != 0) {
     // ---------------- LDS-DMA path: A planes + W planes straight into the swizzled LDS image ----------------
     static_assert(NPASS == 3, "the plane-fed path is the bf16x3 datapath");
     constexpr int NW = WM * WN, PAIRS = NW / 2;          // even waves move hi planes, odd waves lo planes
@@ -520,29 +520,67 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
         if (conv && tap < ntaps) set_tap(tap);
       }
     };
-    // Two LDS stages.  Per k-tile: wait for my pieces of tile kt, barrier (everybody's pieces landed AND everybody has finished
-    // reading the other stage), request tile kt + 1 into the other stage, then run the MFMAs of tile kt under that request.
-    auto step = [&](int kt, auto cur_c) {
-      constexpr int cur = decltype(cur_c)::value;
-      // vmcnt(0): my LDS-DMA pieces of tile kt are in LDS.  lgkmcnt(0): my fragment reads of the OTHER stage (tile kt - 1) have
-      // returned, so no wave can start overwriting that stage (below, after the barrier) while a read of it is in flight.
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      if (kt + 1 < nk) fill(cur ^ 1);
-      Frag g0, g1;
-      ldfrag(cur, 0, g0);
-      ldfrag(cur, 1, g1);
-      mma(g0, 0, TM * TN);
-      mma(g1, 0, TM * TN);
-    };
-    fill(0);
-    int kt = 0;
+    if constexpr (APL == 1) {
+      // Two LDS stages.  Per k-tile: wait for my pieces of tile kt, barrier (everybody's pieces landed AND everybody has finished
+      // reading the other stage), request tile kt + 1 into the other stage, then run the MFMAs of tile kt under that request.
+      auto step = [&](int kt, auto cur_c) {
+        constexpr int cur = decltype(cur_c)::value;
+        // vmcnt(0): my LDS-DMA pieces of tile kt are in LDS.  lgkmcnt(0): my fragment reads of the OTHER stage (tile kt - 1) have
+        // returned, so no wave can start overwriting that stage (below, after the barrier) while a read of it is in flight.
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 1 < nk) fill(cur ^ 1);
+        Frag g0, g1;
+        ldfrag(cur, 0, g0);
+        ldfrag(cur, 1, g1);
+        mma(g0, 0, TM * TN);
+        mma(g1, 0, TM * TN);
+      };
+      fill(0);
+      int kt = 0;
 #pragma unroll 1
-    for (; kt + 1 < nk; kt += 2) {
-      step(kt, std::integral_constant<int, 0>{});
-      step(kt + 1, std::integral_constant<int, 1>{});
+      for (; kt + 1 < nk; kt += 2) {
+        step(kt, std::integral_constant<int, 0>{});
+        step(kt + 1, std::integral_constant<int, 1>{});
+      }
+      if (kt < nk) step(kt, std::integral_constant<int, 0>{});
+    } else {
+      // Barrier in the MIDDLE of the k-tile (the register-staged loop's shape): on entry the ks = 0 fragments of tile kt are in
+      // registers; its ks = 1 fragments are requested and the ks = 0 MFMAs run under them; then everybody waits for tile kt + 1
+      // to have landed and for its own reads of tile kt's stage to have returned, the barrier publishes both facts, tile kt + 2 is
+      // requested into the stage just freed, the ks = 0 fragments of tile kt + 1 are requested and the ks = 1 MFMAs run under them.
+      const bool late = d.splits != 0 && wv >= NW / 2;          // staggered request (see DDPO_APL_MODE)
+      Frag g0, g1;
+      fill(0);
+      if (nk > 1) fill(1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      ldfrag(0, 0, g0);
+      auto step2 = [&](int kt, auto cur_c) {
+        constexpr int cur = decltype(cur_c)::value;
+        ldfrag(cur, 1, g1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(g0, 0, TM * TN);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nk && !late) fill(cur);
+        if (kt + 1 < nk) ldfrag(cur ^ 1, 0, g0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(g1, 0, (TM * TN) / 2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 2 < nk && late) fill(cur);
+        mma(g1, (TM * TN) / 2, TM * TN);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      int kt = 0;
+#pragma unroll 1
+      for (; kt + 1 < nk; kt += 2) {
+        step2(kt, std::integral_constant<int, 0>{});
+        step2(kt + 1, std::integral_constant<int, 1>{});
+      }
+      if (kt < nk) step2(kt, std::integral_constant<int, 0>{});
     }
-    if (kt < nk) step(kt, std::integral_constant<int, 0>{});
   } else {
     const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(d.src);
     const __amdgpu_buffer_rsrc_t rs_wh = make_rsrc(w_hi);
@@ -859,7 +897,7 @@ static bool buf_path_ok(const ddpo_gemm_desc& d, int ldw) {
 }
 extern "C" void ddpo_debug_force_generic_gemm(int on) { g_force_generic = on != 0; }
 
-template <int BM, int BN, int NPASS, int WM = 2, int WN = 2, bool APL = false>
+template <int BM, int BN, int NPASS, int WM = 2, int WN = 2, int APL = 0>
 static int launch_bf16(const ddpo_gemm_desc& d, const uint16_t* w_hi, const uint16_t* w_lo, int ldw, float* ws, size_t ws_bytes,
                        hipStream_t st) {
   const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;
@@ -927,7 +965,7 @@ static int wide_splits(const ddpo_gemm_desc& d, bool have_ws, size_t ws_bytes) {
   return splits;
 }
 
-template <int NPASS, bool APL = false>
+template <int NPASS, int APL = 0>
 static int launch_bf16_wide(const ddpo_gemm_desc& d, const uint16_t* w_hi, const uint16_t* w_lo, int ldw, float* ws, size_t ws_bytes,
                             hipStream_t st) {
   constexpr int BM = 128, BN = 320, WM = 4, WN = 2;
@@ -991,7 +1029,7 @@ extern "C" int ddpo_debug_gemm_ablate(const ddpo_gemm_desc* dp, const uint16_t* 
 
 // Tile-shape / split-K selection shared by the fp32-fed and the plane-fed entry points: the SAME rules, so both produce
 // bit-identical results for the same layer (APL is only instantiated for npass == 3).
-template <bool APL>
+template <int APL>
 static int dispatch_bf16(const ddpo_gemm_desc& d, const uint16_t* w_hi, const uint16_t* w_lo, int ldw, int npass, void* ws, size_t ws_bytes,
                          hipStream_t st) {
   if (d.epilogue != 0) {       // GEGLU output stage: 128-wide tiles of the buffer-addressed kernel, vector epilogue only
@@ -1036,7 +1074,7 @@ extern "C" int ddpo_gemm_conv_fwd_bf16(const ddpo_gemm_desc* dp, const uint16_t*
   } else if (ldw < d.K || (ldw & 7)) {
     return DDPO_EINVAL;
   }
-  return dispatch_bf16<false>(d, w_hi, w_lo, ldw, npass, ws, ws_bytes, as_stream(stream));
+  return dispatch_bf16<0>(d, w_hi, w_lo, ldw, npass, ws, ws_bytes, as_stream(stream));
 }
 
 /* Plane-fed variant: the activation operand comes as bf16 hi / lo planes (see the APL note on gemm_conv_bf16_buf_kernel). */
@@ -1058,7 +1096,14 @@ extern "C" int ddpo_gemm_conv_fwd_bf16_planes(const ddpo_gemm_desc* dp, const ui
   d.w = reinterpret_cast<const float*>(a_lo);
   d.ld_src = lda;
   if (!buf_path_ok(d, ldw)) return DDPO_EINVAL;      // Cin (K) % 32 == 0 and 31-bit byte offsets: callers keep such layers on the fp32-fed entry
-  return dispatch_bf16<true>(d, w_hi, w_lo, ldw, 3, ws, ws_bytes, as_stream(stream));
+  // DDPO_APL_MODE (tuning knob, read once): 1 = plain two-stage loop (wait, barrier, request, compute); 2 = barrier in the
+  // middle of the k-tile with the fragment reads software-pipelined across it; +4 = the upper half of the waves requests its
+  // pieces half a k-tile later than the lower half (the two waves of a SIMD then alternate between DMA issue and MFMAs).
+  // Measured on the SD-1.5 layers at batch 16 (profiles/r01_probe_gemm_planes_modes.md): 6 (default) > 1 ~ 2 > fp32-fed.
+  static const int apl_mode = [] { const char* e = getenv("DDPO_APL_MODE"); return e ? atoi(e) : 6; }();
+  d.splits = (apl_mode & 4) ? 1 : 0;                 // `splits` is a wgrad-only field: the forward kernel reads it as the stagger flag
+  return (apl_mode & 3) == 1 ? dispatch_bf16<1>(d, w_hi, w_lo, ldw, 3, ws, ws_bytes, as_stream(stream))
+                             : dispatch_bf16<2>(d, w_hi, w_lo, ldw, 3, ws, ws_bytes, as_stream(stream));
 }
 
 // ------------------------------------------------------------------------------------------------
