@@ -46,4 +46,21 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
   return 0.5f * x * (1.f + tanhf(u));
 }
 
+// ---- fp32 -> bf16 hi / lo split of the bf16x3 datapath (x ~= hi + lo, both bf16, round-to-nearest-even conversions)
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+
+// split 4 floats into 4 bf16 "hi" (2 dwords) and 4 bf16 "lo" (2 dwords)
+__device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo) {
+  hi.x = cvt_pk_bf16(v.x, v.y);
+  hi.y = cvt_pk_bf16(v.z, v.w);
+  const float r0 = v.x - __uint_as_float(hi.x << 16), r1 = v.y - __uint_as_float(hi.x & 0xFFFF0000u);
+  const float r2 = v.z - __uint_as_float(hi.y << 16), r3 = v.w - __uint_as_float(hi.y & 0xFFFF0000u);
+  lo.x = cvt_pk_bf16(r0, r1);
+  lo.y = cvt_pk_bf16(r2, r3);
+}
+
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }

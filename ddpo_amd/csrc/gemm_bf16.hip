@@ -19,22 +19,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define BF_BK 32
 #define BF_THREADS 256
 
-__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
-  uint32_t r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-  return r;
-}
-
-// split 4 floats into 4 bf16 "hi" (2 dwords) and 4 bf16 "lo" (2 dwords)
-__device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo) {
-  hi.x = cvt_pk_bf16(v.x, v.y);
-  hi.y = cvt_pk_bf16(v.z, v.w);
-  const float r0 = v.x - __uint_as_float(hi.x << 16), r1 = v.y - __uint_as_float(hi.x & 0xFFFF0000u);
-  const float r2 = v.z - __uint_as_float(hi.y << 16), r3 = v.w - __uint_as_float(hi.y & 0xFFFF0000u);
-  lo.x = cvt_pk_bf16(r0, r1);
-  lo.y = cvt_pk_bf16(r2, r3);
-}
-
 // two floats -> packed bf16 hi pair and packed bf16 lo pair
 __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
   hi = cvt_pk_bf16(a, b);

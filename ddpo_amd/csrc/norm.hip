@@ -110,9 +110,12 @@ __global__ void __launch_bounds__(64) gn_finalize_kernel(const double* __restric
 }
 
 // Pass 3: y = act(x*a + s)
-template <bool SILU>
+// PL: instead of the fp32 tensor write its bf16 hi / lo planes (rows, ldy) — the operand format of the plane-fed GEMM
+// (ddpo_gemm_conv_fwd_bf16_planes); same arithmetic, so the planes hold exactly the split of the fp32 result.
+template <bool SILU, bool PL = false>
 __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
-                                                       const float* __restrict__ ab, int B, int HW, int C) {
+                                                       const float* __restrict__ ab, int B, int HW, int C,
+                                                       uint16_t* __restrict__ y_hi = nullptr, uint16_t* __restrict__ y_lo = nullptr) {
   const int C4 = C >> 2;
   const int64_t total = (int64_t)B * HW * C4;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -125,7 +128,14 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__
     float4 o;
     o.x = v.x * k0.x + k0.y; o.y = v.y * k0.z + k0.w; o.z = v.z * k1.x + k1.y; o.w = v.w * k1.z + k1.w;
     if (SILU) { o.x = silu_f(o.x); o.y = silu_f(o.y); o.z = silu_f(o.z); o.w = silu_f(o.w); }
-    *reinterpret_cast<float4*>(y + row * ldy + c) = o;
+    if (PL) {
+      uint2 h, l;
+      split4(o, h, l);
+      *reinterpret_cast<uint2*>(y_hi + row * ldy + c) = h;
+      *reinterpret_cast<uint2*>(y_lo + row * ldy + c) = l;
+    } else {
+      *reinterpret_cast<float4*>(y + row * ldy + c) = o;
+    }
   }
 }
 
@@ -143,12 +153,16 @@ extern "C" size_t ddpo_groupnorm_ws_bytes(int B, int HW, int C, int G) {
 }
 extern "C" size_t ddpo_groupnorm_stats_floats(int B, int C, int G) { return (size_t)B * C * 2 + (size_t)B * G * 2; }
 
-extern "C" int ddpo_groupnorm_fwd(const float* x, int ldx, float* y, int ldy, const float* gamma, const float* beta, int B,
-                                  int HW, int C, int G, float eps, int fuse_silu, void* ws, float* stats, void* stream) {
-  if (!x || !y || !gamma || !beta || !ws || !stats || B <= 0 || HW <= 0 || C <= 0 || G <= 0 || G > GN_MAXG) return DDPO_EINVAL;
+static int groupnorm_fwd_impl(const float* x, int ldx, float* y, uint16_t* y_hi, uint16_t* y_lo, int ldy, const float* gamma,
+                              const float* beta, int B, int HW, int C, int G, float eps, int fuse_silu, void* ws, float* stats,
+                              void* stream) {
+  const bool planes = y == nullptr;
+  if (!x || !gamma || !beta || !ws || !stats || B <= 0 || HW <= 0 || C <= 0 || G <= 0 || G > GN_MAXG) return DDPO_EINVAL;
+  if (planes ? (!y_hi || !y_lo) : false) return DDPO_EINVAL;
   if ((C & 3) || (C % G) || (ldx & 3) || (ldy & 3) || C > GN_MAXC || B > 65535) return DDPO_EINVAL;
-  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(ws) |
-       reinterpret_cast<uintptr_t>(stats)) & 15) return DDPO_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(ws) | reinterpret_cast<uintptr_t>(stats)) & 15) return DDPO_EINVAL;
+  if (planes ? ((reinterpret_cast<uintptr_t>(y_hi) | reinterpret_cast<uintptr_t>(y_lo)) & 7) != 0 : (reinterpret_cast<uintptr_t>(y) & 15) != 0)
+    return DDPO_EINVAL;
   hipStream_t st = as_stream(stream);
   const int C4 = C >> 2;
   const int ppb = gn_ppb(C);
@@ -162,21 +176,43 @@ extern "C" int ddpo_groupnorm_fwd(const float* x, int ldx, float* y, int ldy, co
   DDPO_LAUNCH_CHECK();
   int64_t blocks = ((int64_t)B * HW * C4 + 255) / 256;
   if (blocks > 16384) blocks = 16384;
-  if (fuse_silu)
-    hipLaunchKernelGGL(gn_apply_kernel<true>, dim3((int)blocks), dim3(256), 0, st, x, ldx, y, ldy, ab, B, HW, C);
-  else
-    hipLaunchKernelGGL(gn_apply_kernel<false>, dim3((int)blocks), dim3(256), 0, st, x, ldx, y, ldy, ab, B, HW, C);
+  uint16_t* const no = nullptr;
+  if (planes) {
+    if (fuse_silu)
+      hipLaunchKernelGGL((gn_apply_kernel<true, true>), dim3((int)blocks), dim3(256), 0, st, x, ldx, y, ldy, ab, B, HW, C, y_hi, y_lo);
+    else
+      hipLaunchKernelGGL((gn_apply_kernel<false, true>), dim3((int)blocks), dim3(256), 0, st, x, ldx, y, ldy, ab, B, HW, C, y_hi, y_lo);
+  } else if (fuse_silu) {
+    hipLaunchKernelGGL((gn_apply_kernel<true, false>), dim3((int)blocks), dim3(256), 0, st, x, ldx, y, ldy, ab, B, HW, C, no, no);
+  } else {
+    hipLaunchKernelGGL((gn_apply_kernel<false, false>), dim3((int)blocks), dim3(256), 0, st, x, ldx, y, ldy, ab, B, HW, C, no, no);
+  }
   DDPO_LAUNCH_CHECK();
   return DDPO_OK;
+}
+
+extern "C" int ddpo_groupnorm_fwd(const float* x, int ldx, float* y, int ldy, const float* gamma, const float* beta, int B,
+                                  int HW, int C, int G, float eps, int fuse_silu, void* ws, float* stats, void* stream) {
+  if (!y) return DDPO_EINVAL;
+  return groupnorm_fwd_impl(x, ldx, y, nullptr, nullptr, ldy, gamma, beta, B, HW, C, G, eps, fuse_silu, ws, stats, stream);
+}
+
+extern "C" int ddpo_groupnorm_fwd_planes(const float* x, int ldx, uint16_t* y_hi, uint16_t* y_lo, int ldy, const float* gamma,
+                                         const float* beta, int B, int HW, int C, int G, float eps, int fuse_silu, void* ws,
+                                         float* stats, void* stream) {
+  if (!y_hi || !y_lo) return DDPO_EINVAL;
+  return groupnorm_fwd_impl(x, ldx, nullptr, y_hi, y_lo, ldy, gamma, beta, B, HW, C, G, eps, fuse_silu, ws, stats, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
 // LayerNorm: one wave per row, row held in registers (C <= 64*4*LN_MAXV = 2560)
 // ------------------------------------------------------------------------------------------------
 #define LN_MAXV 10
+template <bool PL>
 __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                        int rows, int C, float eps) {
+                                                        int rows, int C, float eps, uint16_t* __restrict__ y_hi,
+                                                        uint16_t* __restrict__ y_lo) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -215,7 +251,14 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
       o.y = (v[j].y - mean) * rstd * g.y + bt.y;
       o.z = (v[j].z - mean) * rstd * g.z + bt.z;
       o.w = (v[j].w - mean) * rstd * g.w + bt.w;
-      *reinterpret_cast<float4*>(yr + (c4 << 2)) = o;
+      if (PL) {             // bf16 hi / lo planes (rows, C) instead of the fp32 tensor (see gn_apply_kernel)
+        uint2 h, l;
+        split4(o, h, l);
+        *reinterpret_cast<uint2*>(y_hi + (int64_t)row * C + (c4 << 2)) = h;
+        *reinterpret_cast<uint2*>(y_lo + (int64_t)row * C + (c4 << 2)) = l;
+      } else {
+        *reinterpret_cast<float4*>(yr + (c4 << 2)) = o;
+      }
     }
   }
 }
@@ -223,7 +266,19 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
 extern "C" int ddpo_layernorm_fwd(const float* x, float* y, const float* gamma, const float* beta, int rows, int C, float eps,
                                   void* stream) {
   if (!x || !y || !gamma || !beta || rows <= 0 || C <= 0 || (C & 3) || C > 256 * LN_MAXV) return DDPO_EINVAL;
-  hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, as_stream(stream), x, y, gamma, beta, rows, C, eps);
+  uint16_t* const no = nullptr;
+  hipLaunchKernelGGL(layernorm_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, as_stream(stream), x, y, gamma, beta, rows, C, eps, no, no);
+  DDPO_LAUNCH_CHECK();
+  return DDPO_OK;
+}
+
+extern "C" int ddpo_layernorm_fwd_planes(const float* x, uint16_t* y_hi, uint16_t* y_lo, const float* gamma, const float* beta,
+                                         int rows, int C, float eps, void* stream) {
+  if (!x || !y_hi || !y_lo || !gamma || !beta || rows <= 0 || C <= 0 || (C & 3) || C > 256 * LN_MAXV) return DDPO_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(y_hi) | reinterpret_cast<uintptr_t>(y_lo)) & 7) return DDPO_EINVAL;
+  float* const nof = nullptr;
+  hipLaunchKernelGGL(layernorm_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, as_stream(stream), x, nof, gamma, beta, rows, C, eps, y_hi,
+                     y_lo);
   DDPO_LAUNCH_CHECK();
   return DDPO_OK;
 }

@@ -66,6 +66,9 @@ _SIGS = {
     "ddpo_gemm_conv_fwd_bf16_planes": (c_int, [POINTER(GemmDesc), c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_size_t,
                                                c_void_p]),
     "ddpo_split_planes_bf16": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p]),
+    "ddpo_groupnorm_fwd_planes": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                          c_float, c_int, c_void_p, c_void_p, c_void_p]),
+    "ddpo_layernorm_fwd_planes": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "ddpo_pack_weights_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ddpo_attention_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int,
                                    c_int, c_int, c_int, c_float, c_void_p]),
@@ -107,6 +110,51 @@ _lib = None
 DATAPATH = os.environ.get("DDPO_DATAPATH", "fp32")
 SPLITK_WS_BYTES = 64 << 20       # scratch for the deterministic split-K of under-filled launches
 PACKED = {}          # data_ptr of an fp32 weight tensor -> dict(fwd=(hi, lo, Kp), bwd=(hi, lo) | None, K, N)
+
+# Plane-fed GEMMs (bf16x3 datapath, inference / sampling forward only): GroupNorm / LayerNorm write their result as bf16
+# hi / lo planes and the consuming conv / linear layers fetch both operands by LDS-DMA (ddpo_gemm_conv_fwd_bf16_planes).
+# Bit-identical to the fp32-fed kernels; DDPO_PLANES=0 switches it off.
+PLANES = os.environ.get("DDPO_PLANES", "1") != "0"
+
+
+class Planes:
+    """An activation (rows, C) stored as bf16 hi / lo planes (two int16 tensors): x ~= hi + lo."""
+    __slots__ = ("hi", "lo")
+
+    def __init__(self, rows, C, device):
+        self.hi = torch.empty(rows, C, dtype=torch.int16, device=device)
+        self.lo = torch.empty(rows, C, dtype=torch.int16, device=device)
+
+    @property
+    def device(self):
+        return self.hi.device
+
+    @property
+    def shape(self):
+        return self.hi.shape
+
+    def data_ptr(self):
+        return self.hi.data_ptr()
+
+    def float(self):
+        """hi + lo as fp32 (tests / debugging)."""
+        f = lambda t: (t.to(torch.int32) << 16).view(torch.float32)
+        return f(self.hi) + f(self.lo)
+
+
+def planes_ok(w, cin):
+    """True when a GEMM / conv with weight tensor `w` and `cin` reduction channels per tap can take a plane-fed activation:
+    bf16x3 datapath, weight planes registered (pack_weights), 32-channel k-tiles that never straddle a tap."""
+    return PLANES and DATAPATH == "bf16x3" and (cin % 32 == 0) and PACKED.get(w.data_ptr()) is not None
+
+
+def split_planes(x):
+    """fp32 (rows, C) -> Planes (what a plane-emitting producer writes; used by tests and tools)."""
+    rows, C = x.shape
+    pl = Planes(rows, C, x.device)
+    _check(load().ddpo_split_planes_bf16(_p(x), C, _p(pl.hi), _p(pl.lo), C, rows, C, _stream()), "ddpo_split_planes_bf16")
+    return pl
+
 
 # When set to a list, every ddpo_gemm_conv_fwd launch appends (start_event, end_event, algorithmic_flops);
 # used by bench.py for the live roofline measurement of the dominant kernel.
@@ -271,9 +319,17 @@ def _scratch(nbytes, device, tag):
     return ws
 
 
-def groupnorm(x, B, HW, gamma, beta, groups, eps, silu, out=None, ld_x=None, ld_out=None, return_stats=False):
-    """x: (B*HW, C) NHWC rows (row stride ld_x).  Returns (B*HW, C) [and the saved statistics for the backward]."""
+def groupnorm(x, B, HW, gamma, beta, groups, eps, silu, out=None, ld_x=None, ld_out=None, return_stats=False, planes=False):
+    """x: (B*HW, C) NHWC rows (row stride ld_x).  Returns (B*HW, C) [and the saved statistics for the backward].
+    planes=True: the result comes back as `Planes` (bf16 hi / lo) for a plane-fed conv / linear."""
     C = gamma.numel()
+    if planes:
+        pl = Planes(B * HW, C, x.device)
+        ws = _scratch(load().ddpo_groupnorm_ws_bytes(B, HW, C, groups), x.device, "gn")
+        stats = torch.empty(load().ddpo_groupnorm_stats_floats(B, C, groups), dtype=torch.float32, device=x.device)
+        _check(load().ddpo_groupnorm_fwd_planes(_p(x), int(ld_x or C), _p(pl.hi), _p(pl.lo), C, _p(gamma), _p(beta), B, HW, C, groups,
+                                                float(eps), int(bool(silu)), _p(ws), _p(stats), _stream()), "ddpo_groupnorm_fwd_planes")
+        return (pl, stats) if return_stats else pl
     if out is None:
         out = torch.empty(B * HW, C, dtype=torch.float32, device=x.device)
     ws = _scratch(load().ddpo_groupnorm_ws_bytes(B, HW, C, groups), x.device, "gn")
@@ -293,8 +349,13 @@ def groupnorm_bwd(x, dy, stats, gamma, B, HW, groups, silu, dgamma, dbeta, dx_ad
     return dx
 
 
-def layernorm(x, gamma, beta, eps=1e-5, out=None):
+def layernorm(x, gamma, beta, eps=1e-5, out=None, planes=False):
     rows, C = x.shape
+    if planes:
+        pl = Planes(rows, C, x.device)
+        _check(load().ddpo_layernorm_fwd_planes(_p(x), _p(pl.hi), _p(pl.lo), _p(gamma), _p(beta), rows, C, float(eps), _stream()),
+               "ddpo_layernorm_fwd_planes")
+        return pl
     if out is None:
         out = torch.empty_like(x)
     _check(load().ddpo_layernorm_fwd(_p(x), _p(out), _p(gamma), _p(beta), rows, C, float(eps), _stream()), "ddpo_layernorm_fwd")
@@ -356,6 +417,9 @@ def linear_geglu(x, w, out=None):
     N = w.shape[1]
     if (M * K * 4) >= (1 << 31):
         return None
+    pl = x if isinstance(x, Planes) else None
+    if pl is not None and (DATAPATH != "bf16x3" or K % 32):
+        raise DdpoHipError("plane-fed linear_geglu needs the bf16x3 datapath and K % 32 == 0 (check planes_ok before asking for planes)")
     if out is None:
         out = torch.empty(M, N // 2, dtype=torch.float32, device=x.device)
     d = GemmDesc()
@@ -369,7 +433,11 @@ def linear_geglu(x, w, out=None):
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _check(load().ddpo_gemm_conv_fwd_bf16(byref(d), _p(g["hi"]), _p(g["lo"]), K, npass, None, 0, _stream()), "ddpo_gemm_conv_fwd_bf16")
+    if pl is not None:
+        _check(load().ddpo_gemm_conv_fwd_bf16_planes(byref(d), _p(pl.hi), _p(pl.lo), K, _p(g["hi"]), _p(g["lo"]), K, None, 0, _stream()),
+               "ddpo_gemm_conv_fwd_bf16_planes")
+    else:
+        _check(load().ddpo_gemm_conv_fwd_bf16(byref(d), _p(g["hi"]), _p(g["lo"]), K, npass, None, 0, _stream()), "ddpo_gemm_conv_fwd_bf16")
     if PROFILE is not None:
         e1.record()
         PROFILE.append((e0, e1, 2.0 * M * N * K, DATAPATH, 4.0 * (M * K + K * N + M * N // 2)))
@@ -399,6 +467,7 @@ def _bf16_route(w, K, N, conv, dgrad):
 def gemm_conv(src, w, *, M, N, K, bias=None, rowbias=None, rows_per_batch=0, residual=None, out=None, alpha=1.0,
               w_trans=False, ld_src=None, ld_out=None, ld_res=None, conv=None):
     """Generic entry: conv = dict(ksize, stride, pad, upsample, B, H, W, Cin, OH, OW) or None for a dense GEMM."""
+    pl = src if isinstance(src, Planes) else None
     d = GemmDesc()
     d.src = src.data_ptr(); d.ld_src = int(ld_src if ld_src is not None else (conv["Cin"] if conv else K))
     d.w = w.data_ptr(); d.w_trans = int(bool(w_trans))
@@ -416,10 +485,18 @@ def gemm_conv(src, w, *, M, N, K, bias=None, rowbias=None, rows_per_batch=0, res
         for k in ("ksize", "stride", "pad", "upsample", "B", "H", "W", "Cin", "OH", "OW"):
             setattr(d, k, int(conv[k]))
     route = None if w_trans else _bf16_route(w, K, N, conv, False)
+    if pl is not None and (route is None or route[3] != 3 or (conv["Cin"] if conv else K) % 32 or ld_src is not None):
+        raise DdpoHipError("a plane-fed GEMM needs the bf16x3 datapath, registered weight planes and 32-channel k-tiles "
+                           "(check planes_ok before asking a producer for planes)")
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    if route is not None:
+    if pl is not None:
+        hi, lo, ldw, npass = route
+        ws = _scratch(SPLITK_WS_BYTES, src.device, "splitk")
+        _check(load().ddpo_gemm_conv_fwd_bf16_planes(byref(d), _p(pl.hi), _p(pl.lo), int(pl.hi.shape[1]), _p(hi), _p(lo), ldw, _p(ws),
+                                                     SPLITK_WS_BYTES, _stream()), "ddpo_gemm_conv_fwd_bf16_planes")
+    elif route is not None:
         hi, lo, ldw, npass = route
         ws = _scratch(SPLITK_WS_BYTES, src.device, "splitk")
         _check(load().ddpo_gemm_conv_fwd_bf16(byref(d), _p(hi), _p(lo), ldw, npass, _p(ws), SPLITK_WS_BYTES, _stream()), "ddpo_gemm_conv_fwd_bf16")

@@ -198,13 +198,19 @@ class Act:
 def resnet_forward(P, name, x: Act, temb_act, groups, eps, tape=None):
     """FlaxResnetBlock2D: GN-SiLU-conv3x3 (+time proj) - GN-SiLU-conv3x3 (+ shortcut)."""
     cout = P[name + ".conv1.bias"].numel()
-    h1, st1 = L.groupnorm(x.t, x.B, x.HW, P[name + ".norm1.scale"], P[name + ".norm1.bias"], groups, eps, True, return_stats=True)
+    # inference / sampling (no tape): the two GroupNorm+SiLU results feed only their convolution, so they are written as bf16
+    # hi / lo planes and the convolutions run plane-fed (LDS-DMA operands; bit-identical to the fp32-fed kernels)
+    pl1 = tape is None and L.planes_ok(P[name + ".conv1.kernel"], x.C)
+    pl2 = tape is None and L.planes_ok(P[name + ".conv2.kernel"], cout)
+    h1, st1 = L.groupnorm(x.t, x.B, x.HW, P[name + ".norm1.scale"], P[name + ".norm1.bias"], groups, eps, True, return_stats=True,
+                          planes=pl1)
     rowbias = None
     if temb_act is not None:
         rowbias = L.linear(temb_act, P[name + ".time_emb_proj.kernel"], P[name + ".time_emb_proj.bias"])
     c1, _, _ = L.conv2d(h1, P[name + ".conv1.kernel"], P[name + ".conv1.bias"], x.B, x.H, x.W, x.C, cout, 3,
                         rowbias=rowbias, rows_per_batch=x.HW)
-    h2, st2 = L.groupnorm(c1, x.B, x.HW, P[name + ".norm2.scale"], P[name + ".norm2.bias"], groups, eps, True, return_stats=True)
+    h2, st2 = L.groupnorm(c1, x.B, x.HW, P[name + ".norm2.scale"], P[name + ".norm2.bias"], groups, eps, True, return_stats=True,
+                          planes=pl2)
     res = x.t
     shortcut = (name + ".conv_shortcut.kernel") in P
     if shortcut:
@@ -297,22 +303,28 @@ class UNet2DCondition:
         P, cfg = self.params, self.cfg
         C, B, N = x.C, x.B, x.HW
         rec = None if tape is None else dict(name=name, x=x, heads=heads, ctx=ctx, ctx_len=ctx_len)
-        hn, st = L.groupnorm(x.t, B, N, P[name + ".norm.scale"], P[name + ".norm.bias"], cfg.norm_groups, 1e-5, False, return_stats=True)
+        tb = name + ".transformer_blocks_0"
+        inf = tape is None                         # plane-fed GEMMs behind the norms (see resnet_forward)
+        pl_in = inf and L.planes_ok(P[name + ".proj_in.kernel"], C)
+        pl_1 = inf and all(L.planes_ok(P[f"{tb}.attn1.{n}.kernel"], C) for n in ("to_q", "to_k", "to_v"))
+        pl_2 = inf and L.planes_ok(P[tb + ".attn2.to_q.kernel"], C)
+        pl_3 = inf and L.planes_ok(P[tb + ".ff.net_0.proj.kernel"], C)
+        hn, st = L.groupnorm(x.t, B, N, P[name + ".norm.scale"], P[name + ".norm.bias"], cfg.norm_groups, 1e-5, False, return_stats=True,
+                             planes=pl_in)
         if cfg.use_linear_projection:
             h0 = L.linear(hn, P[name + ".proj_in.kernel"], P[name + ".proj_in.bias"])
         else:
             h0, _, _ = L.conv2d(hn, P[name + ".proj_in.kernel"], P[name + ".proj_in.bias"], B, x.H, x.W, C, C, 1)
-        tb = name + ".transformer_blocks_0"
-        ln = lambda n, t: L.layernorm(t, P[f"{tb}.{n}.scale"], P[f"{tb}.{n}.bias"], 1e-5)
+        ln = lambda n, t, pl=False: L.layernorm(t, P[f"{tb}.{n}.scale"], P[f"{tb}.{n}.bias"], 1e-5, planes=pl)
         a1r = None if rec is None else {}
         a2r = None if rec is None else {}
-        l1 = ln("norm1", h0)
+        l1 = ln("norm1", h0, pl_1)
         a1 = self._attention(tb + ".attn1", l1, B, N, C, heads, None, 0, a1r)
         h1 = L.linear(a1, P[tb + ".attn1.to_out_0.kernel"], P[tb + ".attn1.to_out_0.bias"], residual=h0)
-        l2 = ln("norm2", h1)
+        l2 = ln("norm2", h1, pl_2)
         a2 = self._attention(tb + ".attn2", l2, B, N, C, heads, ctx, ctx_len, a2r)
         h2 = L.linear(a2, P[tb + ".attn2.to_out_0.kernel"], P[tb + ".attn2.to_out_0.bias"], residual=h1)
-        l3 = ln("norm3", h2)
+        l3 = ln("norm3", h2, pl_3)
         f = None
         gg = L.linear_geglu(l3, P[tb + ".ff.net_0.proj.kernel"]) if tape is None else None     # sampling: GEGLU fused into the GEMM epilogue
         if gg is None:
@@ -452,7 +464,8 @@ class UNet2DCondition:
                 if tape is not None:
                     tape.append(("up", dict(name=name, x=h)))
                 h = Act(t, B, OH, OW, h.C)
-        hn, st = L.groupnorm(h.t, B, h.HW, P["conv_norm_out.scale"], P["conv_norm_out.bias"], G, 1e-5, True, return_stats=True)
+        hn, st = L.groupnorm(h.t, B, h.HW, P["conv_norm_out.scale"], P["conv_norm_out.bias"], G, 1e-5, True, return_stats=True,
+                             planes=tape is None and L.planes_ok(P["conv_out.kernel"], h.C))
         t, _, _ = L.conv2d(hn, P["conv_out.kernel"], P["conv_out.bias"], B, h.H, h.W, h.C, cfg.out_channels, 3)
         if tape is not None:
             tape.append(("tail", dict(x=h, hn=hn, st=st)))

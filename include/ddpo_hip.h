@@ -103,6 +103,11 @@ size_t ddpo_groupnorm_ws_bytes(int B, int HW, int C, int G);
 size_t ddpo_groupnorm_stats_floats(int B, int C, int G);
 int ddpo_groupnorm_fwd(const float* x, int ldx, float* y, int ldy, const float* gamma, const float* beta,
                        int B, int HW, int C, int G, float eps, int fuse_silu, void* ws, float* stats, void* stream);
+/* Same, but the result is written as bf16 hi / lo planes (B*HW, ldy) — hi = bf16(y), lo = bf16(y - hi) — the activation
+ * operand format of ddpo_gemm_conv_fwd_bf16_planes (the fp32 tensor is not materialised; same bytes). */
+int ddpo_groupnorm_fwd_planes(const float* x, int ldx, uint16_t* y_hi, uint16_t* y_lo, int ldy, const float* gamma,
+                              const float* beta, int B, int HW, int C, int G, float eps, int fuse_silu, void* ws,
+                              float* stats, void* stream);
 /* Backward of y = act(GroupNorm(x)): dx (+= dx_add if given), dgamma/dbeta accumulated atomically (they live in the
  * flat gradient buffer).  ws: ddpo_groupnorm_bwd_ws_bytes(B,HW,C,G) bytes. */
 size_t ddpo_groupnorm_bwd_ws_bytes(int B, int HW, int C, int G);
@@ -112,6 +117,8 @@ int ddpo_groupnorm_bwd(const float* x, int ldx, const float* dy, int lddy, const
 /* LayerNorm over the last dim: x,y:(rows,C) contiguous. */
 int ddpo_layernorm_fwd(const float* x, float* y, const float* gamma, const float* beta, int rows, int C,
                        float eps, void* stream);
+int ddpo_layernorm_fwd_planes(const float* x, uint16_t* y_hi, uint16_t* y_lo, const float* gamma, const float* beta,
+                              int rows, int C, float eps, void* stream);      /* planes (rows, C), as above */
 /* dx = LayerNorm backward (+ dx_add if given; statistics recomputed from x); dgamma/dbeta += (two-stage reduction
  * through ws = ddpo_layernorm_bwd_ws_bytes(rows, C) bytes of 16-byte aligned scratch). */
 size_t ddpo_layernorm_bwd_ws_bytes(int rows, int C);

@@ -1,0 +1,159 @@
+"""Plane-fed bf16x3 GEMM / conv (LDS-DMA operands) and the plane-emitting GroupNorm / LayerNorm output stages.
+
+Contract under test: an activation written as bf16 hi / lo planes by a producer and consumed by
+`ddpo_gemm_conv_fwd_bf16_planes` gives BIT-IDENTICAL results to the fp32 tensor consumed by `ddpo_gemm_conv_fwd_bf16`
+(same tiles, same k order, same MFMA passes; the planes hold exactly the split the fp32-fed loader computes on the fly).
+The U-Net / VAE sampling forward therefore does not change by a single bit when `lib.PLANES` is switched on, and the
+training forward (always fp32-fed: its backward needs the fp32 activations) keeps matching the sampler bit for bit.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from ddpo_amd import lib as L
+
+DEV = "cuda"
+
+
+def _bf16x3():
+    L.DATAPATH = "bf16x3"
+
+
+def test_split_planes_is_the_loader_split():
+    x = torch.randn(257, 96, device=DEV) * torch.logspace(-6, 4, 96, device=DEV)
+    pl = L.split_planes(x)
+    hi_ref = x.bfloat16()                                             # round-to-nearest-even, like v_cvt_pk_bf16_f32
+    assert torch.equal(pl.hi.view(torch.bfloat16), hi_ref)
+    lo_ref = (x - hi_ref.float()).bfloat16()
+    assert torch.equal(pl.lo.view(torch.bfloat16), lo_ref)
+    assert float(((pl.float() - x).abs() / x.abs().clamp_min(1e-30)).max()) < 2.0 ** -15
+
+
+@pytest.mark.parametrize("B,HW,C,silu", [(2, 64, 64, True), (3, 49, 96, False), (1, 1024, 320, True)])
+def test_groupnorm_planes_equal_split_of_fp32_result(B, HW, C, silu):
+    g = torch.Generator(device=DEV).manual_seed(1)
+    x = torch.randn(B * HW, C, device=DEV, generator=g) * 3 + 0.5
+    gamma, beta = torch.randn(C, device=DEV, generator=g), torch.randn(C, device=DEV, generator=g)
+    y = L.groupnorm(x, B, HW, gamma, beta, 32, 1e-5, silu)
+    pl = L.groupnorm(x, B, HW, gamma, beta, 32, 1e-5, silu, planes=True)
+    ref = L.split_planes(y)
+    assert torch.equal(pl.hi, ref.hi) and torch.equal(pl.lo, ref.lo)
+
+
+@pytest.mark.parametrize("rows,C", [(77, 64), (1024, 320), (130, 1280)])
+def test_layernorm_planes_equal_split_of_fp32_result(rows, C):
+    g = torch.Generator(device=DEV).manual_seed(2)
+    x = torch.randn(rows, C, device=DEV, generator=g) * 2 - 0.3
+    gamma, beta = torch.randn(C, device=DEV, generator=g), torch.randn(C, device=DEV, generator=g)
+    ref = L.split_planes(L.layernorm(x, gamma, beta))
+    pl = L.layernorm(x, gamma, beta, planes=True)
+    assert torch.equal(pl.hi, ref.hi) and torch.equal(pl.lo, ref.lo)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,ks,stride,ups", [
+    (2, 16, 16, 64, 96, 3, 1, False),      # 128x64 tiles, ragged N
+    (4, 32, 32, 320, 320, 3, 1, False),    # 128x320 tiles
+    (2, 16, 16, 128, 128, 3, 1, False),    # 128x128 / 128x64
+    (1, 8, 8, 1280, 1280, 3, 1, False),    # split-K
+    (2, 16, 16, 64, 64, 3, 2, False), (2, 8, 8, 64, 64, 3, 1, True), (3, 12, 20, 96, 160, 1, 1, False)])
+def test_conv_planes_bit_identical(B, H, W, Cin, Cout, ks, stride, ups):
+    _bf16x3()
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn(B * H * W, Cin, device=DEV, generator=g)
+    w = torch.randn(ks, ks, Cin, Cout, device=DEV, generator=g) / (ks * ks * Cin) ** 0.5
+    b = torch.randn(Cout, device=DEV, generator=g)
+    L.pack_weights(w, bwd=False)
+    assert L.planes_ok(w, Cin)
+    y0, OH, OW = L.conv2d(x, w, b, B, H, W, Cin, Cout, ks, stride=stride, upsample=ups)
+    res = torch.randn_like(y0)
+    rb = torch.randn(B, Cout, device=DEV, generator=g)
+    y1, _, _ = L.conv2d(x, w, b, B, H, W, Cin, Cout, ks, stride=stride, upsample=ups, residual=res, rowbias=rb, rows_per_batch=OH * OW)
+    pl = L.split_planes(x)
+    z0, _, _ = L.conv2d(pl, w, b, B, H, W, Cin, Cout, ks, stride=stride, upsample=ups)
+    z1, _, _ = L.conv2d(pl, w, b, B, H, W, Cin, Cout, ks, stride=stride, upsample=ups, residual=res, rowbias=rb, rows_per_batch=OH * OW)
+    assert torch.equal(y0, z0) and torch.equal(y1, z1)
+
+
+@pytest.mark.parametrize("M,K,N", [(77, 64, 96), (4096, 320, 320), (1024, 640, 5120), (300, 1280, 1280), (64, 5120, 1280), (5, 32, 8)])
+def test_linear_planes_bit_identical(M, K, N):
+    _bf16x3()
+    g = torch.Generator(device=DEV).manual_seed(4)
+    x = torch.randn(M, K, device=DEV, generator=g)
+    w = torch.randn(K, N, device=DEV, generator=g) / K ** 0.5
+    b = torch.randn(N, device=DEV, generator=g)
+    L.pack_weights(w, bwd=False)
+    res = torch.randn(M, N, device=DEV, generator=g)
+    y = L.linear(x, w, b, residual=res)
+    z = L.linear(L.split_planes(x), w, b, residual=res)
+    assert torch.equal(y, z)
+
+
+def test_linear_geglu_planes_bit_identical():
+    _bf16x3()
+    g = torch.Generator(device=DEV).manual_seed(5)
+    M, K, F = 1000, 320, 1280
+    x = torch.randn(M, K, device=DEV, generator=g)
+    w = torch.randn(K, 2 * F, device=DEV, generator=g) / K ** 0.5
+    b = torch.randn(2 * F, device=DEV, generator=g)
+    L.pack_weights(w, bwd=False)
+    assert L.pack_weights_geglu(w, b)
+    y = L.linear_geglu(x, w)
+    z = L.linear_geglu(L.split_planes(x), w)
+    assert y is not None and torch.equal(y, z)
+
+
+def test_planes_rejected_where_the_fp32_entry_must_be_used():
+    _bf16x3()
+    x = torch.randn(64, 40, device=DEV)                 # K % 32 != 0
+    w = torch.randn(40, 64, device=DEV)
+    L.pack_weights(w, bwd=False)
+    assert not L.planes_ok(w, 40)
+    with pytest.raises(L.DdpoHipError):
+        L.linear(L.split_planes(x), w)
+    w2 = torch.randn(64, 64, device=DEV)                # weight planes not registered
+    assert not L.planes_ok(w2, 64)
+    L.DATAPATH = "fp32"
+    assert not L.planes_ok(w, 64)
+
+
+@pytest.mark.parametrize("model", ["tiny", "tiny21"])
+def test_unet_and_vae_forward_unchanged_by_planes(model, monkeypatch):
+    """Sampling forward with plane-fed GEMMs == without, bit for bit; the training forward (tape) never uses planes."""
+    from ddpo_amd.models.unet import UNet2DCondition, UNetConfig
+    from ddpo_amd.models.vae import VAEDecoder, VAEConfig
+    _bf16x3()
+    cfg = UNetConfig.named(model)
+    unet = UNet2DCondition(cfg, DEV)
+    unet.params.init_synthetic(0)
+    unet.params.pack_bf16()
+    g = torch.Generator(device=DEV).manual_seed(6)
+    x = torch.randn(4, 4, 16, 16, device=DEV, generator=g)
+    t = torch.tensor([981, 21, 481, 1], dtype=torch.int32, device=DEV)
+    ctx = torch.randn(4, 77, cfg.cross_attention_dim, device=DEV, generator=g)
+    monkeypatch.setattr(L, "PLANES", True)
+    counter = {"n": 0}
+    real = L.gemm_conv
+
+    def counting(src, *a, **k):
+        counter["n"] += isinstance(src, L.Planes)
+        return real(src, *a, **k)
+    monkeypatch.setattr(L, "gemm_conv", counting)
+    y_pl = unet(x, t, ctx)
+    assert counter["n"] > 20                                  # the plane-fed path really ran
+    tape = []
+    counter["n"] = 0
+    y_train = unet.forward(x, t, ctx, tape=tape)
+    assert counter["n"] == 0
+    monkeypatch.setattr(L, "PLANES", False)
+    y_fp = unet(x, t, ctx)
+    assert counter["n"] == 0
+    assert torch.equal(y_pl, y_fp) and torch.equal(y_pl, y_train)
+    vae = VAEDecoder(VAEConfig.named("tiny"), DEV)
+    vae.params.init_synthetic(1)
+    vae.params.pack_bf16(bwd=False)
+    lat = torch.randn(2, 4, 8, 8, device=DEV, generator=g)
+    img_fp = vae.decode(lat)
+    monkeypatch.setattr(L, "PLANES", True)
+    img_pl = vae.decode(lat)
+    assert torch.equal(img_fp, img_pl)
