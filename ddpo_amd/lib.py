@@ -113,8 +113,10 @@ PACKED = {}          # data_ptr of an fp32 weight tensor -> dict(fwd=(hi, lo, Kp
 
 # Plane-fed GEMMs (bf16x3 datapath, inference / sampling forward only): GroupNorm / LayerNorm write their result as bf16
 # hi / lo planes and the consuming conv / linear layers fetch both operands by LDS-DMA (ddpo_gemm_conv_fwd_bf16_planes).
-# Bit-identical to the fp32-fed kernels; DDPO_PLANES=0 switches it off.
-PLANES = os.environ.get("DDPO_PLANES", "1") != "0"
+# Bit-identical to the fp32-fed kernels (tests/test_gpu_planes.py).  Opt-in (DDPO_PLANES=1) for now: layer by layer the
+# plane-fed kernel is 9-23 % faster on the convolutions (profiles/r01_probe_gemm_planes_modes.md), but the end-to-end
+# sampling bench moved by only +0.7 % (3.249 vs 3.227 images/s on the same box) — see DESIGN.md §6 for what to measure next.
+PLANES = os.environ.get("DDPO_PLANES", "0") == "1"
 
 
 class Planes:
@@ -142,10 +144,18 @@ class Planes:
         return f(self.hi) + f(self.lo)
 
 
-def planes_ok(w, cin):
-    """True when a GEMM / conv with weight tensor `w` and `cin` reduction channels per tap can take a plane-fed activation:
-    bf16x3 datapath, weight planes registered (pack_weights), 32-channel k-tiles that never straddle a tap."""
-    return PLANES and DATAPATH == "bf16x3" and (cin % 32 == 0) and PACKED.get(w.data_ptr()) is not None
+def planes_ok(w, cin, rows):
+    """True when a GEMM / conv with weight tensor `w`, `cin` reduction channels per tap and `rows` source rows (B*H*W pixels
+    of a convolution's input, M of a dense layer) can take a plane-fed activation: bf16x3 datapath, weight planes registered
+    (pack_weights), 32-channel k-tiles that never straddle a tap, and 31-bit byte offsets (the conditions of the
+    buffer-addressed kernel, buf_path_ok() in csrc/gemm_bf16.hip — the VAE's 512x512 levels at batch 8 exceed them)."""
+    if not (PLANES and DATAPATH == "bf16x3" and cin % 32 == 0):
+        return False
+    ent = PACKED.get(w.data_ptr())
+    if ent is None:
+        return False
+    lim = 0x7FFFFFFF
+    return rows * cin * 4 < lim and ent["N"] * ent["fwd"][2] * 2 < lim
 
 
 def split_planes(x):

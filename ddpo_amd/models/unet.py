@@ -200,8 +200,8 @@ def resnet_forward(P, name, x: Act, temb_act, groups, eps, tape=None):
     cout = P[name + ".conv1.bias"].numel()
     # inference / sampling (no tape): the two GroupNorm+SiLU results feed only their convolution, so they are written as bf16
     # hi / lo planes and the convolutions run plane-fed (LDS-DMA operands; bit-identical to the fp32-fed kernels)
-    pl1 = tape is None and L.planes_ok(P[name + ".conv1.kernel"], x.C)
-    pl2 = tape is None and L.planes_ok(P[name + ".conv2.kernel"], cout)
+    pl1 = tape is None and L.planes_ok(P[name + ".conv1.kernel"], x.C, x.M)
+    pl2 = tape is None and L.planes_ok(P[name + ".conv2.kernel"], cout, x.M)
     h1, st1 = L.groupnorm(x.t, x.B, x.HW, P[name + ".norm1.scale"], P[name + ".norm1.bias"], groups, eps, True, return_stats=True,
                           planes=pl1)
     rowbias = None
@@ -305,10 +305,10 @@ class UNet2DCondition:
         rec = None if tape is None else dict(name=name, x=x, heads=heads, ctx=ctx, ctx_len=ctx_len)
         tb = name + ".transformer_blocks_0"
         inf = tape is None                         # plane-fed GEMMs behind the norms (see resnet_forward)
-        pl_in = inf and L.planes_ok(P[name + ".proj_in.kernel"], C)
-        pl_1 = inf and all(L.planes_ok(P[f"{tb}.attn1.{n}.kernel"], C) for n in ("to_q", "to_k", "to_v"))
-        pl_2 = inf and L.planes_ok(P[tb + ".attn2.to_q.kernel"], C)
-        pl_3 = inf and L.planes_ok(P[tb + ".ff.net_0.proj.kernel"], C)
+        pl_in = inf and L.planes_ok(P[name + ".proj_in.kernel"], C, B * N)
+        pl_1 = inf and all(L.planes_ok(P[f"{tb}.attn1.{n}.kernel"], C, B * N) for n in ("to_q", "to_k", "to_v"))
+        pl_2 = inf and L.planes_ok(P[tb + ".attn2.to_q.kernel"], C, B * N)
+        pl_3 = inf and L.planes_ok(P[tb + ".ff.net_0.proj.kernel"], C, B * N)
         hn, st = L.groupnorm(x.t, B, N, P[name + ".norm.scale"], P[name + ".norm.bias"], cfg.norm_groups, 1e-5, False, return_stats=True,
                              planes=pl_in)
         if cfg.use_linear_projection:
@@ -465,7 +465,7 @@ class UNet2DCondition:
                     tape.append(("up", dict(name=name, x=h)))
                 h = Act(t, B, OH, OW, h.C)
         hn, st = L.groupnorm(h.t, B, h.HW, P["conv_norm_out.scale"], P["conv_norm_out.bias"], G, 1e-5, True, return_stats=True,
-                             planes=tape is None and L.planes_ok(P["conv_out.kernel"], h.C))
+                             planes=tape is None and L.planes_ok(P["conv_out.kernel"], h.C, h.M))
         t, _, _ = L.conv2d(hn, P["conv_out.kernel"], P["conv_out.bias"], B, h.H, h.W, h.C, cfg.out_channels, 3)
         if tape is not None:
             tape.append(("tail", dict(x=h, hn=hn, st=st)))

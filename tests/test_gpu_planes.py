@@ -64,7 +64,7 @@ def test_conv_planes_bit_identical(B, H, W, Cin, Cout, ks, stride, ups):
     w = torch.randn(ks, ks, Cin, Cout, device=DEV, generator=g) / (ks * ks * Cin) ** 0.5
     b = torch.randn(Cout, device=DEV, generator=g)
     L.pack_weights(w, bwd=False)
-    assert L.planes_ok(w, Cin)
+    assert L.planes_ok(w, Cin, B * H * W)
     y0, OH, OW = L.conv2d(x, w, b, B, H, W, Cin, Cout, ks, stride=stride, upsample=ups)
     res = torch.randn_like(y0)
     rb = torch.randn(B, Cout, device=DEV, generator=g)
@@ -108,13 +108,16 @@ def test_planes_rejected_where_the_fp32_entry_must_be_used():
     x = torch.randn(64, 40, device=DEV)                 # K % 32 != 0
     w = torch.randn(40, 64, device=DEV)
     L.pack_weights(w, bwd=False)
-    assert not L.planes_ok(w, 40)
+    assert not L.planes_ok(w, 40, 64)
     with pytest.raises(L.DdpoHipError):
         L.linear(L.split_planes(x), w)
     w2 = torch.randn(64, 64, device=DEV)                # weight planes not registered
-    assert not L.planes_ok(w2, 64)
+    assert not L.planes_ok(w2, 64, 64)
+    w3 = torch.randn(64, 64, device=DEV)
+    L.pack_weights(w3, bwd=False)
+    assert L.planes_ok(w3, 64, 1000) and not L.planes_ok(w3, 64, 1 << 24)      # 31-bit byte offsets (buf_path_ok)
     L.DATAPATH = "fp32"
-    assert not L.planes_ok(w, 64)
+    assert not L.planes_ok(w3, 64, 1000)
 
 
 @pytest.mark.parametrize("model", ["tiny", "tiny21"])
