@@ -78,3 +78,25 @@ def test_gemm_desc_field_order_matches_header():
         decl = re.sub(r"^(const\s+)?(float|int|int32_t|int64_t|size_t|void)\s*\*?\s*", "", stmt)
         names += [n.strip().lstrip("*") for n in decl.split(",")]
     assert names == [f[0] for f in L.GemmDesc._fields_]
+
+
+def test_planes_host_logic(monkeypatch):
+    """Eligibility rule of the plane-fed GEMM (mirror of buf_path_ok in csrc/gemm_bf16.hip) and the Planes container; no launch."""
+    import torch
+    monkeypatch.setattr(L, "PLANES", True)
+    monkeypatch.setattr(L, "DATAPATH", "bf16x3")
+    w = torch.zeros(64, 64)
+    monkeypatch.setitem(L.PACKED, w.data_ptr(), dict(K=64, N=64, fwd=(None, None, 64), bwd=None))
+    assert L.planes_ok(w, 64, 1000)
+    assert not L.planes_ok(w, 64, 1 << 24)            # 2^24 rows x 64 channels x 4 B >= 2^31: stays on the pointer-addressed kernel
+    assert not L.planes_ok(w, 40, 10)                 # k-tiles of 32 must not straddle a tap
+    assert not L.planes_ok(torch.zeros(8, 8), 32, 10)     # weight planes not registered
+    monkeypatch.setattr(L, "DATAPATH", "fp32")
+    assert not L.planes_ok(w, 64, 1000)
+    monkeypatch.setattr(L, "DATAPATH", "bf16x3")
+    monkeypatch.setattr(L, "PLANES", False)
+    assert not L.planes_ok(w, 64, 1000)
+    pl = L.Planes(4, 8, "cpu")
+    pl.hi.fill_(0x3F80)                                # bf16 1.0
+    pl.lo.fill_(0x3B80)                                # bf16 2^-8
+    assert pl.shape == (4, 8) and torch.equal(pl.float(), torch.full((4, 8), 1.0 + 2.0 ** -8))

@@ -16,6 +16,12 @@ from ddpo_amd import lib as L
 DEV = "cuda"
 
 
+@pytest.fixture(autouse=True)
+def _planes_on(monkeypatch):
+    """The plane-fed path is opt-in (DDPO_PLANES=1); these tests exercise it whatever the environment says."""
+    monkeypatch.setattr(L, "PLANES", True)
+
+
 def _bf16x3():
     L.DATAPATH = "bf16x3"
 
