@@ -115,7 +115,8 @@ __global__ void __launch_bounds__(64) gn_finalize_kernel(const double* __restric
 template <bool SILU, bool PL = false>
 __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
                                                        const float* __restrict__ ab, int B, int HW, int C,
-                                                       uint16_t* __restrict__ y_hi = nullptr, uint16_t* __restrict__ y_lo = nullptr) {
+                                                       uint16_t* __restrict__ y_hi = nullptr, uint16_t* __restrict__ y_lo = nullptr,
+                                                       int pair = 0) {
   const int C4 = C >> 2;
   const int64_t total = (int64_t)B * HW * C4;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -131,8 +132,17 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__
     if (PL) {
       uint2 h, l;
       split4(o, h, l);
-      *reinterpret_cast<uint2*>(y_hi + row * ldy + c) = h;
-      *reinterpret_cast<uint2*>(y_lo + row * ldy + c) = l;
+      if (pair) {
+        // 16-byte plane stores: lanes 2j / 2j+1 hold adjacent channel quads of one row (C % 8 == 0); the even lane collects
+        // both hi halves and writes 8 channels of the hi plane, the odd lane both lo halves and writes the lo plane
+        const bool odd = threadIdx.x & 1;
+        const uint32_t rx = __shfl_xor(odd ? h.x : l.x, 1, 64), ry = __shfl_xor(odd ? h.y : l.y, 1, 64);
+        if (!odd) *reinterpret_cast<uint4*>(y_hi + row * ldy + c) = make_uint4(h.x, h.y, rx, ry);
+        else *reinterpret_cast<uint4*>(y_lo + row * ldy + c - 4) = make_uint4(rx, ry, l.x, l.y);
+      } else {
+        *reinterpret_cast<uint2*>(y_hi + row * ldy + c) = h;
+        *reinterpret_cast<uint2*>(y_lo + row * ldy + c) = l;
+      }
     } else {
       *reinterpret_cast<float4*>(y + row * ldy + c) = o;
     }
@@ -178,14 +188,17 @@ static int groupnorm_fwd_impl(const float* x, int ldx, float* y, uint16_t* y_hi,
   if (blocks > 16384) blocks = 16384;
   uint16_t* const no = nullptr;
   if (planes) {
+    // lane-paired 16-byte stores need 8-channel granularity and 16-byte aligned plane rows
+    const int pair = ((C & 7) == 0 && (ldy & 7) == 0 &&
+                      ((reinterpret_cast<uintptr_t>(y_hi) | reinterpret_cast<uintptr_t>(y_lo)) & 15) == 0) ? 1 : 0;
     if (fuse_silu)
-      hipLaunchKernelGGL((gn_apply_kernel<true, true>), dim3((int)blocks), dim3(256), 0, st, x, ldx, y, ldy, ab, B, HW, C, y_hi, y_lo);
+      hipLaunchKernelGGL((gn_apply_kernel<true, true>), dim3((int)blocks), dim3(256), 0, st, x, ldx, y, ldy, ab, B, HW, C, y_hi, y_lo, pair);
     else
-      hipLaunchKernelGGL((gn_apply_kernel<false, true>), dim3((int)blocks), dim3(256), 0, st, x, ldx, y, ldy, ab, B, HW, C, y_hi, y_lo);
+      hipLaunchKernelGGL((gn_apply_kernel<false, true>), dim3((int)blocks), dim3(256), 0, st, x, ldx, y, ldy, ab, B, HW, C, y_hi, y_lo, pair);
   } else if (fuse_silu) {
-    hipLaunchKernelGGL((gn_apply_kernel<true, false>), dim3((int)blocks), dim3(256), 0, st, x, ldx, y, ldy, ab, B, HW, C, no, no);
+    hipLaunchKernelGGL((gn_apply_kernel<true, false>), dim3((int)blocks), dim3(256), 0, st, x, ldx, y, ldy, ab, B, HW, C, no, no, 0);
   } else {
-    hipLaunchKernelGGL((gn_apply_kernel<false, false>), dim3((int)blocks), dim3(256), 0, st, x, ldx, y, ldy, ab, B, HW, C, no, no);
+    hipLaunchKernelGGL((gn_apply_kernel<false, false>), dim3((int)blocks), dim3(256), 0, st, x, ldx, y, ldy, ab, B, HW, C, no, no, 0);
   }
   DDPO_LAUNCH_CHECK();
   return DDPO_OK;
@@ -212,7 +225,7 @@ template <bool PL>
 __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         int rows, int C, float eps, uint16_t* __restrict__ y_hi,
-                                                        uint16_t* __restrict__ y_lo) {
+                                                        uint16_t* __restrict__ y_lo, int pair) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -254,8 +267,15 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
       if (PL) {             // bf16 hi / lo planes (rows, C) instead of the fp32 tensor (see gn_apply_kernel)
         uint2 h, l;
         split4(o, h, l);
-        *reinterpret_cast<uint2*>(y_hi + (int64_t)row * C + (c4 << 2)) = h;
-        *reinterpret_cast<uint2*>(y_lo + (int64_t)row * C + (c4 << 2)) = l;
+        if (pair) {           // lane-paired 16-byte stores (see gn_apply_kernel); C % 8 == 0 keeps both lanes of a pair inside the row
+          const bool odd = lane & 1;
+          const uint32_t rx = __shfl_xor(odd ? h.x : l.x, 1, 64), ry = __shfl_xor(odd ? h.y : l.y, 1, 64);
+          if (!odd) *reinterpret_cast<uint4*>(y_hi + (int64_t)row * C + (c4 << 2)) = make_uint4(h.x, h.y, rx, ry);
+          else *reinterpret_cast<uint4*>(y_lo + (int64_t)row * C + (c4 << 2) - 4) = make_uint4(rx, ry, l.x, l.y);
+        } else {
+          *reinterpret_cast<uint2*>(y_hi + (int64_t)row * C + (c4 << 2)) = h;
+          *reinterpret_cast<uint2*>(y_lo + (int64_t)row * C + (c4 << 2)) = l;
+        }
       } else {
         *reinterpret_cast<float4*>(yr + (c4 << 2)) = o;
       }
@@ -267,7 +287,7 @@ extern "C" int ddpo_layernorm_fwd(const float* x, float* y, const float* gamma, 
                                   void* stream) {
   if (!x || !y || !gamma || !beta || rows <= 0 || C <= 0 || (C & 3) || C > 256 * LN_MAXV) return DDPO_EINVAL;
   uint16_t* const no = nullptr;
-  hipLaunchKernelGGL(layernorm_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, as_stream(stream), x, y, gamma, beta, rows, C, eps, no, no);
+  hipLaunchKernelGGL(layernorm_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, as_stream(stream), x, y, gamma, beta, rows, C, eps, no, no, 0);
   DDPO_LAUNCH_CHECK();
   return DDPO_OK;
 }
@@ -277,8 +297,9 @@ extern "C" int ddpo_layernorm_fwd_planes(const float* x, uint16_t* y_hi, uint16_
   if (!x || !y_hi || !y_lo || !gamma || !beta || rows <= 0 || C <= 0 || (C & 3) || C > 256 * LN_MAXV) return DDPO_EINVAL;
   if ((reinterpret_cast<uintptr_t>(y_hi) | reinterpret_cast<uintptr_t>(y_lo)) & 7) return DDPO_EINVAL;
   float* const nof = nullptr;
+  const int pair = ((C & 7) == 0 && ((reinterpret_cast<uintptr_t>(y_hi) | reinterpret_cast<uintptr_t>(y_lo)) & 15) == 0) ? 1 : 0;
   hipLaunchKernelGGL(layernorm_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, as_stream(stream), x, nof, gamma, beta, rows, C, eps, y_hi,
-                     y_lo);
+                     y_lo, pair);
   DDPO_LAUNCH_CHECK();
   return DDPO_OK;
 }

@@ -36,18 +36,19 @@ def test_split_planes_is_the_loader_split():
     assert float(((pl.float() - x).abs() / x.abs().clamp_min(1e-30)).max()) < 2.0 ** -15
 
 
-@pytest.mark.parametrize("B,HW,C,silu", [(2, 64, 64, True), (3, 49, 96, False), (1, 1024, 320, True)])
-def test_groupnorm_planes_equal_split_of_fp32_result(B, HW, C, silu):
+@pytest.mark.parametrize("B,HW,C,G,silu", [(2, 64, 64, 32, True), (3, 49, 96, 32, False), (1, 1024, 320, 32, True),
+                                           (2, 25, 36, 4, True)])        # C % 8 != 0: the unpaired 8-byte plane stores
+def test_groupnorm_planes_equal_split_of_fp32_result(B, HW, C, G, silu):
     g = torch.Generator(device=DEV).manual_seed(1)
     x = torch.randn(B * HW, C, device=DEV, generator=g) * 3 + 0.5
     gamma, beta = torch.randn(C, device=DEV, generator=g), torch.randn(C, device=DEV, generator=g)
-    y = L.groupnorm(x, B, HW, gamma, beta, 32, 1e-5, silu)
-    pl = L.groupnorm(x, B, HW, gamma, beta, 32, 1e-5, silu, planes=True)
+    y = L.groupnorm(x, B, HW, gamma, beta, G, 1e-5, silu)
+    pl = L.groupnorm(x, B, HW, gamma, beta, G, 1e-5, silu, planes=True)
     ref = L.split_planes(y)
     assert torch.equal(pl.hi, ref.hi) and torch.equal(pl.lo, ref.lo)
 
 
-@pytest.mark.parametrize("rows,C", [(77, 64), (1024, 320), (130, 1280)])
+@pytest.mark.parametrize("rows,C", [(77, 64), (1024, 320), (130, 1280), (10, 36)])
 def test_layernorm_planes_equal_split_of_fp32_result(rows, C):
     g = torch.Generator(device=DEV).manual_seed(2)
     x = torch.randn(rows, C, device=DEV, generator=g) * 2 - 0.3
