@@ -528,6 +528,90 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
         step(kt + 1, std::integral_constant<int, 1>{});
       }
       if (kt < nk) step(kt, std::integral_constant<int, 0>{});
+    } else if constexpr (APL == 3) {
+      // Mode 2's shape with the WEIGHT operand three LDS stages deep: [A s0 | A s1 | W s0 | W s1 | W s2] (128x320: 2 x 16 KB +
+      // 3 x 40 KB = 152 KB).  At the barrier of k-tile s the activation pieces of tile s + 2 and the weight pieces of tile s + 3
+      // are requested, in that order; the wait in front of the next barrier is a COUNTED vmcnt(NB): everything but the newest NB
+      // pieces (the weight tile that is not needed for another whole k-tile) has landed.  Weights are the cold operand in the
+      // model — every launch streams them from HBM — and now have two k-tiles of latency tolerance like the register-staged loop.
+      constexpr int A_STAGE = NPL * A_BYTES, W_STAGE = NPL * B_BYTES;
+      const uint32_t lds_a3 = lds0 + plane * A_BYTES + pr * 1024;
+      const uint32_t lds_w3 = lds0 + 2 * A_STAGE + plane * B_BYTES + pr * 1024;
+      int kw_next = kt0;                                   // tap / cib / set_tap follow the ACTIVATION tiles
+      auto fill_a = [&](int stage) {
+        const uint32_t so_a = (uint32_t)cib * 2u, la = lds_a3 + stage * A_STAGE;
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+          asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                       :: "s"(la + i * (PAIRS * 1024)), "v"(avoff[i]), "s"(rs_a), "s"(so_a) : "memory");
+        cib += BK;
+        if (cib >= cin) {
+          cib = 0; ++tap;
+          if (conv && tap < ntaps) set_tap(tap);
+        }
+      };
+      auto fill_w = [&](int stage) {
+        const uint32_t so_w = (uint32_t)kw_next * (BK * 2), lw = lds_w3 + stage * W_STAGE;
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+          asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                       :: "s"(lw + i * (PAIRS * 1024)), "v"(bvoff[i]), "s"(rs_w), "s"(so_w) : "memory");
+        ++kw_next;
+      };
+      // stage offsets are RUNTIME scalars (one v_add per fragment read): with compile-time stages the 152 KB image exceeds the
+      // 64 KB reach of the ds_read offset field, the compiler keeps one address register per (stage, fragment) and spills
+      auto ldfrag3 = [&](uint32_t a_off, uint32_t w_off, int ks, Frag& f) {
+        const char* sa = smem + a_off;
+        const char* sb = smem + 2 * A_STAGE + w_off;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          f.ah[i] = *reinterpret_cast<const bf16x8*>(sa + a_ld[ks][i]);
+          f.al[i] = *reinterpret_cast<const bf16x8*>(sa + A_BYTES + a_ld[ks][i]);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          f.bh[j] = *reinterpret_cast<const bf16x8*>(sb + b_ld[ks][j]);
+          f.bl[j] = *reinterpret_cast<const bf16x8*>(sb + B_BYTES + b_ld[ks][j]);
+        }
+      };
+      const bool late = d.splits != 0 && wv >= NW / 2;
+      Frag g0, g1;
+      fill_a(0); fill_w(0);
+      if (nk > 1) { fill_a(1); fill_w(1); }
+      if (nk > 2) fill_w(2);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      ldfrag3(0, 0, 0, g0);
+      uint32_t as = 0, ws = 0;                             // stage INDICES of the current k-tile (kt & 1, kt % 3)
+#pragma unroll 1
+      for (int kt = 0; kt < nk; ++kt) {
+        const uint32_t a_off = as * A_STAGE, w_off = ws * W_STAGE;
+        const uint32_t as_n = as ^ 1, ws_n = ws == 2 ? 0 : ws + 1;
+        ldfrag3(a_off, w_off, 1, g1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(g0, 0, TM * TN);
+        __builtin_amdgcn_sched_barrier(0);
+        // tile kt + 1 (A requested one barrier ago, W two barriers ago) must have landed; the weight tile kt + 2 requested one
+        // barrier ago — the newest NB pieces of this wave — may stay in flight.  lgkmcnt(0): my reads of tile kt's stages returned.
+        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(NB) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (!late) {                                       // activation tile kt + 2, then weight tile kt + 3, into the stages just freed
+          if (kt + 2 < nk) fill_a(as);
+          if (kt + 3 < nk) fill_w(ws);
+        }
+        if (kt + 1 < nk) ldfrag3(as_n * A_STAGE, ws_n * W_STAGE, 0, g0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(g1, 0, (TM * TN) / 2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (late) {
+          if (kt + 2 < nk) fill_a(as);
+          if (kt + 3 < nk) fill_w(ws);
+        }
+        mma(g1, (TM * TN) / 2, TM * TN);
+        __builtin_amdgcn_sched_barrier(0);
+        as = as_n; ws = ws_n;
+      }
     } else {
       // Barrier in the MIDDLE of the k-tile (the register-staged loop's shape): on entry the ks = 0 fragments of tile kt are in
       // registers; its ks = 1 fragments are requested and the ks = 0 MFMAs run under them; then everybody waits for tile kt + 1
@@ -900,7 +984,7 @@ static int launch_bf16(const ddpo_gemm_desc& d, const uint16_t* w_hi, const uint
   splits = (nk_total + ktps - 1) / ktps;
   float* part = splits > 1 ? ws : nullptr;
   constexpr int NPL = (NPASS == 3) ? 2 : 1;
-  size_t lds = 2 * NPL * (size_t)(BM + BN) * 64;
+  size_t lds = (APL == 3) ? NPL * (size_t)(2 * BM + 3 * BN) * 64 : 2 * NPL * (size_t)(BM + BN) * 64;     // APL 3: three weight stages
   if (lds < (size_t)BM * BN * 4) lds = (size_t)BM * BN * 4;     // the epilogue transposes the C tile through LDS
   static bool attr_set = false;
   if (!attr_set) {
@@ -1083,11 +1167,16 @@ extern "C" int ddpo_gemm_conv_fwd_bf16_planes(const ddpo_gemm_desc* dp, const ui
   // DDPO_APL_MODE (tuning knob, read once): 1 = plain two-stage loop (wait, barrier, request, compute); 2 = barrier in the
   // middle of the k-tile with the fragment reads software-pipelined across it; +4 = the upper half of the waves requests its
   // pieces half a k-tile later than the lower half (the two waves of a SIMD then alternate between DMA issue and MFMAs).
-  // Measured on the SD-1.5 layers at batch 16 (profiles/r01_probe_gemm_planes_modes.md): 6 (default) > 1 ~ 2 > fp32-fed.
+  // 3 = mode 2 with the weight operand three LDS stages deep (requested two k-tiles ahead, counted vmcnt); 7 = 3 + stagger.
+  // Measured on the SD-1.5 layers at batch 16 (profiles/r01_probe_gemm_planes_modes.md): 6 (default) > 1 ~ 2 > fp32-fed;
+  // modes 3 / 7 were written after the round's GPU budget was spent and are NOT yet run on hardware.
   static const int apl_mode = [] { const char* e = getenv("DDPO_APL_MODE"); return e ? atoi(e) : 6; }();
   d.splits = (apl_mode & 4) ? 1 : 0;                 // `splits` is a wgrad-only field: the forward kernel reads it as the stagger flag
-  return (apl_mode & 3) == 1 ? dispatch_bf16<1>(d, w_hi, w_lo, ldw, 3, ws, ws_bytes, as_stream(stream))
-                             : dispatch_bf16<2>(d, w_hi, w_lo, ldw, 3, ws, ws_bytes, as_stream(stream));
+  switch (apl_mode & 3) {
+    case 1: return dispatch_bf16<1>(d, w_hi, w_lo, ldw, 3, ws, ws_bytes, as_stream(stream));
+    case 3: return dispatch_bf16<3>(d, w_hi, w_lo, ldw, 3, ws, ws_bytes, as_stream(stream));      // three weight stages (7 = + stagger)
+    default: return dispatch_bf16<2>(d, w_hi, w_lo, ldw, 3, ws, ws_bytes, as_stream(stream));
+  }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -8,6 +8,10 @@ P=tools/native/kernel_probe
 timeout 60 $P ppo > gpurun_out/probe_ppo.log 2>&1; echo "exit $?" >> gpurun_out/probe_ppo.log; tail -3 gpurun_out/probe_ppo.log
 timeout 120 $P gemm ${PROBE_BATCH:-16} ${PROBE_ITERS:-10} > gpurun_out/probe_gemm.log 2>&1; echo "exit $?" >> gpurun_out/probe_gemm.log; tail -4 gpurun_out/probe_gemm.log
 timeout 120 $P attn ${PROBE_BATCH:-16} ${PROBE_ITERS:-10} > gpurun_out/probe_attn.log 2>&1; echo "exit $?" >> gpurun_out/probe_attn.log; tail -4 gpurun_out/probe_attn.log
+# every k-loop variant of the plane-fed kernel (bitwise check against the fp32-fed kernel + timings)
+for m in ${PROBE_APL_MODES:-}; do
+  DDPO_APL_MODE=$m timeout 120 $P gemm2 ${PROBE_BATCH:-16} ${PROBE_ITERS:-10} > gpurun_out/probe_gemm2_mode$m.log 2>&1; echo "exit $?" >> gpurun_out/probe_gemm2_mode$m.log; tail -2 gpurun_out/probe_gemm2_mode$m.log
+done
 for kv in ${PROBE_KNOBS:-}; do
   env $kv timeout 120 $P gemm ${PROBE_BATCH:-16} ${PROBE_ITERS:-10} > gpurun_out/probe_gemm_${kv//[^A-Za-z0-9_=]/_}.log 2>&1
 done
