@@ -528,6 +528,31 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
         step(kt + 1, std::integral_constant<int, 1>{});
       }
       if (kt < nk) step(kt, std::integral_constant<int, 0>{});
+    } else if constexpr (APL == 4) {
+      // Plain schedule for the TALL 256x320 tile (64 x 160 per wave: 160 accumulator registers leave room for ONE fragment set;
+      // the second wave of the SIMD covers the LDS latency).  28 fragment reads and 9 LDS-DMA pieces feed 60 MFMAs per wave and
+      // k-tile, against 24 + 7 for 30 MFMAs on the 128x320 tile: 36 % fewer L2 and 42 % fewer LDS bytes per MFMA.
+      const bool late = d.splits != 0 && wv >= NW / 2;
+      auto step4 = [&](int kt, auto cur_c) {
+        constexpr int cur = decltype(cur_c)::value;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 1 < nk && !late) fill(cur ^ 1);
+        Frag g;
+        ldfrag(cur, 0, g);
+        mma(g, 0, TM * TN);
+        if (kt + 1 < nk && late) fill(cur ^ 1);
+        ldfrag(cur, 1, g);
+        mma(g, 0, TM * TN);
+      };
+      fill(0);
+      int kt = 0;
+#pragma unroll 1
+      for (; kt + 1 < nk; kt += 2) {
+        step4(kt, std::integral_constant<int, 0>{});
+        step4(kt + 1, std::integral_constant<int, 1>{});
+      }
+      if (kt < nk) step4(kt, std::integral_constant<int, 0>{});
     } else if constexpr (APL == 3) {
       // Mode 2's shape with the WEIGHT operand three LDS stages deep: [A s0 | A s1 | W s0 | W s1 | W s2] (128x320: 2 x 16 KB +
       // 3 x 40 KB = 152 KB).  At the barrier of k-tile s the activation pieces of tile s + 2 and the weight pieces of tile s + 3
@@ -825,7 +850,53 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
                       (!d.residual || ((d.ld_res & 3) == 0 && (reinterpret_cast<uintptr_t>(d.residual) & 15) == 0)) &&
                       (!d.rowbias || ((d.ld_rowbias & 3) == 0 && (reinterpret_cast<uintptr_t>(d.rowbias) & 15) == 0)) &&
                       (!d.bias || (reinterpret_cast<uintptr_t>(d.bias) & 15) == 0);
-  if (vec_ok && !(ABL & 16)) {
+  if constexpr (BM == 256) {
+    // tall tile: the wave sub-tile (64 x 160 fp32 = 40 KB) does not fit an eighth of the LDS, so it is transposed and stored in
+    // TM passes of 32 rows through a 20 KB wave-private slice (in-order LDS access within the wave: no barrier between passes)
+    if (vec_ok) {
+      constexpr int LPR = WTN / 4;
+      constexpr int NIT = 32 * LPR / 64;
+      static_assert((32 * LPR) % 64 == 0, "32-row pass must be a whole number of wave instructions");
+      __syncthreads();
+      float* cw = reinterpret_cast<float*>(smem) + wid * (32 * WTN);
+      float* pp = part ? part + (int64_t)blockIdx.y * d.M * d.N : nullptr;
+#pragma unroll
+      for (int ih = 0; ih < TM; ++ih) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            cw[((r & 3) + 8 * (r >> 2) + 4 * khalf) * WTN + j * 32 + (lane & 31)] = acc[ih][j][r];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          const int e = it * 64 + lane;
+          const int rr = e / LPR, lcol = (e - rr * LPR) * 4;
+          const int row = m0 + wm * WTM + ih * 32 + rr;
+          const int col = n0 + wn * WTN + lcol;
+          if (row >= d.M || col >= d.N) continue;
+          float4 v = *reinterpret_cast<const float4*>(cw + rr * WTN + lcol);
+          if (pp) {
+            *reinterpret_cast<float4*>(pp + (int64_t)row * d.N + col) = v;
+            continue;
+          }
+          float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (d.bias) bv = *reinterpret_cast<const float4*>(d.bias + col);
+          v.x = d.alpha * v.x + bv.x; v.y = d.alpha * v.y + bv.y; v.z = d.alpha * v.z + bv.z; v.w = d.alpha * v.w + bv.w;
+          if (d.rowbias) {
+            const float4 rb = *reinterpret_cast<const float4*>(d.rowbias + (int64_t)(row / d.rows_per_batch) * d.ld_rowbias + col);
+            v.x += rb.x; v.y += rb.y; v.z += rb.z; v.w += rb.w;
+          }
+          if (d.residual) {
+            const float4 rs = *reinterpret_cast<const float4*>(d.residual + (int64_t)row * d.ld_res + col);
+            v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w;
+          }
+          *reinterpret_cast<float4*>(d.out + (int64_t)row * d.ld_out + col) = v;
+        }
+      }
+      return;
+    }
+  }
+  if (vec_ok && !(ABL & 16) && BM != 256) {
     constexpr int LPR = WTN / 4;                 // float4 per row of the wave sub-tile (WTM rows x WTN columns)
     constexpr int NIT = WTM * LPR / 64;          // wave instructions to move it
     static_assert((WTM * LPR) % 64 == 0, "wave sub-tile must be a whole number of 1 KiB rows");
@@ -1064,6 +1135,26 @@ static int launch_bf16_wide(const ddpo_gemm_desc& d, const uint16_t* w_hi, const
   return DDPO_OK;
 }
 
+// Tall 256x320 tiles (plane-fed path only, 8 waves of 64x160, one workgroup per CU, plain k-loop APL = 4): for layers whose tile
+// grid still covers the chip — the 64x64-latent level of the U-Net (M = 65536: 256 tiles per 320 columns).  No split-K.
+static int launch_bf16_tall(const ddpo_gemm_desc& d, const uint16_t* w_hi, const uint16_t* w_lo, int ldw, hipStream_t st) {
+  constexpr int BM = 256, BN = 320, WM = 4, WN = 2;
+  const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;
+  const int nblk = tiles_m * tiles_n;
+  const int nk_total = d.K / BF_BK;
+  const size_t lds = 8 * 32 * 160 * 4;                     // epilogue slices (160 KB) > 2 stages of operand tiles (144 KB)
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_bf16_buf_kernel<BM, BN, 3, 0, WM, WN, true, 4>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_conv_bf16_buf_kernel<BM, BN, 3, 0, WM, WN, true, 4>), dim3(nblk, 1), dim3(64 * WM * WN), lds, st, d, w_hi, w_lo, ldw,
+                     tiles_m, tiles_n, nblk, nk_total, (float*)nullptr);
+  DDPO_LAUNCH_CHECK();
+  return DDPO_OK;
+}
+
 // timing ablations of the 128x128 bf16x3 k-loop (results are WRONG for mode != 0); used by tools/ablate_gemm.py only
 template <int ABL>
 static void launch_abl(const ddpo_gemm_desc& d, const uint16_t* w_hi, const uint16_t* w_lo, int ldw, hipStream_t st) {
@@ -1109,6 +1200,12 @@ static int dispatch_bf16(const ddpo_gemm_desc& d, const uint16_t* w_hi, const ui
   static const int wide_mode = [] { const char* e = getenv("DDPO_GEMM_WIDE"); return e ? atoi(e) : 1; }();   // tuning knob: 0 disables 128x320
   // 128x320 tiles (one workgroup per CU) when they, times the split of the reduction, give every CU a workgroup; a
   // many-column GEMM with a very short reduction is better on 128x128 (measured: K=320, N=2560; the 160 KB epilogue image)
+  if constexpr (APL != 0) {
+    // DDPO_APL_TALL=1 (tuning knob, NOT yet run on hardware): 256x320 tiles where they still give every CU a workgroup
+    static const int tall_mode = [] { const char* e = getenv("DDPO_APL_TALL"); return e ? atoi(e) : 0; }();
+    if (tall_mode && d.N % 320 == 0 && d.epilogue == 0 && (long)((d.M + 255) / 256) * (d.N / 320) >= 200)
+      return launch_bf16_tall(d, w_hi, w_lo, ldw, st);
+  }
   const int wsplits = wide_splits(d, wsf != nullptr, ws_bytes);
   if (wide_mode && d.N % 320 == 0 && d.M >= 512 && buf_path_ok(d, ldw) && !(d.K / BF_BK < 16 && d.N > 1280) &&
       (long)((d.M + 127) / 128) * (d.N / 320) * wsplits >= 200 &&
