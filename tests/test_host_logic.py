@@ -141,3 +141,32 @@ def test_byte_tokenizer_framing():
     ids = t(["a cat", ""], padding="max_length", max_length=77, truncation=True, return_tensors="np").input_ids
     assert ids.shape == (2, 77) and ids[0, 0] == 49406 and (ids[1, 1:] == 49407).all()
     assert t.batch_decode(ids) == ["a cat", ""] and np.array_equal(make_uncond_text(t, 1)[0], ids[1])
+
+
+@pytest.mark.parametrize("BM,BN,NW", [(128, 320, 8), (128, 128, 4), (128, 64, 4), (256, 320, 8)])
+def test_lds_dma_piece_map_reproduces_the_swizzled_lds_image(BM, BN, NW):
+    """Index algebra of the plane-fed GEMM's operand fill (csrc/gemm_bf16.hip, APL path), modelled lane by lane: every
+    16-byte slot of every tile row is written exactly once per plane, by the lane whose SOURCE chunk is the one swz_off()
+    places there (LDS-DMA writes lane-linearly: 64 lanes x 16 B = 16 rows x 64 B per wave instruction)."""
+    PAIRS = NW // 2
+    for rows, base in ((BM, 0), (BN, 2 * BM * 64)):              # A planes, then W planes: [hi | lo] each, 64 B per row
+        G = rows // 16
+        assert G % PAIRS == 0
+        pieces = G // PAIRS
+        plane_bytes = rows * 64
+        seen = {}
+        for w in range(NW):
+            plane, pr = w & 1, w >> 1
+            for i in range(pieces):
+                lds_piece = base + plane * plane_bytes + pr * 1024 + i * PAIRS * 1024
+                for lane in range(64):
+                    src_row = 16 * (pr + PAIRS * i) + (lane >> 2)
+                    src_chunk = (lane & 3) ^ ((lane >> 4) & 3)
+                    addr = lds_piece + lane * 16                                  # lane-linear destination
+                    off = addr - base - plane * plane_bytes
+                    row, slot = off // 64, (off % 64) // 16
+                    assert row == src_row
+                    assert slot == src_chunk ^ ((row >> 2) & 3)                   # == swz_off(row, chunk)
+                    assert (plane, row, slot) not in seen
+                    seen[(plane, row, slot)] = (w, lane)
+        assert len(seen) == 2 * rows * 4
