@@ -55,37 +55,47 @@ def parse():
 
 
 def cpu_baseline(args):
-    """Times the oracle restatement (torch CPU, all host cores) on ONE CFG denoising step of ONE image
-    (U-Net batch 2 at the benchmark resolution), then scales by the analytic FLOP count of a full image."""
+    """Times the oracle restatement (torch CPU, all host cores) on a bounded sample of the benchmark workload: ONE classifier-free
+    guidance step of one image (the U-Net on a batch of 2 at the benchmark resolution, as the sampler runs it) and ONE VAE decode
+    of one image — about 10-30 s of CPU work on the GPU box — and assembles seconds/image = T x step + decode."""
     from oracle import unet as OU
     cores = min(os.cpu_count() or 1, 32)      # torch-CPU stops scaling (and oversubscribes) beyond a few dozen threads
     torch.set_num_threads(cores)
     cfg = OU.SD15 if args.model == "sd15" else OU.TINY
+    vcfg = OU.VAE_SD if args.model == "sd15" else OU.VAE_TINY
     g = torch.Generator().manual_seed(0)
-    params = {}
-    for name, shp in OU.unet_param_shapes(cfg).items():
-        fan = int(np.prod(shp[:-1])) if name.endswith(".kernel") else 1
-        params[name] = torch.randn(shp, generator=g) / (fan ** 0.5) if name.endswith(".kernel") else \
-            (torch.ones(shp) if name.endswith(".scale") else torch.zeros(shp))
+
+    def synth(shapes):
+        params = {}
+        for name, shp in shapes.items():
+            fan = int(np.prod(shp[:-1])) if name.endswith(".kernel") else 1
+            params[name] = torch.randn(shp, generator=g) / (fan ** 0.5) if name.endswith(".kernel") else \
+                (torch.ones(shp) if name.endswith(".scale") else torch.zeros(shp))
+        return params
+    params = synth(OU.unet_param_shapes(cfg))
     hw = args.resolution // 8
     x = torch.randn(1, 4, hw, hw, generator=g)
-    ctx = torch.randn(1, 77, cfg.cross_attention_dim, generator=g)
-    t = torch.full((1,), 481, dtype=torch.int32)
+    ctx = torch.randn(2, 77, cfg.cross_attention_dim, generator=g)
+    t = torch.full((2,), 481, dtype=torch.int32)
     t0 = time.perf_counter()
     with torch.no_grad():
-        OU.unet_forward(params, cfg, x, t, ctx)
-    dt = 2.0 * (time.perf_counter() - t0)       # a CFG step is two such forwards (uncond + cond)
+        OU.unet_forward(params, cfg, torch.cat([x, x]), t, ctx)          # [uncond; cond] in one batch, like the sampler
+    dt = time.perf_counter() - t0
+    del params
+    vparams = synth(OU.vae_decoder_param_shapes(vcfg))
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        OU.vae_decode(vparams, vcfg, x)
+    dt_vae = time.perf_counter() - t0
     T = args.n_inference_steps
+    per_image = dt * T + dt_vae
+    gflops = None
     if args.model == "sd15" and hw == 64:
-        per_image = dt * T * (1.0 + VAE_TFLOP["sd15"] / (T * 2 * UNET_FWD_TFLOP["sd15"]))
-        gflops = 2 * UNET_FWD_TFLOP["sd15"] * 1e3 / dt
-    else:
-        per_image = dt * T
-        gflops = None
+        gflops = (2 * UNET_FWD_TFLOP["sd15"] + VAE_TFLOP["sd15"]) * 1e3 / (dt + dt_vae)
     return {"value": 1.0 / per_image, "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"one oracle U-Net forward (batch 1, {hw}x{hw} latents) timed, x2 for a CFG step = {dt:.2f} s on "
-                      f"{cores} torch-CPU threads; x{T} steps + VAE decode scaled by analytic FLOPs",
-            "seconds_per_cfg_step": dt, "cpu_gflops": gflops}
+            "sample": f"oracle (torch CPU, {cores} threads): one CFG step of one image (U-Net on a batch of 2, {hw}x{hw} latents) = {dt:.2f} s, "
+                      f"one VAE decode to {args.resolution}x{args.resolution} = {dt_vae:.2f} s; seconds/image = {T} x step + decode",
+            "seconds_per_cfg_step": dt, "seconds_per_vae_decode": dt_vae, "cpu_gflops": gflops}
 
 
 def bench_train(args, world, rank, dev, dist, unet, sched, state, emb, neg):
