@@ -119,3 +119,44 @@ def save_checkpoint(ckpt_dir, params, step, resume_state=None, flax_format=True)
     if resume_state is not None:
         torch.save(resume_state, os.path.join(ckpt_dir, f"resume_{step}.pt"))
     return path
+
+
+def save_rank_resume(ckpt_dir, step, rank, rank_state):
+    """Per-rank part of a resumable checkpoint (host RNG streams and the JAX-style sampling key of THIS rank; the shared part —
+    parameters, optimizer moments, tracker, reward history — is rank 0's `resume_<step>.pt`)."""
+    os.makedirs(ckpt_dir, exist_ok=True)
+    torch.save(rank_state, os.path.join(ckpt_dir, f"resume_{step}.rank{rank}.pt"))
+
+
+def load_resume(ckpt_dir, rank=0, epoch=None):
+    """Everything `pipeline/policy_gradient.py` needs to continue a run after epoch `epoch` (default: the latest one that has a
+    resume bundle).  The reference cannot resume at all (/root/reference/pipeline/policy_gradient.py:97-103 never loads): this is
+    an addition, switched on with DDPO_RESUME=<run>/checkpoints.  Returns a dict: epoch, params_path (safetensors or flax file),
+    opt_count, mu, nu, tracker, mean_rewards, std_rewards, wall, and — when the rank file exists — sample_rng, py_random,
+    np_random."""
+    if not os.path.isdir(ckpt_dir):
+        raise FileNotFoundError(f"no checkpoint directory {ckpt_dir}")
+    if epoch is None:
+        steps = sorted(int(f[len("resume_"):-len(".pt")]) for f in os.listdir(ckpt_dir)
+                       if f.startswith("resume_") and f.endswith(".pt") and ".rank" not in f)
+        if not steps:
+            raise FileNotFoundError(f"no resume_<epoch>.pt in {ckpt_dir}")
+        epoch = steps[-1]
+    epoch = int(epoch)
+    out = dict(torch.load(os.path.join(ckpt_dir, f"resume_{epoch}.pt"), map_location="cpu", weights_only=False))
+    out["epoch"] = epoch
+    st = os.path.join(ckpt_dir, f"checkpoint_{epoch}.safetensors")
+    out["params_path"] = st if os.path.exists(st) else os.path.join(ckpt_dir, f"checkpoint_{epoch}")
+    rf = os.path.join(ckpt_dir, f"resume_{epoch}.rank{rank}.pt")
+    if os.path.exists(rf):
+        out.update(torch.load(rf, map_location="cpu", weights_only=False))
+    return out
+
+
+def load_params_file(store, path):
+    """Fill a ParamStore from a `checkpoint_<epoch>.safetensors` or flax-msgpack `checkpoint_<epoch>` file."""
+    if path.endswith(".safetensors"):
+        _load_safetensors_into(store, path)
+    else:
+        from .flax_msgpack import load_flax_checkpoint
+        store.load_dict(load_flax_checkpoint(path))

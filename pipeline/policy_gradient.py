@@ -19,6 +19,7 @@ gradients are all-reduced once per optimizer update instead of every micro-step 
 """
 import json
 import os
+import random
 import sys
 import time
 from concurrent import futures
@@ -35,7 +36,7 @@ from ddpo_amd.training import distributed as D
 from ddpo_amd.training.policy_gradient import (AccumulatingTrainState, AdamWConfig, train_fuse_default, train_step,
                                                train_steps_fused)
 from ddpo_amd.utils import prng
-from ddpo_amd.utils.serialization import load_unet, save_checkpoint
+from ddpo_amd.utils.serialization import load_params_file, load_resume, load_unet, save_checkpoint, save_rank_resume
 from ddpo_amd.utils.stat_tracking import PerPromptStatTracker
 from ddpo_amd.models.text import make_uncond_text
 
@@ -122,7 +123,30 @@ def main(argv=None):
 
     mean_rewards, std_rewards, wall = [], [], []
     t_start = time.time()
-    for epoch in range(args.num_train_epochs):
+    start_epoch = 0
+    if os.environ.get("DDPO_RESUME"):
+        # not in the reference (it never loads a policy-gradient run): continue from <run>/checkpoints — parameters, AdamW moments
+        # and count, the sampling key, the host RNG streams of this rank, the per-prompt tracker and the reward history
+        rs = load_resume(os.environ["DDPO_RESUME"], worker_id, os.environ.get("DDPO_RESUME_EPOCH"))
+        load_params_file(state.params, rs["params_path"])
+        if L.DATAPATH != "fp32":
+            state.params.pack_bf16()
+        state.opt_state["mu"].copy_(rs["mu"])
+        state.opt_state["nu"].copy_(rs["nu"])
+        state.opt_state["count"] = state.step = int(rs["opt_count"])
+        if "sample_rng" in rs:
+            sample_rng = rs["sample_rng"]
+        if "py_random" in rs:
+            random.setstate(rs["py_random"])
+            np.random.set_state(rs["np_random"])
+        if per_prompt_stats is not None and rs.get("tracker") is not None:
+            per_prompt_stats.load_state_dict(rs["tracker"])
+        mean_rewards, std_rewards, wall = list(rs.get("mean_rewards", [])), list(rs.get("std_rewards", [])), list(rs.get("wall", []))
+        if wall:
+            t_start -= wall[-1]
+        start_epoch = rs["epoch"] + 1
+        print(f"[ policy_gradient ] resumed from {rs['params_path']} (epoch {rs['epoch']}, {state.step} optimizer updates)")
+    for epoch in range(start_epoch, args.num_train_epochs):
         samples = []
         for i in range(args.num_sample_batches_per_epoch):
             # ----------------------------- make prompts ----------------------------- #
@@ -234,10 +258,13 @@ def main(argv=None):
                 np.save(utils.fs.join_and_create(localpath, f"train_info/{worker_id}_{epoch}_{inner_epoch}.npy"), all_infos)
 
         if (epoch + 1) % args.save_freq == 0 or epoch == args.num_train_epochs - 1:
+            save_rank_resume(os.path.join(args.savepath, "checkpoints"), epoch, worker_id,
+                             {"sample_rng": sample_rng, "py_random": random.getstate(), "np_random": np.random.get_state()})
             if worker_id == 0:
                 resume = {"epoch": epoch, "opt_count": state.opt_state["count"], "mu": state.opt_state["mu"].cpu(),
                           "nu": state.opt_state["nu"].cpu(), "sample_rng": sample_rng,
-                          "tracker": None if per_prompt_stats is None else per_prompt_stats.state_dict()}
+                          "tracker": None if per_prompt_stats is None else per_prompt_stats.state_dict(),
+                          "mean_rewards": list(mean_rewards), "std_rewards": list(std_rewards), "wall": list(wall)}
                 save_checkpoint(os.path.join(args.savepath, "checkpoints"), state.params, step=epoch, resume_state=resume)
             D.barrier()
 

@@ -5,6 +5,7 @@ from flax 0.6.9 `serialization.msgpack_serialize`, see ddpo_amd/utils/flax_msgpa
 import os
 
 import msgpack
+import pytest
 import numpy as np
 
 from ddpo_amd.utils import flax_msgpack as FM
@@ -71,3 +72,39 @@ def test_save_checkpoint_formats_and_load_unet_paths(tmp_path, monkeypatch):
     for loadpath in (d1, d2, "flax:" + d2, "flax:" + os.path.join(d2, "checkpoint_9")):
         _, params = load_unet(loadpath, pretrained_model="none", device="cpu")
         assert all(torch.equal(params["unet"][n], store[n]) for n in store.views), loadpath
+
+
+def test_resume_bundle_round_trip(tmp_path):
+    """The resumable part of a checkpoint (an addition: the reference never reloads a policy-gradient run): rank 0's shared bundle
+    + one small file per rank with that rank's host RNG streams and sampling key; `load_resume` picks the latest epoch, finds the
+    parameter file (safetensors or flax) and restores RNG streams that continue exactly where they were saved."""
+    import random
+    import numpy as np
+    import torch
+    from ddpo_amd.utils.serialization import load_resume, save_rank_resume
+    ck = str(tmp_path / "checkpoints")
+    os.makedirs(ck)
+    random.seed(5); np.random.seed(6)
+    random.random(); np.random.permutation(7)
+    for epoch in (0, 3):
+        torch.save({"epoch": epoch, "opt_count": 4 * (epoch + 1), "mu": torch.zeros(3, dtype=torch.bfloat16), "nu": torch.ones(3),
+                    "sample_rng": np.asarray([1, 2], dtype=np.uint32), "tracker": {"a dog": [[0.5, 1.0]]},
+                    "mean_rewards": [0.1] * (epoch + 1), "std_rewards": [0.2] * (epoch + 1), "wall": [10.0 * (epoch + 1)]},
+                   os.path.join(ck, f"resume_{epoch}.pt"))
+    open(os.path.join(ck, "checkpoint_3"), "wb").close()                    # flax-format file only for epoch 3
+    open(os.path.join(ck, "checkpoint_0.safetensors"), "wb").close()
+    for rank in (0, 1):
+        save_rank_resume(ck, 3, rank, {"sample_rng": np.asarray([7 + rank, 9], dtype=np.uint32), "py_random": random.getstate(),
+                                       "np_random": np.random.get_state()})
+    expect = (random.random(), np.random.permutation(5).tolist())
+    random.seed(0); np.random.seed(0)
+    rs = load_resume(ck, rank=1)
+    assert rs["epoch"] == 3 and rs["opt_count"] == 16 and rs["params_path"].endswith("checkpoint_3")
+    assert rs["sample_rng"].tolist() == [8, 9] and rs["mu"].dtype == torch.bfloat16 and rs["wall"] == [40.0]
+    random.setstate(rs["py_random"]); np.random.set_state(rs["np_random"])
+    assert (random.random(), np.random.permutation(5).tolist()) == expect
+    rs0 = load_resume(ck, rank=0, epoch="0")
+    assert rs0["epoch"] == 0 and rs0["params_path"].endswith("checkpoint_0.safetensors") and "py_random" not in rs0
+    assert rs0["sample_rng"].tolist() == [1, 2]                             # no rank file for epoch 0: the shared bundle's key
+    with pytest.raises(FileNotFoundError):
+        load_resume(str(tmp_path / "nothing"))

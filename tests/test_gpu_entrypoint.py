@@ -91,3 +91,29 @@ def test_entrypoint_llava_bertscore_with_stub_server(tmp_path, monkeypatch):
         assert out["state"].step == 1                                   # 2 minibatches of 1, accumulation 2 -> one update
     finally:
         srv.shutdown()
+
+
+@pytest.mark.skipif(os.environ.get("DDPO_EXPERIMENTAL") != "1", reason="DDPO_RESUME was written after the round-1 GPU budget was spent: set DDPO_EXPERIMENTAL=1")
+def test_entrypoint_resume_continues_the_run(tmp_path, monkeypatch):
+    """One epoch, stop, resume for the second epoch (DDPO_RESUME) == two epochs in one go: same prompts and noise (host RNG
+    streams and the sampling key are part of the bundle), rewards and final weights equal up to the atomics' fp32 noise."""
+    monkeypatch.setenv("DDPO_MODEL_CONFIG", "tiny")
+    monkeypatch.chdir(tmp_path)
+    sys.path.insert(0, ROOT)
+    import importlib
+    pg = importlib.import_module("pipeline.policy_gradient")
+    from safetensors.torch import load_file
+    flags = [f for f in FLAGS]
+    straight = pg.main(flags + ["--logbase", str(tmp_path / "a")])
+    one = [("1" if flags[i - 1] == "--num_train_epochs" else f) for i, f in enumerate(flags)]
+    pg.main(one + ["--logbase", str(tmp_path / "b")])
+    monkeypatch.setenv("DDPO_RESUME", os.path.join(str(tmp_path / "b"), "models/pg/checkpoints"))
+    resumed = pg.main(flags + ["--logbase", str(tmp_path / "b")])
+    assert len(resumed["mean_rewards"]) == 2
+    assert resumed["mean_rewards"][0] == straight["mean_rewards"][0]
+    assert resumed["mean_rewards"][1] == pytest.approx(straight["mean_rewards"][1], rel=1e-3)
+    wa = load_file(os.path.join(str(tmp_path / "a"), "models/pg/checkpoints/checkpoint_1.safetensors"))
+    wb = load_file(os.path.join(str(tmp_path / "b"), "models/pg/checkpoints/checkpoint_1.safetensors"))
+    num = sum(float((wa[k].double() - wb[k].double()).pow(2).sum()) for k in wa)
+    den = sum(float((wa[k].double()).pow(2).sum()) for k in wa)
+    assert (num / den) ** 0.5 < 1e-4
