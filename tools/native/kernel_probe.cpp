@@ -6,6 +6,8 @@
 //
 //   kernel_probe gemm [batch=16] [iters=10]     bf16x3 implicit-GEMM conv / dense shapes of one SD-1.5 U-Net forward
 //   kernel_probe gemm2 [batch=16] [iters=10]    plane-fed (LDS-DMA) kernel vs the fp32-fed one: timing + bitwise comparison
+//                                               PROBE_COLD=1: flush the caches before every timed launch and re-read only the
+//                                               activations (weights cold, as in the model)
 //   kernel_probe attn [batch=16] [iters=10]     bf16x3 / fp32 flash-attention shapes of the same forward
 //   kernel_probe ppo                            scoring-mode log-prob + PPO-clip + grouped micro-batches vs a host loop
 //
@@ -82,6 +84,43 @@ static float time_ms(int iters, const std::function<void()>& fn) {
   HIP_OK(hipEventDestroy(e0)); HIP_OK(hipEventDestroy(e1));
   return ms / iters;
 }
+
+// "In-model" timing (PROBE_COLD=1): before every timed launch the caches are flushed (768 MB streamed through L2 and the
+// 256 MB Infinity Cache) and the ACTIVATION buffers are read back in — in the model the activations were just written by the
+// previous kernel while the layer's weights come from HBM on every launch.  Only the launch itself is inside the event pair.
+__global__ void warm_kernel(const uint4* p, int64_t n16, unsigned int* sink) {
+  unsigned int acc = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint4 v = p[i];
+    acc ^= v.x ^ v.y ^ v.z ^ v.w;
+  }
+  if (acc == 0x12345678u) *sink = acc;
+}
+struct WarmBuf { const void* p; size_t bytes; };
+static float time_cold_ms(int iters, const std::function<void()>& fn, const std::vector<WarmBuf>& warm) {
+  static float* flush = nullptr;
+  static unsigned int* sink = nullptr;
+  const int64_t flush_n = (int64_t)768 << 18;          // 768 MB of floats
+  if (!flush) { HIP_OK(hipMalloc(&flush, flush_n * 4)); HIP_OK(hipMalloc(&sink, 4)); }
+  hipEvent_t e0, e1;
+  HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+  fn();
+  double total = 0.0;
+  for (int i = 0; i < iters; ++i) {
+    hipLaunchKernelGGL(fill_kernel, dim3(2048), dim3(256), 0, 0, flush, flush_n, 99u + i, 1.0f);
+    for (const WarmBuf& w : warm) hipLaunchKernelGGL(warm_kernel, dim3(1024), dim3(256), 0, 0, (const uint4*)w.p, (int64_t)(w.bytes / 16), sink);
+    HIP_OK(hipEventRecord(e0, 0));
+    fn();
+    HIP_OK(hipEventRecord(e1, 0));
+    HIP_OK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+    total += ms;
+  }
+  HIP_OK(hipEventDestroy(e0)); HIP_OK(hipEventDestroy(e1));
+  return (float)(total / iters);
+}
+static bool probe_cold() { const char* e = getenv("PROBE_COLD"); return e && atoi(e) != 0; }
 
 // ------------------------------------------------------------------------------------------------ gemm / conv
 struct ConvCase { int H, Cin, Cout, ks, stride, ups; };      // square H x H source, pad = ks / 2; ks == 0: dense with M = B*H rows
@@ -203,12 +242,17 @@ static void run_gemm2(int B, int H, int Cin, int Cout, int ks, int stride, int u
   if (conv) { d.ksize = ks; d.stride = stride; d.pad = pad; d.upsample = ups; d.B = B; d.H = H; d.W = H; d.Cin = Cin; d.OH = OH; d.OW = OH; }
   ddpo_gemm_desc d1 = d, d2 = d;
   d1.out = out1; d2.out = out2;
-  const float ms1 = time_ms(iters, [&] { ABI_OK(ddpo_gemm_conv_fwd_bf16(&d1, hi, lo, Kp, 3, ws, ws_bytes, nullptr)); });
+  const bool cold = probe_cold();
+  const std::vector<WarmBuf> warm1 = {{src.p, (size_t)arows * acols * 4}, {res.p, (size_t)M * N * 4}};
+  const std::vector<WarmBuf> warm2 = {{ah, (size_t)arows * acols * 2}, {al, (size_t)arows * acols * 2}, {res.p, (size_t)M * N * 4}};
+  auto f1 = [&] { ABI_OK(ddpo_gemm_conv_fwd_bf16(&d1, hi, lo, Kp, 3, ws, ws_bytes, nullptr)); };
+  const float ms1 = cold ? time_cold_ms(iters, f1, warm1) : time_ms(iters, f1);
   const int rc = ddpo_gemm_conv_fwd_bf16_planes(&d2, ah, al, acols, hi, lo, Kp, ws, ws_bytes, nullptr);
   if (rc != DDPO_OK) {
     printf("%s K=%d N=%d: plane-fed entry returned %d (layer stays on the fp32-fed kernel)\n", conv ? "conv" : "gemm", K, N, rc);
   } else {
-    const float ms2 = time_ms(iters, [&] { ABI_OK(ddpo_gemm_conv_fwd_bf16_planes(&d2, ah, al, acols, hi, lo, Kp, ws, ws_bytes, nullptr)); });
+    auto f2 = [&] { ABI_OK(ddpo_gemm_conv_fwd_bf16_planes(&d2, ah, al, acols, hi, lo, Kp, ws, ws_bytes, nullptr)); };
+    const float ms2 = cold ? time_cold_ms(iters, f2, warm2) : time_ms(iters, f2);
     unsigned long long* cnt = (unsigned long long*)dalloc(8);
     float* mx = (float*)dalloc(4);
     hipLaunchKernelGGL(diff_kernel, dim3(1024), dim3(256), 0, 0, out1, out2, M * N, cnt, mx);
@@ -399,9 +443,11 @@ int main(int argc, char** argv) {
   const int B = argc > 2 ? atoi(argv[2]) : 16, iters = argc > 3 ? atoi(argv[3]) : 10;
   hipDeviceProp_t prop;
   HIP_OK(hipGetDeviceProperties(&prop, 0));
-  printf("# %s (%s, %d CUs), libddpo_hip ABI v%d, mode %s, batch %d, DDPO_GEMM_WIDE=%s DDPO_GEMM_BIG_MIN=%s\n", prop.name, prop.gcnArchName,
-         prop.multiProcessorCount, ddpo_abi_version(), mode.c_str(), B, getenv("DDPO_GEMM_WIDE") ? getenv("DDPO_GEMM_WIDE") : "-",
-         getenv("DDPO_GEMM_BIG_MIN") ? getenv("DDPO_GEMM_BIG_MIN") : "-");
+  printf("# %s (%s, %d CUs), libddpo_hip ABI v%d, mode %s, batch %d, DDPO_GEMM_WIDE=%s DDPO_GEMM_BIG_MIN=%s DDPO_APL_MODE=%s DDPO_APL_TALL=%s PROBE_COLD=%s\n",
+         prop.name, prop.gcnArchName, prop.multiProcessorCount, ddpo_abi_version(), mode.c_str(), B,
+         getenv("DDPO_GEMM_WIDE") ? getenv("DDPO_GEMM_WIDE") : "-", getenv("DDPO_GEMM_BIG_MIN") ? getenv("DDPO_GEMM_BIG_MIN") : "-",
+         getenv("DDPO_APL_MODE") ? getenv("DDPO_APL_MODE") : "-", getenv("DDPO_APL_TALL") ? getenv("DDPO_APL_TALL") : "-",
+         getenv("PROBE_COLD") ? getenv("PROBE_COLD") : "-");
   int rc;
   if (mode == "gemm") rc = probe_gemm(B, iters);
   else if (mode == "gemm2") rc = probe_gemm2(B, iters);
