@@ -643,6 +643,10 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
       // to have landed and for its own reads of tile kt's stage to have returned, the barrier publishes both facts, tile kt + 2 is
       // requested into the stage just freed, the ks = 0 fragments of tile kt + 1 are requested and the ks = 1 MFMAs run under them.
       const bool late = d.splits != 0 && wv >= NW / 2;          // staggered request (see DDPO_APL_MODE)
+      // APL == 5: the same loop with s_setprio 1 around the MFMA clusters — with the staggered request the two waves of a SIMD
+      // are in different phases (one issuing LDS-DMA / fragment reads, one in MFMAs), which is when the priority hint has
+      // something to arbitrate (programming guide T5).  A separate instantiation, so APL == 2's code is untouched.
+      constexpr bool PRIO = (APL == 5);
       Frag g0, g1;
       fill(0);
       if (nk > 1) fill(1);
@@ -653,17 +657,23 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
         constexpr int cur = decltype(cur_c)::value;
         ldfrag(cur, 1, g1);
         __builtin_amdgcn_sched_barrier(0);
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
         mma(g0, 0, TM * TN);
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (kt + 2 < nk && !late) fill(cur);
         if (kt + 1 < nk) ldfrag(cur ^ 1, 0, g0);
         __builtin_amdgcn_sched_barrier(0);
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
         mma(g1, 0, (TM * TN) / 2);
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         if (kt + 2 < nk && late) fill(cur);
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
         mma(g1, (TM * TN) / 2, TM * TN);
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
       };
       int kt = 0;
@@ -1264,11 +1274,13 @@ extern "C" int ddpo_gemm_conv_fwd_bf16_planes(const ddpo_gemm_desc* dp, const ui
   // DDPO_APL_MODE (tuning knob, read once): 1 = plain two-stage loop (wait, barrier, request, compute); 2 = barrier in the
   // middle of the k-tile with the fragment reads software-pipelined across it; +4 = the upper half of the waves requests its
   // pieces half a k-tile later than the lower half (the two waves of a SIMD then alternate between DMA issue and MFMAs).
-  // 3 = mode 2 with the weight operand three LDS stages deep (requested two k-tiles ahead, counted vmcnt); 7 = 3 + stagger.
+  // 3 = mode 2 with the weight operand three LDS stages deep (requested two k-tiles ahead, counted vmcnt); 7 = 3 + stagger;
+  // +8 on mode 2 / 6 (10 / 14) = s_setprio 1 around the MFMA clusters.
   // Measured on the SD-1.5 layers at batch 16 (profiles/r01_probe_gemm_planes_modes.md): 6 (default) > 1 ~ 2 > fp32-fed;
-  // modes 3 / 7 were written after the round's GPU budget was spent and are NOT yet run on hardware.
+  // modes 3 / 7 / 10 / 14 were written after the round's GPU budget was spent and are NOT yet run on hardware.
   static const int apl_mode = [] { const char* e = getenv("DDPO_APL_MODE"); return e ? atoi(e) : 6; }();
   d.splits = (apl_mode & 4) ? 1 : 0;                 // `splits` is a wgrad-only field: the forward kernel reads it as the stagger flag
+  if ((apl_mode & 11) == 10) return dispatch_bf16<5>(d, w_hi, w_lo, ldw, 3, ws, ws_bytes, as_stream(stream));   // 2 + 8: s_setprio (10 / 14)
   switch (apl_mode & 3) {
     case 1: return dispatch_bf16<1>(d, w_hi, w_lo, ldw, 3, ws, ws_bytes, as_stream(stream));
     case 3: return dispatch_bf16<3>(d, w_hi, w_lo, ldw, 3, ws, ws_bytes, as_stream(stream));      // three weight stages (7 = + stagger)

@@ -169,7 +169,7 @@ def test_unet_and_vae_forward_unchanged_by_planes(model, monkeypatch):
     assert torch.equal(img_fp, img_pl)
 
 
-@pytest.mark.parametrize("mode", [1, 2, 6, 3, 7, "tall"])
+@pytest.mark.parametrize("mode", [1, 2, 6, 3, 7, 14, "tall"])
 def test_kernel_probe_all_k_loop_variants_bit_identical(mode):
     """tools/native/kernel_probe gemm2 compares the plane-fed kernel with the fp32-fed one output by output on 23 layer shapes
     (conv borders, strides, upsampling, ragged M / N, split-K) and exits non-zero on any mismatch.  DDPO_APL_MODE is read once
@@ -182,7 +182,7 @@ def test_kernel_probe_all_k_loop_variants_bit_identical(mode):
     exe = os.path.join(root, "tools", "native", "kernel_probe")
     if not os.path.exists(exe):
         pytest.skip("tools/native/kernel_probe not built (python __graft_entry__.py)")
-    if mode in (3, 7, "tall") and os.environ.get("DDPO_EXPERIMENTAL") != "1":
+    if mode in (3, 7, 14, "tall") and os.environ.get("DDPO_EXPERIMENTAL") != "1":
         pytest.skip("k-loop variant not yet validated on hardware: set DDPO_EXPERIMENTAL=1")
     env, batch = dict(os.environ, DDPO_APL_MODE=str(mode)), "4"
     if mode == "tall":                                  # 256x320 tiles (DDPO_APL_TALL=1) apply from 200 tiles on: batch 16 at the 64^2 level

@@ -3,7 +3,7 @@
 #   gpurun --timeout 300 -- 'bash tools/probe_round.sh'
 # PROBE_KNOBS="DDPO_GEMM_WIDE=0 DDPO_GEMM_BIG_MIN=128" adds one extra gemm sweep per listed VAR=value setting.
 # PROBE_APL_MODES="1 2 6 3 7" / PROBE_COLD_MODES="6 7": plane-fed vs fp32-fed per k-loop variant, caches warm / flushed.
-# First call of round 2:  PROBE_APL_MODES="6 3 7" PROBE_COLD_MODES="6 7" bash tools/probe_round.sh
+# First call of round 2:  PROBE_APL_MODES="6 3 7 14" PROBE_COLD_MODES="6 7 14" bash tools/probe_round.sh
 mkdir -p gpurun_out
 P=tools/native/kernel_probe
 [ -x $P ] || make -C tools/native > gpurun_out/probe_build.log 2>&1
