@@ -278,10 +278,21 @@ static int probe_gemm2(int B, int iters) {
   const ConvCase convs[] = {{64, 320, 320, 3, 1, 0}, {32, 640, 640, 3, 1, 0}, {16, 1280, 1280, 3, 1, 0}, {8, 1280, 1280, 3, 1, 0},
                             {64, 960, 320, 3, 1, 0}, {32, 1920, 640, 3, 1, 0}, {16, 2560, 1280, 3, 1, 0}, {32, 320, 640, 3, 1, 0},
                             {32, 640, 640, 3, 1, 1}, {64, 320, 320, 3, 2, 0},  {64, 320, 320, 1, 1, 0},   {20, 64, 96, 3, 1, 0}};
-  for (const ConvCase& c : convs) run_gemm2(B, c.H, c.Cin, c.Cout, c.ks, c.stride, c.ups, iters, ws, ws_bytes);
+  // PROBE_ONLY=c<i> / d<i>: run a single convolution / dense case (PMC passes: one kernel pair per process)
+  const char* only = getenv("PROBE_ONLY");
+  const int only_i = only && only[0] ? atoi(only + 1) : -1;
+  int ci = 0;
+  for (const ConvCase& c : convs) {
+    if (!only || (only[0] == 'c' && ci == only_i)) run_gemm2(B, c.H, c.Cin, c.Cout, c.ks, c.stride, c.ups, iters, ws, ws_bytes);
+    ++ci;
+  }
   const int dense[][3] = {{4096, 320, 320}, {4096, 320, 2560}, {4096, 1280, 320}, {1024, 640, 5120}, {1024, 2560, 640},
                           {256, 1280, 10240}, {256, 5120, 1280}, {64, 1280, 1280}, {77, 768, 320}, {1, 1280, 1280}, {37, 96, 72}};
-  for (auto& g : dense) run_gemm2(B, g[0], g[1], g[2], 0, 1, 0, iters, ws, ws_bytes);
+  int di = 0;
+  for (auto& g : dense) {
+    if (!only || (only[0] == 'd' && di == only_i)) run_gemm2(B, g[0], g[1], g[2], 0, 1, 0, iters, ws, ws_bytes);
+    ++di;
+  }
   HIP_OK(hipFree(ws));
   return g_fail;
 }
