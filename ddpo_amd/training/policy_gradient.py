@@ -25,9 +25,17 @@ ADV_CLIP_MAX = 10.0
 DEFAULT_TRAIN_FUSE = 10
 
 
-def train_fuse_default():
+def train_fuse_default(unet_rows_per_micro_step=None, latent_pixels=None):
+    """Micro-steps per launch.  An explicit DDPO_TRAIN_FUSE is taken as is; the default of 10 is reduced for geometries whose
+    activation tape would outgrow the footprint validated on hardware (U-Net batch 40 at 64x64 latents = 163,840 latent pixels
+    per launch): SD-2.1 at 96x96 latents fuses 4 micro-steps."""
     import os
-    return max(1, int(os.environ.get("DDPO_TRAIN_FUSE", str(DEFAULT_TRAIN_FUSE))))
+    if "DDPO_TRAIN_FUSE" in os.environ:
+        return max(1, int(os.environ["DDPO_TRAIN_FUSE"]))
+    k = DEFAULT_TRAIN_FUSE
+    if unet_rows_per_micro_step and latent_pixels:
+        k = min(k, max(1, (40 * 4096) // (int(unet_rows_per_micro_step) * int(latent_pixels))))
+    return k
 
 
 class AdamWConfig:

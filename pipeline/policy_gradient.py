@@ -217,7 +217,8 @@ def main(argv=None):
             n_mini = total_batch_size // (n_devices * args.train_batch_size)
             all_infos = []
             do_opt_update = False
-            train_fuse = train_fuse_default()
+            train_fuse = train_fuse_default(args.train_batch_size * (2 if args.train_cfg else 1),
+                                            devs["latents"].shape[-1] * devs["latents"].shape[-2])
             t_train = time.time()
             for i in range(n_mini):
                 sl = slice(i * args.train_batch_size, (i + 1) * args.train_batch_size)
