@@ -7,13 +7,24 @@ A "step" = one pass of the sampling hot path over one per-GPU batch of `sample_b
 weights (no checkpoints are reachable offline).  Weak scaling: every rank samples its own batch, no data-path
 collective; value = all images of all ranks / max-over-ranks wall time.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     — dominant kernel (fp32-MFMA implicit-GEMM conv/GEMM): algorithmic FLOPs / event-timed duration
+Launch: `python bench.py --gpus N` starts its own N ranks (one per GPU, `torch.distributed.run`, backend nccl = RCCL) when it
+is not already running under a launcher; under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` it uses
+the launcher's ranks.  It refuses to run when the node has fewer GPUs than `--gpus`, or when WORLD_SIZE != --gpus.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
+  roofline     — dominant kernel (implicit-GEMM conv / GEMM on the MFMA datapath): algorithmic FLOPs / event-timed duration
   cpu_baseline — the CPU oracle (oracle/, torch-CPU) timed on a bounded sample of the same workload (rank 0, N=1)
+  extra.train  — PPO train sample-timesteps/s of the same model (fused micro-steps, one AdamW update), rank-0 view
+  rccl_ranks, allreduce — N > 1: world size seen by RCCL and a timed all-reduce of the flat fp32 gradient buffer
+
+Modes: sample (headline) | train (PPO micro-steps) | epoch (one sample batch + its PPO micro-steps + optimizer updates with
+the gradient all-reduce: what a DDPO epoch costs per GPU) | comm (the collective alone; also runs on CPU/gloo for the tests).
 """
 import argparse
 import json
 import os
+import socket
+import statistics
 import sys
 import time
 
@@ -24,45 +35,86 @@ if ROOT not in sys.path:
 import numpy as np
 import torch
 
-UNET_FWD_TFLOP = {"sd15": 0.8033, "tiny": None}      # per sample at 64x64 latents
-VAE_TFLOP = {"sd15": 2.5145}
+# algorithmic TFLOP per sample: U-Net forward at the benchmark latent size, VAE decode of one image
+UNET_FWD_TFLOP = {("sd15", 512): 0.8033, ("sd21", 768): 2.1491}
+VAE_TFLOP = {("sd15", 512): 2.5145, ("sd21", 768): 5.7543}
 FP32_MFMA_PEAK_TFLOPS = 157.3                          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0                         # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16 dense peak
+N_UNET_PARAMS = {"sd15": 859_520_964, "sd21": 865_910_724}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--model", default="sd15", choices=["sd15", "tiny"])
-    ap.add_argument("--resolution", type=int, default=512)
+    ap.add_argument("--model", default="sd15", choices=["sd15", "sd21", "tiny", "tiny21"])
+    ap.add_argument("--resolution", type=int, default=None, help="default: 512 (sd15), 768 (sd21), 64 (tiny)")
     ap.add_argument("--n-inference-steps", type=int, default=50)
     ap.add_argument("--sample-batch-size", type=int, default=8)
     ap.add_argument("--datapath", default=os.environ.get("DDPO_DATAPATH", "bf16x3"), choices=["fp32", "bf16x3", "bf16"],
                     help="contraction datapath: exact-fp32 MFMA, bf16-split MFMA x3 (fp32-accurate to ~1e-5, default), single-pass bf16")
-    ap.add_argument("--mode", default="sample", choices=["sample", "train"],
-                    help="sample (headline): images/sec of the sampling hot path; train: PPO sample-timesteps/sec of train_step "
-                         "(U-Net fwd cond+uncond, log-prob, PPO-clip, backward, one AdamW update per step group)")
+    ap.add_argument("--mode", default="sample", choices=["sample", "train", "epoch", "comm"],
+                    help="sample (headline): images/sec of the sampling hot path; train: PPO sample-timesteps/sec of train_step; "
+                         "epoch: one sample batch + its PPO micro-steps + optimizer updates (gradient all-reduce included); "
+                         "comm: only the gradient all-reduce")
     ap.add_argument("--train-batch-size", type=int, default=2)
     ap.add_argument("--train-fuse", type=int, default=int(os.environ.get("DDPO_TRAIN_FUSE", "10")),
-                    help="--mode train: micro-steps per U-Net forward/backward (train_steps_fused, the entrypoint's default is 10); "
-                         "1 = one launch per micro-step")
+                    help="micro-steps per U-Net forward/backward (train_steps_fused, the entrypoint's default is 10); 1 = unfused")
+    ap.add_argument("--backend", default=os.environ.get("DDPO_DIST_BACKEND"), help="nccl (= RCCL, default on GPUs) | gloo (CPU tests of --mode comm)")
+    ap.add_argument("--comm-mib", type=float, default=None, help="--mode comm: buffer size in MiB (default: the flat fp32 gradient, 3.44 GB)")
     ap.add_argument("--no-graph", action="store_true", help="launch the U-Net kernels eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    return ap.parse_args()
+    ap.add_argument("--no-train-extra", action="store_true", help="skip the short train-step measurement attached to the headline line")
+    args = ap.parse_args(argv)
+    if args.resolution is None:
+        args.resolution = {"sd15": 512, "sd21": 768}.get(args.model, 64)
+    return args
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def maybe_self_launch(args, argv):
+    """`python bench.py --gpus N` outside a launcher: check the node, then re-exec under torch.distributed.run with N ranks."""
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" in os.environ:
+        if int(os.environ["WORLD_SIZE"]) != args.gpus:
+            raise SystemExit(f"bench.py: launched with WORLD_SIZE={os.environ['WORLD_SIZE']} but --gpus {args.gpus}; they must agree")
+        return
+    if args.gpus == 1:
+        return
+    on_cpu = args.mode == "comm" and (args.backend == "gloo")
+    if not on_cpu:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} requested but this node exposes {have} GPU(s); "
+                             f"refusing to run fewer ranks than asked (one process per GPU, RCCL)")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    os.execvpe(cmd[0], cmd, env)
 
 
 def cpu_baseline(args):
-    """Times the oracle restatement (torch CPU, all host cores) on a bounded sample of the benchmark workload: ONE classifier-free
-    guidance step of one image (the U-Net on a batch of 2 at the benchmark resolution, as the sampler runs it) and ONE VAE decode
-    of one image — about 10-30 s of CPU work on the GPU box — and assembles seconds/image = T x step + decode."""
+    """Times the oracle restatement (torch CPU, all host cores up to 32) on a bounded sample of the benchmark workload: ONE
+    classifier-free guidance step of one image (the U-Net on a batch of 2 at the benchmark resolution, as the sampler runs it)
+    and ONE VAE decode of one image; seconds/image = T x step + decode.  Protocol: 1 warm-up + 3 timed repeats
+    of the U-Net step, median; the VAE decode (about a tenth of the U-Net share of an image) gets 1 warm-up + 1 timed run
+    unless it is quick."""
     from oracle import unet as OU
-    cores = min(os.cpu_count() or 1, 32)      # torch-CPU stops scaling (and oversubscribes) beyond a few dozen threads
-    torch.set_num_threads(cores)
-    cfg = OU.SD15 if args.model == "sd15" else OU.TINY
-    vcfg = OU.VAE_SD if args.model == "sd15" else OU.VAE_TINY
+    ncpu = os.cpu_count() or 1
+    threads = min(ncpu, 32)      # torch-CPU stops scaling (and oversubscribes) beyond a few dozen threads
+    torch.set_num_threads(threads)
+    cfg = {"sd15": OU.SD15, "sd21": getattr(OU, "SD21", None), "tiny": OU.TINY, "tiny21": getattr(OU, "TINY21", OU.TINY)}[args.model]
+    vcfg = OU.VAE_SD if args.model in ("sd15", "sd21") else OU.VAE_TINY
     g = torch.Generator().manual_seed(0)
 
     def synth(shapes):
@@ -77,131 +129,293 @@ def cpu_baseline(args):
     x = torch.randn(1, 4, hw, hw, generator=g)
     ctx = torch.randn(2, 77, cfg.cross_attention_dim, generator=g)
     t = torch.full((2,), 481, dtype=torch.int32)
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        OU.unet_forward(params, cfg, torch.cat([x, x]), t, ctx)          # [uncond; cond] in one batch, like the sampler
-    dt = time.perf_counter() - t0
+
+    def timed(fn, warm, reps):
+        for _ in range(warm):
+            fn()
+        out = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            out.append(time.perf_counter() - t0)
+        return out
+
+    def unet_step():
+        with torch.no_grad():
+            OU.unet_forward(params, cfg, torch.cat([x, x]), t, ctx)          # [uncond; cond] in one batch, like the sampler
+    unet_times = timed(unet_step, 1, 3)
+    dt = statistics.median(unet_times)
     del params
     vparams = synth(OU.vae_decoder_param_shapes(vcfg))
+
+    def vae_step():
+        with torch.no_grad():
+            OU.vae_decode(vparams, vcfg, x)
     t0 = time.perf_counter()
-    with torch.no_grad():
-        OU.vae_decode(vparams, vcfg, x)
-    dt_vae = time.perf_counter() - t0
+    vae_step()                                           # warm-up (also tells how long one decode takes)
+    first = time.perf_counter() - t0
+    vae_times = timed(vae_step, 0, 3 if first < 3.0 else 1)
+    dt_vae = statistics.median(vae_times)
     T = args.n_inference_steps
     per_image = dt * T + dt_vae
-    gflops = None
-    if args.model == "sd15" and hw == 64:
-        gflops = (2 * UNET_FWD_TFLOP["sd15"] + VAE_TFLOP["sd15"]) * 1e3 / (dt + dt_vae)
-    return {"value": 1.0 / per_image, "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"oracle (torch CPU, {cores} threads): one CFG step of one image (U-Net on a batch of 2, {hw}x{hw} latents) = {dt:.2f} s, "
-                      f"one VAE decode to {args.resolution}x{args.resolution} = {dt_vae:.2f} s; seconds/image = {T} x step + decode",
+    key = (args.model, args.resolution)
+    gflops = (2 * UNET_FWD_TFLOP[key] + VAE_TFLOP[key]) * 1e3 / (dt + dt_vae) if key in UNET_FWD_TFLOP else None
+    return {"value": 1.0 / per_image, "unit": "images/sec", "cores": threads, "host_cpu_count": ncpu, "threads": threads, "kind": "port",
+            "sample": f"oracle (torch CPU, {threads} threads on a {ncpu}-core host): one CFG step of one image (U-Net on a batch of 2, {hw}x{hw} "
+                      f"latents), 1 warm-up + 3 repeats, median {dt:.2f} s (runs {', '.join(f'{v:.2f}' for v in unet_times)}); one VAE decode to "
+                      f"{args.resolution}x{args.resolution}, 1 warm-up + {len(vae_times)} run(s), median {dt_vae:.2f} s; "
+                      f"seconds/image = {T} x step + decode",
             "seconds_per_cfg_step": dt, "seconds_per_vae_decode": dt_vae, "cpu_gflops": gflops}
 
 
-def bench_train(args, world, rank, dev, dist, unet, sched, state, emb, neg):
-    """Secondary metric: one "step" = `train_batch_size` sample-timesteps through train_step with train_cfg=True, every
-    4th step applying the optimizer (grad all-reduce over ranks + fused AdamW), as at the reference defaults scaled down."""
-    from ddpo_amd import lib as L
-    from ddpo_amd.training.policy_gradient import AccumulatingTrainState, AdamWConfig, train_step, train_steps_fused
-    if L.DATAPATH != "fp32":
-        unet.params.pack_bf16(bwd=True)
-    b = args.train_batch_size
-    hw = args.resolution // 8
-    g = torch.Generator().manual_seed(3 + rank)
-    st = sched.set_timesteps(state, args.n_inference_steps)
-    lat = torch.randn(b, 4, hw, hw, generator=g).to(dev)
-    batch = {"latents": lat, "next_latents": (0.98 * lat + 0.05 * torch.randn(b, 4, hw, hw, generator=g).to(dev)),
-             "ts": torch.tensor([481, 21, 961, 241][:b], dtype=torch.int32, device=dev),
-             "log_probs": torch.full((b,), -1.0, device=dev), "advantages": torch.tensor([0.7, -1.1, 0.3, -0.2][:b], device=dev),
-             "prompt_embeds": emb[:b].contiguous(), "uncond_embeds": neg[:b].contiguous()}
-    tstate = AccumulatingTrainState(unet, AdamWConfig())
-    k = 0
+class Comm:
+    """World bookkeeping + the two collectives the benchmark itself needs (barrier, max over ranks)."""
 
-    fuse = max(1, args.train_fuse)
+    def __init__(self, args):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.dist = None
+        self.backend = None
+        on_gpu = torch.cuda.is_available() and not (args.mode == "comm" and args.backend == "gloo")
+        self.dev = torch.device("cuda", self.local_rank) if on_gpu else torch.device("cpu")
+        if on_gpu:
+            torch.cuda.set_device(self.local_rank)
+        if self.world > 1:
+            import torch.distributed as dist
+            self.dist = dist
+            self.backend = args.backend or ("nccl" if on_gpu else "gloo")
+            kw = {"device_id": self.dev} if self.backend == "nccl" else {}
+            dist.init_process_group(self.backend, **kw)
+            assert dist.get_world_size() == self.world == args.gpus
 
-    def one():              # one "step" = `fuse` micro-steps of b sample-timesteps; the optimizer steps after every 4th micro-step group
-        nonlocal k
-        k += 1
-        if fuse == 1:
-            train_step(tstate, batch, st, sched, True, 5.0, 1.0, 1e-4, do_opt_update=(k % 4 == 0))
-        else:
-            train_steps_fused(tstate, [batch] * fuse, st, sched, True, 5.0, 1.0, 1e-4, do_opt_update=(k % 4 == 0))
+    def sync(self):
+        if self.dist is not None:
+            self.dist.barrier()
+        if self.dev.type == "cuda":
+            torch.cuda.synchronize()
 
-    def sync():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+    def max_over_ranks(self, seconds):
+        if self.dist is None:
+            return seconds
+        tt = torch.tensor([seconds], dtype=torch.float64, device=self.dev)
+        self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.destroy_process_group()
+
+
+def time_allreduce(comm, numel, reps=3):
+    """all_reduce(SUM) of an fp32 buffer of `numel` floats (the flat gradient): max-over-ranks milliseconds and bus bandwidth
+    (2 (W-1)/W x bytes / time — what each rank's links carry in a ring / direct reduce-scatter + all-gather)."""
+    if comm.dist is None:
+        return None
+    buf = torch.ones(int(numel), dtype=torch.float32, device=comm.dev)
+    comm.dist.all_reduce(buf)                         # warm-up: communicator setup, first-touch
+    comm.sync()
+    times = []
+    for _ in range(reps):
+        buf.fill_(1.0)
+        comm.sync()
+        t0 = time.perf_counter()
+        comm.dist.all_reduce(buf, op=comm.dist.ReduceOp.SUM)
+        if comm.dev.type == "cuda":
+            torch.cuda.synchronize()
+        times.append(comm.max_over_ranks(time.perf_counter() - t0))
+    ok = bool((buf == float(comm.world)).all().item())
+    dt = statistics.median(times)
+    nbytes = 4.0 * numel
+    W = comm.world
+    return {"bytes": nbytes, "ms": dt * 1e3, "algbw_GBps": nbytes / dt / 1e9, "busbw_GBps": 2.0 * (W - 1) / W * nbytes / dt / 1e9,
+            "backend": comm.backend, "ranks": comm.dist.get_world_size(), "sum_correct": ok, "repeats": reps}
+
+
+def bench_comm(args, comm):
+    numel = int((args.comm_mib * (1 << 20)) // 4) if args.comm_mib else N_UNET_PARAMS.get(args.model, N_UNET_PARAMS["sd15"])
+    if comm.dist is None:
+        raise SystemExit("bench.py --mode comm needs --gpus >= 2")
     for _ in range(args.warmup):
-        one()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one()
-    sync()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    value = world * b * fuse * args.steps / dt
-    if rank == 0:
-        tf = value * 6 * UNET_FWD_TFLOP["sd15"] if (args.model == "sd15" and args.resolution == 512) else None
-        print(json.dumps({"metric": "PPO train sample-timesteps/sec (train_cfg, 512^2)", "value": value, "unit": "sample-timesteps/sec",
-                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.datapath, "data": "synthetic",
-                          "config": {"workload": f"train_step, {args.model}, train_batch_size {b}/GPU, train_cfg, {fuse} micro-step(s) per U-Net "
-                                                 f"forward/backward, optimizer update every 4 steps",
-                                     "parallelism": f"dp{world}"},
-                          "end_to_end_tflops": tf}), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+        time_allreduce(comm, numel, reps=1)
+    res = time_allreduce(comm, numel, reps=max(1, args.steps))
+    if comm.rank == 0:
+        print(json.dumps({"metric": "gradient all-reduce bus bandwidth", "value": res["busbw_GBps"], "unit": "GB/s", "n_gpus": comm.world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms"], "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": f"all_reduce(SUM) of {numel} fp32 (flat U-Net gradient buffer)", "parallelism": f"dp{comm.world}"},
+                          "rccl_ranks": res["ranks"], "allreduce": res}), flush=True)
+    comm.close()
 
 
-def main():
-    args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the DDPO engine has no CPU path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_mod
-        dist = dist_mod
-        dist.init_process_group("nccl", device_id=dev)
-
+def build_engine(args, comm):
     from ddpo_amd import lib as L
     from ddpo_amd.models.unet import UNet2DCondition, UNetConfig
     from ddpo_amd.models.vae import VAEDecoder, VAEConfig
     from ddpo_amd.diffusers_patch.scheduling_ddim import DDIMScheduler
     from ddpo_amd.diffusers_patch.pipeline_stable_diffusion import StableDiffusionPipeline
-    from ddpo_amd.utils import prng
-
     L.load()
     L.DATAPATH = args.datapath
+    dev = comm.dev
     ucfg = UNetConfig.named(args.model)
     unet = UNet2DCondition(ucfg, dev)
     unet.params.init_synthetic(seed=0)
-    vae = VAEDecoder(VAEConfig.named("sd" if args.model == "sd15" else "tiny"), dev)
+    vae = VAEDecoder(VAEConfig.named("sd" if args.model in ("sd15", "sd21") else "tiny"), dev)
     vae.params.init_synthetic(seed=1)
     if L.DATAPATH != "fp32":
-        unet.params.pack_bf16(bwd=False)
+        unet.params.pack_bf16(bwd=args.mode in ("train", "epoch"))
         vae.params.pack_bf16(bwd=False)
-    sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", set_alpha_to_one=False, steps_offset=1)
+    sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", set_alpha_to_one=False, steps_offset=1,
+                          prediction_type=ucfg.prediction_type)
     state = sched.create_state(device=dev)
     pipe = StableDiffusionPipeline(unet, vae, sched)
     B = args.sample_batch_size
-    g = torch.Generator().manual_seed(1 + rank)
+    g = torch.Generator().manual_seed(1 + comm.rank)
     emb = torch.randn(B, 77, ucfg.cross_attention_dim, generator=g).to(dev)
     neg = torch.randn(1, 77, ucfg.cross_attention_dim, generator=torch.Generator().manual_seed(2)).expand(B, -1, -1).contiguous().to(dev)
+    return L, ucfg, unet, vae, sched, state, pipe, emb, neg
+
+
+def make_train_batch(args, comm, emb, neg, b):
+    hw = args.resolution // 8
+    g = torch.Generator().manual_seed(3 + comm.rank)
+    lat = torch.randn(b, 4, hw, hw, generator=g).to(comm.dev)
+    return {"latents": lat, "next_latents": (0.98 * lat + 0.05 * torch.randn(b, 4, hw, hw, generator=g).to(comm.dev)),
+            "ts": torch.tensor([481, 21, 961, 241][:b], dtype=torch.int32, device=comm.dev),
+            "log_probs": torch.full((b,), -1.0, device=comm.dev), "advantages": torch.tensor([0.7, -1.1, 0.3, -0.2][:b], device=comm.dev),
+            "prompt_embeds": emb[:b].contiguous(), "uncond_embeds": neg[:b].contiguous()}
+
+
+def measure_train(args, comm, L, unet, sched, state, emb, neg, steps, warmup, update_every=4):
+    """`steps` timed launches of `train_fuse` fused micro-steps of `train_batch_size` sample-timesteps (train_cfg=True), every
+    `update_every`-th closing with the optimizer (gradient all-reduce over ranks + fused AdamW + weight re-pack)."""
+    from ddpo_amd.training.policy_gradient import AccumulatingTrainState, AdamWConfig, train_step, train_steps_fused
+    if L.DATAPATH != "fp32":
+        unet.params.pack_bf16(bwd=True)
+    b = args.train_batch_size
+    st = sched.set_timesteps(state, args.n_inference_steps)
+    batch = make_train_batch(args, comm, emb, neg, b)
+    tstate = AccumulatingTrainState(unet, AdamWConfig())
+    fuse = max(1, args.train_fuse)
+    k = 0
+
+    def one():
+        nonlocal k
+        k += 1
+        upd = (k % update_every == 0)
+        if fuse == 1:
+            train_step(tstate, batch, st, sched, True, 5.0, 1.0, 1e-4, do_opt_update=upd)
+        else:
+            train_steps_fused(tstate, [batch] * fuse, st, sched, True, 5.0, 1.0, 1e-4, do_opt_update=upd)
+    for _ in range(warmup):
+        one()
+    comm.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    comm.sync()
+    dt = comm.max_over_ranks(time.perf_counter() - t0)
+    value = comm.world * b * fuse * steps / dt
+    key = (args.model, args.resolution)
+    tf = value * 6 * UNET_FWD_TFLOP[key] if key in UNET_FWD_TFLOP else None
+    return {"metric": "PPO train sample-timesteps/sec (train_cfg)", "value": value, "unit": "sample-timesteps/sec", "steps": steps, "warmup": warmup,
+            "ms_per_step": dt / steps * 1e3, "train_batch_size": b, "micro_steps_per_launch": fuse, "optimizer_update_every": update_every,
+            "end_to_end_tflops": tf,
+            "roofline": None if tf is None else {"bound": "mfma", "achieved": tf / comm.world, "peak": BF16_MFMA_PEAK_TFLOPS if args.datapath != "fp32" else FP32_MFMA_PEAK_TFLOPS,
+                                                 "unit": "TFLOP/s", "frac": tf / comm.world / (BF16_MFMA_PEAK_TFLOPS if args.datapath != "fp32" else FP32_MFMA_PEAK_TFLOPS),
+                                                 "note": "end-to-end: 6 x U-Net-forward algorithmic FLOPs per sample-timestep (2 fwd + 2 bwd) / wall time, per GPU"}}
+
+
+def bench_train(args, comm):
+    L, ucfg, unet, vae, sched, state, pipe, emb, neg = build_engine(args, comm)
+    res = measure_train(args, comm, L, unet, sched, state, emb, neg, args.steps, args.warmup)
+    ar = time_allreduce(comm, unet.params.flat.numel()) if comm.dist is not None else None
+    if comm.rank == 0:
+        print(json.dumps({"metric": "PPO train sample-timesteps/sec (train_cfg, 512^2)", "value": res["value"], "unit": "sample-timesteps/sec",
+                          "n_gpus": comm.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.datapath, "data": "synthetic",
+                          "config": {"workload": f"train_step, {args.model}, train_batch_size {args.train_batch_size}/GPU, train_cfg, "
+                                                 f"{res['micro_steps_per_launch']} micro-step(s) per U-Net forward/backward, optimizer update every 4 steps",
+                                     "parallelism": f"dp{comm.world}"},
+                          "end_to_end_tflops": res["end_to_end_tflops"], "roofline": res["roofline"],
+                          "rccl_ranks": comm.world if comm.dist is not None else None, "allreduce": ar}), flush=True)
+    comm.close()
+
+
+def bench_epoch(args, comm):
+    """One DDPO epoch per GPU at the reference defaults' shape: 1 sample batch of 8 images (50 steps, CFG, VAE decode), then
+    for each of the 8/2 = 4 mini-batches its 50 PPO micro-steps (fused 10 at a time) closed by ONE optimizer update (gradient
+    all-reduce over ranks + AdamW): 200 micro-steps, 4 updates.  Reward evaluation (host JPEG) is not part of the timed region."""
+    from ddpo_amd.training.policy_gradient import AccumulatingTrainState, AdamWConfig, train_steps_fused
+    from ddpo_amd.utils import prng
+    L, ucfg, unet, vae, sched, state, pipe, emb, neg = build_engine(args, comm)
+    T, B, b = args.n_inference_steps, args.sample_batch_size, args.train_batch_size
+    fuse = max(1, min(args.train_fuse, T))
+    st = sched.set_timesteps(state, T)
+    tstate = AccumulatingTrainState(unet, AdamWConfig())
+    _, sample_rng = prng.split(prng.PRNGKey(0))
+    adv = torch.randn(B, generator=torch.Generator().manual_seed(5 + comm.rank)).clamp_(-10, 10).to(comm.dev)
+
+    def one_epoch():
+        nonlocal sample_rng
+        sample_rng, sample_seed = prng.split(sample_rng)
+        key = prng.split(sample_seed, comm.world)[comm.rank]
+        final, lat, nxt, lps, ts = pipe(emb, neg, {"unet": unet.params, "scheduler": state}, key, T, height=args.resolution,
+                                        width=args.resolution, guidance_scale=5.0, eta=1.0, jit=not args.no_graph)
+        img = vae.decode(final)
+        for i in range(B // b):
+            sl = slice(i * b, (i + 1) * b)
+            for j0 in range(0, T, fuse):
+                js = range(j0, min(j0 + fuse, T))
+                batches = [{"prompt_embeds": emb[sl], "uncond_embeds": neg[sl], "advantages": adv[sl], "latents": lat[sl, j].contiguous(),
+                            "next_latents": nxt[sl, j].contiguous(), "log_probs": lps[sl, j].contiguous(), "ts": ts[sl, j].contiguous()} for j in js]
+                train_steps_fused(tstate, batches, st, sched, True, 5.0, 1.0, 1e-4, do_opt_update=(js[-1] == T - 1))
+        return img
+    for _ in range(args.warmup):
+        one_epoch()
+    comm.sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        img = one_epoch()
+    comm.sync()
+    dt = comm.max_over_ranks(time.perf_counter() - t0)
+    assert torch.isfinite(img).all()
+    ar = time_allreduce(comm, unet.params.flat.numel()) if comm.dist is not None else None
+    if comm.rank == 0:
+        n_upd = B // b
+        print(json.dumps({"metric": "DDPO epochs/sec per job (8 images sampled + 200 PPO micro-steps + 4 AdamW updates per GPU)",
+                          "value": args.steps / dt, "unit": "epochs/sec", "n_gpus": comm.world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": args.datapath, "data": "synthetic",
+                          "config": {"workload": f"{args.model} {args.resolution}^2: {B} images x {T} DDIM steps + VAE decode, then {B // b} mini-batches x {T} "
+                                                 f"PPO micro-steps (train_cfg, {fuse} fused per launch), {n_upd} optimizer updates each with one "
+                                                 f"all-reduce of the flat gradient", "parallelism": f"dp{comm.world}", "global_batch": comm.world * B},
+                          "images_per_sec": comm.world * B * args.steps / dt, "sample_timesteps_per_sec": comm.world * B * T * args.steps / dt,
+                          "rccl_ranks": comm.world if comm.dist is not None else None, "allreduce": ar}), flush=True)
+    comm.close()
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse(argv)
+    maybe_self_launch(args, argv)
+    if args.mode != "comm" and not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the DDPO engine has no CPU path)")
+    comm = Comm(args)
+    if args.mode == "comm":
+        return bench_comm(args, comm)
+    if args.mode == "train":
+        return bench_train(args, comm)
+    if args.mode == "epoch":
+        return bench_epoch(args, comm)
+
+    from ddpo_amd.utils import prng
+    L, ucfg, unet, vae, sched, state, pipe, emb, neg = build_engine(args, comm)
+    world, rank, dev = comm.world, comm.rank, comm.dev
+    B = args.sample_batch_size
     # reference key tree (pipeline/policy_gradient.py:51,201,244-245): rank r uses row r of split(sample_seed, n_devices)
     rng = prng.PRNGKey(0)
     _, sample_rng = prng.split(rng)
-
-    if args.mode == "train":
-        return bench_train(args, world, rank, dev, dist, unet, sched, state, emb, neg)
 
     def one_step():
         nonlocal sample_rng
@@ -213,23 +427,14 @@ def main():
         img = vae.decode(final)
         return img, lps
 
-    def sync():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     for _ in range(args.warmup):
         one_step()
-    sync()
+    comm.sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         img, lps = one_step()
-    sync()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    comm.sync()
+    dt = comm.max_over_ranks(time.perf_counter() - t0)
     assert torch.isfinite(img).all() and torch.isfinite(lps).all()
     images = world * B * args.steps
     value = images / dt
@@ -262,30 +467,37 @@ def main():
             tj = json.load(open(tpath)).get(dom)
             if tj:
                 traffic = tj["traffic_bytes_per_launch"]
-                traffic_note = ("PMC (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes) measured per launch of this kernel family, from "
-                                "profiles/roofline_traffic.json; not collectable inside this process")
+                traffic_note = tj.get("note", "PMC (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes) per launch of this kernel family, from "
+                                              "profiles/roofline_traffic.json; not collectable inside this process")
         roofline = {"bound": "mfma", "kernel": kname, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                     "frac": achieved / peak, "traffic": traffic, "traffic_note": traffic_note,
                     "algorithmic_bytes_per_launch": sum(r[4] for r in recs) / max(len(recs), 1),
                     "launches": len(recs), "avg_launch_ms": ms / max(len(recs), 1),
                     "algorithmic_gflop_per_launch": flops / max(len(recs), 1) / 1e9,
                     "mfma_passes_per_algorithmic_flop": passes, "mfma_issue_frac": passes * achieved / peak}
+    ar = time_allreduce(comm, unet.params.flat.numel()) if comm.dist is not None else None
+    extra = {}
+    if not args.no_train_extra and args.model in ("sd15", "sd21"):
+        # the PPO half of an epoch (the wall-clock bottleneck of "reward vs wall-clock"), reported next to the headline number
+        try:
+            extra["train"] = measure_train(args, comm, L, unet, sched, state, emb, neg, steps=4, warmup=2)
+        except Exception as exc:          # the headline line must survive a failure of the secondary measurement
+            extra["train"] = {"error": f"{type(exc).__name__}: {exc}"}
     if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
+        comm.close()
         return
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args)
-    tflop_per_image = None
-    if args.model == "sd15" and args.resolution == 512:
-        tflop_per_image = args.n_inference_steps * 2 * UNET_FWD_TFLOP["sd15"] + VAE_TFLOP["sd15"]
+    key = (args.model, args.resolution)
+    tflop_per_image = args.n_inference_steps * 2 * UNET_FWD_TFLOP[key] + VAE_TFLOP[key] if key in UNET_FWD_TFLOP else None
     out = {
-        "metric": "sampled images/sec (512^2, 50 DDIM steps)", "value": value, "unit": "images/sec", "n_gpus": world,
+        "metric": f"sampled images/sec ({args.resolution}^2, {args.n_inference_steps} DDIM steps)", "value": value, "unit": "images/sec", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": {"fp32": "f32", "bf16x3": "f32 (bf16x3-split MFMA)", "bf16": "bf16 products, f32 accumulate"}[args.datapath],
         "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[1]: compressed-animals geometry, {args.model} U-Net+VAE (random init), "
+        "config": {"workload": f"BASELINE configs[{1 if args.model == 'sd15' else 4}]: {'compressed-animals' if args.model == 'sd15' else 'neg_jpeg'} geometry, "
+                               f"{args.model} U-Net+VAE (random init), "
                                f"{args.resolution}x{args.resolution}, {args.n_inference_steps} DDIM steps, CFG 5.0, eta 1.0, "
                                f"sample_batch_size {B}/GPU, VAE decode included",
                    "datapath": {"fp32": "exact-fp32 MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4_f32)",
@@ -296,10 +508,10 @@ def main():
                    "global_batch": world * B},
         "end_to_end_tflops": None if tflop_per_image is None else value * tflop_per_image,
         "roofline": roofline, "cpu_baseline": cpu,
+        "rccl_ranks": world if comm.dist is not None else None, "allreduce": ar, "extra": extra,
     }
     print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    comm.close()
 
 
 if __name__ == "__main__":
