@@ -1114,10 +1114,10 @@ static int wide_splits(const ddpo_gemm_desc& d, bool have_ws, size_t ws_bytes) {
   return splits;
 }
 
-template <int NPASS, int APL = 0>
+template <int NPASS, int APL = 0, int WM = 4>
 static int launch_bf16_wide(const ddpo_gemm_desc& d, const uint16_t* w_hi, const uint16_t* w_lo, int ldw, float* ws, size_t ws_bytes,
                             hipStream_t st) {
-  constexpr int BM = 128, BN = 320, WM = 4, WN = 2;
+  constexpr int BM = 128, BN = 320, WN = 2;      // WM = 4: 8 waves of 32x160 (two per SIMD); WM = 2: 4 waves of 64x160 (one per SIMD, 512 registers)
   const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;
   const int nblk = tiles_m * tiles_n;
   const int nk_total = d.K / BF_BK;
@@ -1211,16 +1211,24 @@ static int dispatch_bf16(const ddpo_gemm_desc& d, const uint16_t* w_hi, const ui
   // 128x320 tiles (one workgroup per CU) when they, times the split of the reduction, give every CU a workgroup; a
   // many-column GEMM with a very short reduction is better on 128x128 (measured: K=320, N=2560; the 160 KB epilogue image)
   if constexpr (APL != 0) {
-    // DDPO_APL_TALL=1 (tuning knob, NOT yet run on hardware): 256x320 tiles where they still give every CU a workgroup
-    static const int tall_mode = [] { const char* e = getenv("DDPO_APL_TALL"); return e ? atoi(e) : 0; }();
+    // 256x320 tiles where they still give every CU a workgroup (the 64x64-latent level): 345 / 428 TF against 320 / 390 for the
+    // 128x320 tile on conv 320->320 / 960->320 (bit-identical; round-2 probe).  DDPO_APL_TALL=0 switches them off.
+    static const int tall_mode = [] { const char* e = getenv("DDPO_APL_TALL"); return e ? atoi(e) : 1; }();
     if (tall_mode && d.N % 320 == 0 && d.epilogue == 0 && (long)((d.M + 255) / 256) * (d.N / 320) >= 200)
       return launch_bf16_tall(d, w_hi, w_lo, ldw, st);
   }
   const int wsplits = wide_splits(d, wsf != nullptr, ws_bytes);
   if (wide_mode && d.N % 320 == 0 && d.M >= 512 && buf_path_ok(d, ldw) && !(d.K / BF_BK < 16 && d.N > 1280) &&
       (long)((d.M + 127) / 128) * (d.N / 320) * wsplits >= 200 &&
-      !(wsplits > 1 && d.K / BF_BK < 64))       // a split short reduction only adds the reduce pass (measured equal to 128x128 unsplit)
+      !(wsplits > 1 && d.K / BF_BK < 64)) {     // a split short reduction only adds the reduce pass (measured equal to 128x128 unsplit)
+    if constexpr (APL == 2) {
+      // DDPO_APL_W4=1 (tuning knob): the same tile on FOUR waves of 64x160, one per SIMD with the whole 512-entry register file —
+      // 0.47 fragment reads per MFMA instead of 0.8 and no second wave competing for the SIMD's matrix pipe
+      static const int w4_mode = [] { const char* e = getenv("DDPO_APL_W4"); return e ? atoi(e) : 0; }();
+      if (w4_mode) return launch_bf16_wide<3, 2, 2>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st);
+    }
     return npass == 3 ? launch_bf16_wide<3, APL>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st) : launch_bf16_wide<1>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st);
+  }
   const long t128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128);
   static const long big_min = [] { const char* e = getenv("DDPO_GEMM_BIG_MIN"); return e ? atol(e) : 256L; }();   // tuning knob (tools/)
   const bool big = (d.N % 128 == 0) && t128 >= big_min;
@@ -1276,9 +1284,10 @@ extern "C" int ddpo_gemm_conv_fwd_bf16_planes(const ddpo_gemm_desc* dp, const ui
   // pieces half a k-tile later than the lower half (the two waves of a SIMD then alternate between DMA issue and MFMAs).
   // 3 = mode 2 with the weight operand three LDS stages deep (requested two k-tiles ahead, counted vmcnt); 7 = 3 + stagger;
   // +8 on mode 2 / 6 (10 / 14) = s_setprio 1 around the MFMA clusters.
-  // Measured on the SD-1.5 layers at batch 16 (profiles/r01_probe_gemm_planes_modes.md): 6 (default) > 1 ~ 2 > fp32-fed;
-  // modes 3 / 7 / 10 / 14 were written after the round's GPU budget was spent and are NOT yet run on hardware.
-  static const int apl_mode = [] { const char* e = getenv("DDPO_APL_MODE"); return e ? atoi(e) : 6; }();
+  // Measured on the SD-1.5 layers at batch 16 (profiles/r01_probe_gemm_planes_modes.md, r02_planes_ab.md): warm, 6 ~ 7 ~ 14 > 1 ~ 2
+  // > fp32-fed; with the caches flushed before every launch (weights cold = the in-model condition) 7 keeps its gain (400 TF on
+  // conv 960->320 @ 64^2) while 6 drops to 359.  7 is the default; every mode is bit-identical to the fp32-fed kernel on hardware.
+  static const int apl_mode = [] { const char* e = getenv("DDPO_APL_MODE"); return e ? atoi(e) : 7; }();
   d.splits = (apl_mode & 4) ? 1 : 0;                 // `splits` is a wgrad-only field: the forward kernel reads it as the stagger flag
   if ((apl_mode & 11) == 10) return dispatch_bf16<5>(d, w_hi, w_lo, ldw, 3, ws, ws_bytes, as_stream(stream));   // 2 + 8: s_setprio (10 / 14)
   switch (apl_mode & 3) {

@@ -113,10 +113,10 @@ PACKED = {}          # data_ptr of an fp32 weight tensor -> dict(fwd=(hi, lo, Kp
 
 # Plane-fed GEMMs (bf16x3 datapath, inference / sampling forward only): GroupNorm / LayerNorm write their result as bf16
 # hi / lo planes and the consuming conv / linear layers fetch both operands by LDS-DMA (ddpo_gemm_conv_fwd_bf16_planes).
-# Bit-identical to the fp32-fed kernels (tests/test_gpu_planes.py).  Opt-in (DDPO_PLANES=1) for now: layer by layer the
-# plane-fed kernel is 9-23 % faster on the convolutions (profiles/r01_probe_gemm_planes_modes.md), but the end-to-end
-# sampling bench moved by only +0.7 % (3.249 vs 3.227 images/s on the same box) — see DESIGN.md §6 for what to measure next.
-PLANES = os.environ.get("DDPO_PLANES", "0") == "1"
+# Bit-identical to the fp32-fed kernels (tests/test_gpu_planes.py).  ON by default since round 2 (DDPO_PLANES=0 switches it
+# off): on one box, back to back, the sampling bench went 3.222 / 3.243 (off) -> 3.268 (k-loop mode 6) -> 3.297 (mode 7, three
+# weight stages) -> 3.344 images/s (mode 7 + 256x320 tiles at the 64x64 level), profiles/r02_planes_ab.md.
+PLANES = os.environ.get("DDPO_PLANES", "1") == "1"
 
 
 class Planes:

@@ -259,7 +259,7 @@ class UNet2DCondition:
         self.device = torch.device(device)
         self.params = ParamStore(unet_param_shapes(cfg), self.device)
         self.grads = None
-        self._ctx_kv = {}                 # cross-attention name -> (K, V) of the text context (precompute_context)
+        self._ctx_kv = {}                 # (cross-attention name, context rows) -> (K, V) of the text context (precompute_context)
         self._ctx_kv_active = False
 
     def ensure_grads(self):
@@ -272,7 +272,7 @@ class UNet2DCondition:
     def _attention(self, name, x, B, N, C, heads, ctx, ctx_len, rec=None):
         P = self.params
         q = L.linear(x, P[name + ".to_q.kernel"])
-        cached = self._ctx_kv.get(name) if (ctx is not None and rec is None and self._ctx_kv_active) else None
+        cached = self._ctx_kv.get((name, ctx.shape[0])) if (ctx is not None and rec is None and self._ctx_kv_active) else None
         if cached is not None:                     # text-context K / V were projected once for this sampling call
             k, v = cached
         else:
@@ -482,16 +482,18 @@ class UNet2DCondition:
         """Project the (constant) text context through every cross-attention to_k / to_v ONCE for a sampling call: the 50
         DDIM steps then skip 32 small GEMMs each.  Results land in persistent buffers (same addresses across calls, so a
         captured HIP graph keeps reading them); bit-identical to projecting per step.  Valid until `release_context()` or
-        the next parameter update — the sampler brackets its step loop with these two calls."""
+        the next parameter update — the sampler brackets its step loop with these two calls.
+        Buffers are keyed by (layer, context rows) and never freed or replaced: a HIP graph captured for one batch geometry
+        keeps valid addresses when the same U-Net later samples another geometry and comes back (batch 8 -> 4 -> 8)."""
         B, Lc, D = context.shape
         ctx = context.reshape(B * Lc, D).contiguous()
         for name in self.cross_attention_names():
             wk, wv = self.params[name + ".to_k.kernel"], self.params[name + ".to_v.kernel"]
-            ent = self._ctx_kv.get(name)
-            if ent is None or ent[0].shape != (B * Lc, wk.shape[1]):
+            ent = self._ctx_kv.get((name, B * Lc))
+            if ent is None:
                 ent = (torch.empty(B * Lc, wk.shape[1], dtype=torch.float32, device=self.device),
                        torch.empty(B * Lc, wv.shape[1], dtype=torch.float32, device=self.device))
-                self._ctx_kv[name] = ent
+                self._ctx_kv[(name, B * Lc)] = ent
             L.linear(ctx, wk, out=ent[0])
             L.linear(ctx, wv, out=ent[1])
         self._ctx_kv_active = True

@@ -93,7 +93,6 @@ def test_entrypoint_llava_bertscore_with_stub_server(tmp_path, monkeypatch):
         srv.shutdown()
 
 
-@pytest.mark.skipif(os.environ.get("DDPO_EXPERIMENTAL") != "1", reason="DDPO_RESUME was written after the round-1 GPU budget was spent: set DDPO_EXPERIMENTAL=1")
 def test_entrypoint_resume_continues_the_run(tmp_path, monkeypatch):
     """One epoch, stop, resume for the second epoch (DDPO_RESUME) == two epochs in one go: same prompts and noise (host RNG
     streams and the sampling key are part of the bundle), rewards and final weights equal up to the atomics' fp32 noise."""

@@ -92,6 +92,31 @@ def test_sampler_matches_oracle_config1(tiny):
     assert np.abs(img - oimg).max() < 5e-3
 
 
+def test_graph_replay_survives_a_change_of_sampling_geometry(tiny):
+    """the text-context K/V buffers are keyed by (layer, context rows) and never replaced, so a HIP graph captured
+    for batch 2 still reads valid K/V after the same U-Net sampled batch 1 in between (it used to replay against freed memory)."""
+    _, unet, _, vae = tiny
+    sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", set_alpha_to_one=False, steps_offset=1)
+    pipe = StableDiffusionPipeline(unet, vae, sched)
+    state = sched.create_state(device=DEV)
+    g = torch.Generator().manual_seed(11)
+    emb2 = torch.randn(2, 77, 64, generator=g).to(DEV)
+    neg2 = torch.randn(1, 77, 64, generator=g).expand(2, -1, -1).contiguous().to(DEV)
+    emb1 = torch.randn(1, 77, 64, generator=g).to(DEV)
+    key = OP.PRNGKey(5)
+    run = lambda e, n, jit: pipe(e, n, {"unet": unet.params, "scheduler": state}, key, 4, height=64, width=64, guidance_scale=5.0,
+                                 eta=1.0, jit=jit)
+    eager2 = run(emb2, neg2, False)
+    first2 = run(emb2, neg2, True)                      # captures the batch-2 graph
+    run(emb1, neg2[:1].contiguous(), True)              # another geometry: new K/V buffers, its own graph
+    junk = [torch.full((1 << 20,), float("nan"), device=DEV) for _ in range(8)]     # recycle anything that was freed
+    again2 = run(emb2, neg2, True)                      # replay of the batch-2 graph
+    del junk
+    for a, b, c in zip(eager2, first2, again2):
+        assert torch.equal(a, b) and torch.equal(a, c)
+    assert len({k[1] for k in unet._ctx_kv}) == 2       # both context geometries stay resident
+
+
 def test_unet_sd15_single_sample_64x64():
     """Full SD-1.x architecture (859.5 M params) at the 512^2 latent size, one sample, against the torch-CPU oracle."""
     shapes = OU.unet_param_shapes(OU.SD15)
