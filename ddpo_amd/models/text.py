@@ -54,7 +54,25 @@ class TextEncoder:
         self.device = torch.device(device)
         sub = os.path.join(pretrained_dir, "text_encoder") if pretrained_dir else None
         if sub and os.path.isdir(sub):
-            self.model = CLIPTextModel.from_pretrained(sub)
+            has_torch = any(os.path.exists(os.path.join(sub, f)) for f in ("model.safetensors", "pytorch_model.bin"))
+            fx = os.path.join(sub, "flax_model.msgpack")
+            if has_torch:
+                self.model = CLIPTextModel.from_pretrained(sub)
+            elif os.path.exists(fx):
+                # HF Flax repositories (the reference's default `duongna/stable-diffusion-v1-4-flax`) ship only the Flax tree:
+                # read it with the in-tree msgpack reader and transpose it into the torch module (no flax / jax needed)
+                from ..utils.flax_msgpack import flatten, from_bytes
+                from ..utils.serialization import flax_clip_text_to_torch
+                self.model = CLIPTextModel(CLIPTextConfig.from_pretrained(sub))
+                with open(fx, "rb") as f:
+                    sd = flax_clip_text_to_torch(flatten(from_bytes(f.read())))
+                want = {k for k in self.model.state_dict() if not k.endswith("position_ids")}
+                missing, extra = sorted(want - set(sd)), sorted(set(sd) - want)
+                if missing:
+                    raise KeyError(f"{fx}: parameters missing for CLIPTextModel: {missing[:4]}{'...' if len(missing) > 4 else ''}")
+                self.model.load_state_dict({k: v for k, v in sd.items() if k not in extra}, strict=False)
+            else:
+                raise FileNotFoundError(f"{sub} holds neither PyTorch (model.safetensors / pytorch_model.bin) nor Flax (flax_model.msgpack) weights")
             self.synthetic = False
         else:
             if hidden == 768:      # CLIP ViT-L/14 text tower (SD-1.x): 123,060,480 parameters

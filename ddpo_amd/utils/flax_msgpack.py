@@ -55,7 +55,8 @@ def _ext_unpack(code, data):
 def _chunk(arr):
     flat = arr.reshape(-1)
     per = max(1, _MAX_CHUNK_BYTES // arr.dtype.itemsize)
-    return {"__msgpack_chunked_array__": True, "shape": list(arr.shape),
+    # flax writes both tuples through `_tuple_to_dict`: shape = {"0": n, "1": m}, chunks = {"0": ..., "1": ...}
+    return {"__msgpack_chunked_array__": True, "shape": {str(i): int(n) for i, n in enumerate(arr.shape)},
             "chunks": {str(i): flat[o:o + per] for i, o in enumerate(range(0, flat.size, per))}}
 
 
@@ -73,8 +74,10 @@ def _prepare(tree):
 def _unchunk(tree):
     if isinstance(tree, dict):
         if tree.get("__msgpack_chunked_array__"):
-            chunks = tree["chunks"]
-            return np.concatenate([chunks[str(i)] for i in range(len(chunks))]).reshape(tree["shape"])
+            chunks, shape = tree["chunks"], tree["shape"]
+            if isinstance(shape, dict):               # flax's form; a plain list (files written before round 2) is accepted too
+                shape = tuple(int(shape[str(i)]) for i in range(len(shape)))
+            return np.concatenate([chunks[str(i)] for i in range(len(chunks))]).reshape(tuple(shape))
         return {k: _unchunk(v) for k, v in tree.items()}
     return tree
 

@@ -4,17 +4,33 @@
 params = {"text_encoder", "vae", "unet", "scheduler"}; the scheduler state is whatever scheduler the checkpoint ships
 (the entrypoint replaces the scheduler by the DDIM one and only duck-types the state, reference quirk #4).
 
-Weight sources, in order:
-  1. a local directory `pretrained_model` holding `unet.safetensors` / `vae.safetensors` with Flax-named tensors in
-     Flax layouts (what `save_checkpoint` below writes; a converted HF Flax checkpoint has the same names);
-  2. otherwise deterministic random-init weights of the right architecture (this container has no network and no
-     checkpoints) — a warning is printed and `pipeline.synthetic_weights` is True.
+What `pretrained_model` may be (the reference hands it to `FlaxStableDiffusionPipeline.from_pretrained`, :336-341):
+  * a local directory, or a hub id (`duongna/stable-diffusion-v1-4-flax`, the reference default) that resolves to a snapshot
+    in an HF cache directory (`<cache>/models--org--name/snapshots/<rev>`, `$HF_HOME/hub`, `~/.cache/huggingface/hub`) or to
+    `<cache>/<org>/<name>` / `<cache>/<name>` — there is no network here, so nothing is ever downloaded;
+  * in that directory, any of three layouts:
+      HF Flax      unet/diffusion_flax_model.msgpack, vae/diffusion_flax_model.msgpack   (nested Flax tree, HWIO / (in,out))
+      HF PyTorch   unet/diffusion_pytorch_model.safetensors|.bin, vae/...                (OIHW / (out,in) -> converted)
+      flat         unet.safetensors, vae.safetensors with Flax names (what `save_checkpoint` below writes)
+    plus `tokenizer/` and `text_encoder/` (PyTorch weights, or `flax_model.msgpack` converted to the torch module).
+  A directory that holds a U-Net but no VAE / tokenizer / text encoder is REFUSED (no silent mix of real and random parts).
+  With no weights at all the call fails, unless DDPO_ALLOW_SYNTHETIC=1 (set by the benchmark, the tests and the tools): then
+  deterministic random-init weights of the right architecture and a byte-level stand-in tokenizer are used,
+  `pipeline.synthetic_weights` is True and the entrypoint records that in args.json and in every checkpoint.
+
+`dtype` (reference :343-350 casts every parameter tree to it and computes in it): "float32" keeps fp32 parameters on the
+fp32-equivalent datapaths (lib.DATAPATH: bf16x3 by default in the entrypoint, or exact fp32); "bfloat16" rounds the
+parameters to bf16 and selects the single-pass bf16 MFMA datapath with fp32 accumulation — what XLA does with bf16
+parameters.  Activations between layers stay fp32 here (XLA would round them to bf16 as well): strictly more precise.
+
 Checkpoints: the reference saves only the U-Net params every `save_freq` epochs and can never resume
 (/root/reference/pipeline/policy_gradient.py:97-103,457-464); here `save_checkpoint` writes the params as safetensors
 (weights-only, same content) AND in the reference's own flax-msgpack file format (`checkpoint_<epoch>`, readable by its
 `flax:` load path; `utils/flax_msgpack.py`), plus an optional resume bundle (optimizer moments, step, RNG keys, stat tracker).
 """
+import glob
 import os
+import re
 
 import numpy as np
 import torch
@@ -37,6 +53,113 @@ def model_family(pretrained_model):
     return "sd21" if ("stable-diffusion-2" in name or "sd21" in name or "sd-2" in name) else "sd15"
 
 
+def allow_synthetic():
+    return os.environ.get("DDPO_ALLOW_SYNTHETIC", "0") == "1"
+
+
+def resolve_pretrained(pretrained_model, cache="cache"):
+    """Local directory for `pretrained_model` (a path or a hub id), or None.  Nothing is downloaded."""
+    pm = str(pretrained_model)
+    if os.path.isdir(pm):
+        return pm
+    roots = [r for r in (cache, os.path.join(os.environ["HF_HOME"], "hub") if os.environ.get("HF_HOME") else None,
+                         os.environ.get("HUGGINGFACE_HUB_CACHE"), os.path.expanduser("~/.cache/huggingface/hub")) if r]
+    for root in roots:
+        snaps = sorted(glob.glob(os.path.join(root, "models--" + pm.replace("/", "--"), "snapshots", "*")))
+        if snaps:
+            return snaps[-1]
+        for cand in (os.path.join(root, pm), os.path.join(root, pm.split("/")[-1])):
+            if os.path.isdir(cand):
+                return cand
+    return None
+
+
+# ------------------------------------------------------------------------------------------------ layout converters
+def _load_state_file(path):
+    if path.endswith(".safetensors"):
+        from safetensors.torch import load_file
+        return load_file(path)
+    return torch.load(path, map_location="cpu", weights_only=True)
+
+
+_VAE_ATTN = {"to_q": "query", "to_k": "key", "to_v": "value", "to_out_0": "proj_attn"}
+
+
+def torch_to_flax_tree(state, shapes):
+    """diffusers-PyTorch state dict -> {flax_name: tensor in Flax layout} for the parameters named in `shapes`:
+    `blocks.<i>.` -> `blocks_<i>.`; conv `weight` OIHW -> `kernel` HWIO; dense `weight` (out,in) -> `kernel` (in,out); norm
+    `weight` -> `scale`; the VAE attention's newer `to_q/to_k/to_v/to_out.0` names -> `query/key/value/proj_attn`; a 1x1 conv
+    stored where a dense layer is expected (or the reverse: proj_in / proj_out, VAE attention) is reshaped."""
+    out = {}
+    for key, val in state.items():
+        name = re.sub(r"\.(\d+)(?=\.|$)", r"_\1", key)
+        parts = name.split(".")
+        if len(parts) >= 3 and parts[-3].startswith("attentions_") and parts[-2] in _VAE_ATTN and "transformer_blocks_0" not in name:
+            parts[-2] = _VAE_ATTN[parts[-2]]          # VAE mid-block attention only: the U-Net's to_q / to_k live under attn1 / attn2
+        leaf, stem = parts[-1], ".".join(parts[:-1])
+        name = stem + "." + leaf
+        t = torch.as_tensor(val).float()
+        if leaf == "weight":
+            if stem + ".scale" in shapes:
+                out[stem + ".scale"] = t
+                continue
+            tgt = shapes.get(stem + ".kernel")
+            if tgt is None:
+                continue
+            if t.dim() == 4:
+                t = t.permute(2, 3, 1, 0)
+            elif t.dim() == 2:
+                t = t.t()
+            if tuple(t.shape) != tuple(tgt) and t.numel() == int(np.prod(tgt)):
+                t = t.reshape(tgt)            # (1,1,I,O) <-> (I,O)
+            out[stem + ".kernel"] = t.contiguous()
+        elif leaf == "bias" and name in shapes:
+            out[name] = t
+    return out
+
+
+def flax_clip_text_to_torch(flat):
+    """Flax `FlaxCLIPTextModel` params (flattened with '.') -> state dict of transformers' torch `CLIPTextModel`."""
+    sd = {}
+    for name, v in flat.items():
+        t = torch.as_tensor(np.asarray(v)).float()
+        if name.endswith(".kernel"):
+            sd[name[:-len("kernel")] + "weight"] = t.t().contiguous()
+        elif name.endswith(".scale") or name.endswith(".embedding"):
+            sd[name.rsplit(".", 1)[0] + ".weight"] = t
+        else:
+            sd[name] = t
+    return sd
+
+
+def _find(local, sub, names):
+    for n in names:
+        p = os.path.join(local, sub, n) if sub else os.path.join(local, n)
+        if os.path.exists(p):
+            return p
+    return None
+
+
+def load_component(store, local, sub):
+    """Fill `store` (a ParamStore with Flax names / layouts) from `<local>/<sub>/...` in any of the three layouts; returns the
+    layout name, or None when the directory holds no weights for this component."""
+    from .flax_msgpack import flatten, from_bytes
+    p = _find(local, sub, ["diffusion_flax_model.msgpack"])
+    if p:
+        with open(p, "rb") as f:
+            store.load_dict(flatten(from_bytes(f.read())))
+        return "hf-flax"
+    p = _find(local, sub, ["diffusion_pytorch_model.safetensors", "diffusion_pytorch_model.fp32.safetensors", "diffusion_pytorch_model.bin"])
+    if p:
+        store.load_dict(torch_to_flax_tree(_load_state_file(p), store.shapes))
+        return "hf-pytorch"
+    p = _find(local, None, [sub + ".safetensors"])
+    if p:
+        store.load_dict(_load_state_file(p))
+        return "flat"
+    return None
+
+
 def _load_safetensors_into(store, path):
     from safetensors.torch import load_file
     store.load_dict(load_file(path))
@@ -44,21 +167,42 @@ def _load_safetensors_into(store, path):
 
 def load_unet(loadpath=None, epoch="latest", pretrained_model="duongna/stable-diffusion-v1-4-flax", dtype="float32",
               cache="cache", device="cuda", seed=0):
-    if dtype not in ("float32", torch.float32):
-        raise NotImplementedError("this engine computes on the exact-fp32 MFMA datapath; dtype must be float32")
+    from .. import lib as L
+    dname = str(dtype).replace("torch.", "").replace("jnp.", "")
+    if dname in ("bfloat16", "bf16"):
+        bf16_params = True
+        L.DATAPATH = "bf16"           # single-pass bf16 MFMA, fp32 accumulate: XLA's arithmetic with bf16 parameters
+    elif dname in ("float32", "fp32", "f32"):
+        bf16_params = False
+    else:
+        raise ValueError(f"dtype must be float32 or bfloat16 (reference config/base.py:71), got {dtype!r}")
     family = model_family(pretrained_model)
     ucfg = UNetConfig.named(family)
     vcfg = VAEConfig.named("tiny" if family.startswith("tiny") else "sd")
     unet, vae = UNet2DCondition(ucfg, device), VAEDecoder(vcfg, device)
-    local = pretrained_model if os.path.isdir(str(pretrained_model)) else None
-    synthetic = True
-    if local and os.path.exists(os.path.join(local, "unet.safetensors")):
-        _load_safetensors_into(unet.params, os.path.join(local, "unet.safetensors"))
-        _load_safetensors_into(vae.params, os.path.join(local, "vae.safetensors"))
+    local = resolve_pretrained(pretrained_model, cache)
+    synthetic, layout = True, None
+    if local is not None:
+        layout = load_component(unet.params, local, "unet")
+    if layout is not None:
+        missing = []
+        if load_component(vae.params, local, "vae") is None:
+            missing.append("vae")
+        missing += [d for d in ("tokenizer", "text_encoder") if not os.path.isdir(os.path.join(local, d))]
+        if missing:
+            raise FileNotFoundError(f"'{local}' holds U-Net weights ({layout}) but no {', '.join(missing)}: refusing to mix real and "
+                                    f"random-init components")
         synthetic = False
+        print(f"[ utils/serialization ] loaded {family} U-Net + VAE from {local} ({layout} layout)")
     else:
-        print(f"[ utils/serialization ] WARNING: no local weights for '{pretrained_model}' (offline) — using deterministic "
-              f"random-init {family} weights")
+        if not allow_synthetic():
+            raise FileNotFoundError(
+                f"no weights found for pretrained_model='{pretrained_model}' (looked for a local directory and for an HF cache snapshot "
+                f"under cache='{cache}', $HF_HOME/hub, ~/.cache/huggingface/hub; nothing is downloaded).  Point --pretrained_model "
+                f"at a directory with unet/, vae/, tokenizer/, text_encoder/ — or set DDPO_ALLOW_SYNTHETIC=1 to run on deterministic "
+                f"RANDOM-INIT weights (benchmarks / tests only: such a run optimises noise)")
+        print(f"[ utils/serialization ] WARNING: DDPO_ALLOW_SYNTHETIC=1 and no local weights for '{pretrained_model}' — using "
+              f"deterministic random-init {family} weights; checkpoints of this run are marked synthetic")
         unet.params.init_synthetic(seed)
         vae.params.init_synthetic(seed + 1)
     if loadpath and str(loadpath).startswith("flax:"):
@@ -77,16 +221,20 @@ def load_unet(loadpath=None, epoch="latest", pretrained_model="duongna/stable-di
             fx = loadpath if epoch == "latest" else os.path.join(loadpath, f"checkpoint_{epoch}")
             print(f"[ utils/serialization ] loading fine-tuned U-Net from flax checkpoint {fx}")
             unet.params.load_dict(load_flax_checkpoint(fx))
-    from .. import lib as L
-    if L.DATAPATH != "fp32":          # bf16-split MFMA datapath: pre-split the contraction weights once
+    if bf16_params:                   # to_dtype(params, bfloat16) of the reference: round once, keep the fp32 container
+        for store in (unet.params, vae.params):
+            store.flat.copy_(store.flat.to(torch.bfloat16).to(torch.float32))
+    if L.DATAPATH != "fp32":          # bf16 MFMA datapaths: pre-split the contraction weights once
         unet.params.pack_bf16()
         vae.params.pack_bf16(bwd=False)
-    tokenizer = load_tokenizer(local)
-    text_encoder = TextEncoder(local, hidden=ucfg.cross_attention_dim, device=device, seed=seed + 2)
+    tokenizer = load_tokenizer(None if synthetic else local)
+    text_encoder = TextEncoder(None if synthetic else local, hidden=ucfg.cross_attention_dim, device=device, seed=seed + 2)
     pred = ucfg.prediction_type
     scheduler = DDIMScheduler(prediction_type=pred, **SD_SCHEDULER)
     pipeline = StableDiffusionPipeline(unet, vae, scheduler, text_encoder=text_encoder, tokenizer=tokenizer)
     pipeline.synthetic_weights = synthetic
+    pipeline.weights_source = None if synthetic else f"{local} ({layout})"
+    pipeline.param_dtype = "bfloat16" if bf16_params else "float32"
     params = {"unet": unet.params, "vae": vae.params, "text_encoder": text_encoder,
               "scheduler": scheduler.create_state(device=device)}
     return pipeline, params
@@ -100,7 +248,7 @@ def latest_checkpoint(ckpt_dir):
     return os.path.join(ckpt_dir, f"checkpoint_{steps[-1]}.safetensors") if steps else None
 
 
-def save_checkpoint(ckpt_dir, params, step, resume_state=None, flax_format=True):
+def save_checkpoint(ckpt_dir, params, step, resume_state=None, flax_format=True, synthetic_weights=False):
     """Rank-0 write of the U-Net params (Flax names / layouts) as `checkpoint_<step>.safetensors` (+ resume bundle) and,
     with `flax_format`, as `checkpoint_<step>` in flax's msgpack encoding — the file the reference's
     `save_checkpoint_multiprocess(..., unreplicate(state.params), step=epoch)` writes and its `flax:` load path reads."""
@@ -110,14 +258,17 @@ def save_checkpoint(ckpt_dir, params, step, resume_state=None, flax_format=True)
     path = os.path.join(ckpt_dir, f"checkpoint_{step}.safetensors")
     host = {n: v.detach().cpu().contiguous() for n, v in params.views.items()}
     if "safetensors" in formats:
-        save_file(host, path)
+        save_file(host, path, metadata={"synthetic_weights": str(bool(synthetic_weights)), "format": "flax-names"})
     else:
         path = os.path.join(ckpt_dir, f"checkpoint_{step}")
     if flax_format and "flax" in formats:
         from .flax_msgpack import save_flax_checkpoint
         save_flax_checkpoint(ckpt_dir, {n: v.numpy() for n, v in host.items()}, step)
+    if synthetic_weights:             # a run on random-init weights must not pass for a fine-tuned model
+        with open(os.path.join(ckpt_dir, "SYNTHETIC_WEIGHTS"), "w") as f:
+            f.write("this run started from deterministic random-init weights (DDPO_ALLOW_SYNTHETIC=1), not from a pretrained model\n")
     if resume_state is not None:
-        torch.save(resume_state, os.path.join(ckpt_dir, f"resume_{step}.pt"))
+        torch.save(dict(resume_state, synthetic_weights=bool(synthetic_weights)), os.path.join(ckpt_dir, f"resume_{step}.pt"))
     return path
 
 

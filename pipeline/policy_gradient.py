@@ -82,13 +82,14 @@ def main(argv=None):
 
     localpath = "logs/" + args.savepath.replace("gs://", "")
     os.makedirs(localpath, exist_ok=True)
-    with open(f"{localpath}/args.json", "w") as f:
-        json.dump(args._dict, f, indent=4, default=str)
 
     # --------------------------------- models ---------------------------------#
     print("loading models...")
     pipeline, params = load_unet(None, epoch=args.load_epoch, pretrained_model=args.pretrained_model, dtype=args.dtype,
                                  cache=args.cache, device=dev, seed=0)
+    with open(f"{localpath}/args.json", "w") as f:      # after loading: says which weights the run really started from
+        json.dump(dict(args._dict, synthetic_weights=bool(pipeline.synthetic_weights), weights_source=pipeline.weights_source,
+                       param_dtype=pipeline.param_dtype, datapath=L.DATAPATH), f, indent=4, default=str)
     pipeline.safety_checker = None
     unet, vae = pipeline.unet, pipeline.vae
     noise_scheduler_state = pipeline.scheduler.set_timesteps(params["scheduler"], num_inference_steps=args.n_inference_steps)
@@ -266,7 +267,8 @@ def main(argv=None):
                           "nu": state.opt_state["nu"].cpu(), "sample_rng": sample_rng,
                           "tracker": None if per_prompt_stats is None else per_prompt_stats.state_dict(),
                           "mean_rewards": list(mean_rewards), "std_rewards": list(std_rewards), "wall": list(wall)}
-                save_checkpoint(os.path.join(args.savepath, "checkpoints"), state.params, step=epoch, resume_state=resume)
+                save_checkpoint(os.path.join(args.savepath, "checkpoints"), state.params, step=epoch, resume_state=resume,
+                                synthetic_weights=pipeline.synthetic_weights)
             D.barrier()
 
         if worker_id == 0:

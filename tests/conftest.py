@@ -8,8 +8,29 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# tests and tools run on deterministic random-init weights (no checkpoints exist offline); a plain run of the entrypoint
+# refuses to (ddpo_amd/utils/serialization.py) — tests/test_pretrained_layouts.py checks that refusal explicitly
+os.environ.setdefault("DDPO_ALLOW_SYNTHETIC", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    """`pytest tests` on a host without a HIP device (or without the built library) skips the gpu-marked tests instead of
+    failing 300 of them; on the GPU box nothing is skipped here — a missing library there must fail loudly."""
+    try:
+        import torch
+        have_gpu = torch.cuda.is_available()
+    except Exception:
+        have_gpu = False
+    if have_gpu:
+        return
+    skip = pytest.mark.skip(reason="needs an MI355X (no HIP device visible): run `pytest -m gpu` on the GPU box")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
 
 
 @pytest.fixture(scope="session")
