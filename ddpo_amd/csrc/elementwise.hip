@@ -5,7 +5,7 @@
 #include "common.h"
 #include <math.h>
 
-extern "C" int ddpo_abi_version(void) { return 3; }
+extern "C" int ddpo_abi_version(void) { return 4; }
 extern "C" size_t ddpo_sizeof_gemm_desc(void) { return sizeof(ddpo_gemm_desc); }
 extern "C" size_t ddpo_sizeof_ddim_consts(void) { return sizeof(ddpo_ddim_consts); }
 
@@ -465,6 +465,50 @@ extern "C" int ddpo_silu_fwd(const float* x, float* y, int64_t n, void* stream) 
   int64_t blocks = (n + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(silu_kernel, dim3((int)blocks), dim3(256), 0, as_stream(stream), x, y, n);
+  DDPO_LAUNCH_CHECK();
+  return DDPO_OK;
+}
+
+// quick-GELU of the OpenAI CLIP towers (reward model, /root/reference/ddpo/training/callbacks.py:60-95 -> transformers' `quick_gelu`):
+// y = x * sigmoid(1.702 x).  float4 per lane; HBM-bound (8 B / element).
+__global__ void __launch_bounds__(256) quick_gelu_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n4, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    float4 v = reinterpret_cast<const float4*>(x)[i];
+    v.x = v.x / (1.f + __expf(-1.702f * v.x)); v.y = v.y / (1.f + __expf(-1.702f * v.y));
+    v.z = v.z / (1.f + __expf(-1.702f * v.z)); v.w = v.w / (1.f + __expf(-1.702f * v.w));
+    reinterpret_cast<float4*>(y)[i] = v;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {          // ragged tail (n % 4 elements)
+    const int64_t i = (n & ~(int64_t)3) + threadIdx.x;
+    y[i] = x[i] / (1.f + __expf(-1.702f * x[i]));
+  }
+}
+extern "C" int ddpo_quick_gelu_fwd(const float* x, float* y, int64_t n, void* stream) {
+  if (!x || !y || n <= 0 || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15)) return DDPO_EINVAL;
+  int64_t blocks = ((n >> 2) + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(quick_gelu_kernel, dim3((int)blocks), dim3(256), 0, as_stream(stream), x, y, n >> 2, n);
+  DDPO_LAUNCH_CHECK();
+  return DDPO_OK;
+}
+
+// y[r, :] = x[r, :] / ||x[r, :]||_2  (image_features / norm of the aesthetic reward, callbacks.py:80-82); one wave per row, the
+// sum of squares is a wavefront shuffle reduction in a fixed order (bit-reproducible).
+__global__ void __launch_bounds__(256) l2_normalize_rows_kernel(const float* __restrict__ x, float* __restrict__ y, int rows, int cols) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* xr = x + (int64_t)row * cols;
+  float ss = 0.f;
+  for (int c = lane; c < cols; c += 64) ss += xr[c] * xr[c];
+  ss = wave_sum(ss);
+  const float inv = 1.f / sqrtf(ss);
+  float* yr = y + (int64_t)row * cols;
+  for (int c = lane; c < cols; c += 64) yr[c] = xr[c] * inv;
+}
+extern "C" int ddpo_l2_normalize_rows(const float* x, float* y, int rows, int cols, void* stream) {
+  if (!x || !y || rows <= 0 || cols <= 0) return DDPO_EINVAL;
+  hipLaunchKernelGGL(l2_normalize_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, as_stream(stream), x, y, rows, cols);
   DDPO_LAUNCH_CHECK();
   return DDPO_OK;
 }

@@ -36,7 +36,7 @@ class GemmDesc(ctypes.Structure):
                 ("w_dgrad", c_int), ("ld_w", c_int), ("splits", c_int), ("accumulate", c_int), ("epilogue", c_int)]
 
 
-ABI_VERSION = 3          # must equal ddpo_abi_version() of the loaded library (include/ddpo_hip.h)
+ABI_VERSION = 4          # must equal ddpo_abi_version() of the loaded library (include/ddpo_hip.h)
 
 _SIGS = {
     "ddpo_abi_version": (c_int, []),
@@ -94,6 +94,8 @@ _SIGS = {
     "ddpo_add": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "ddpo_geglu_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "ddpo_silu_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "ddpo_quick_gelu_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "ddpo_l2_normalize_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "ddpo_timestep_embedding": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "ddpo_nchw_to_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ddpo_nhwc_to_nchw": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
@@ -720,6 +722,21 @@ def geglu(x):
 def silu(x):
     out = torch.empty_like(x)
     _check(load().ddpo_silu_fwd(_p(x), _p(out), x.numel(), _stream()), "ddpo_silu_fwd")
+    return out
+
+
+def quick_gelu(x, out=None):
+    """x * sigmoid(1.702 x) (the OpenAI CLIP activation); in place when out is x."""
+    if out is None:
+        out = torch.empty_like(x)
+    _check(load().ddpo_quick_gelu_fwd(_p(x), _p(out), x.numel(), _stream()), "ddpo_quick_gelu_fwd")
+    return out
+
+
+def l2_normalize_rows(x):
+    rows, cols = x.shape
+    out = torch.empty_like(x)
+    _check(load().ddpo_l2_normalize_rows(_p(x), _p(out), rows, cols, _stream()), "ddpo_l2_normalize_rows")
     return out
 
 

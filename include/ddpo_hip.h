@@ -234,6 +234,11 @@ int ddpo_debug_gemm_ablate(const ddpo_gemm_desc* d, const uint16_t* w_hi, const 
 /* Small element-wise pieces. */
 int ddpo_geglu_fwd(const float* x, float* y, int64_t rows, int F, void* stream);      /* y = x[:, :F] * gelu_tanh(x[:, F:]) */
 int ddpo_silu_fwd(const float* x, float* y, int64_t n, void* stream);
+/* Reward-model pieces (aesthetic_fn, /root/reference/ddpo/training/callbacks.py:60-95: CLIP ViT-L/14 image tower + LAION MLP run on
+ * this library's GEMM / LayerNorm / attention kernels): quick-GELU y = x * sigmoid(1.702 x) (x, y 16-byte aligned), and the row-wise
+ * L2 normalisation of the image features (:80-82). */
+int ddpo_quick_gelu_fwd(const float* x, float* y, int64_t n, void* stream);
+int ddpo_l2_normalize_rows(const float* x, float* y, int rows, int cols, void* stream);
 int ddpo_timestep_embedding(const int32_t* ts, float* out, int B, int dim, void* stream); /* concat([cos, sin]) */
 int ddpo_nchw_to_nhwc(const float* x, float* y, int B, int C, int HW, void* stream);
 int ddpo_nhwc_to_nchw(const float* x, float* y, int B, int C, int HW, void* stream);

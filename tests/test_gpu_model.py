@@ -205,8 +205,8 @@ def test_sd21_shaped_config_sampler_and_train_step(datapath):
         tstate, info = train_step(tstate, {k: v.to(DEV) for k, v in batch.items()}, st4, sched, True, 5.0, 1.0, 1e-4, do_opt_update=False)
         gn_o = math.sqrt(sum(float((v.double() ** 2).sum()) for v in ograds.values()))
         gn = math.sqrt(float((unet.grads.flat.double() ** 2).sum()))
-        tol = 1e-3 if datapath == "fp32" else 3e-3     # PPO's 1e-4 clip range amplifies log-prob noise on the bf16x3 path
-        assert gn == pytest.approx(gn_o, rel=tol)
+        print(f"\n[tiny21 T=4 train step] {datapath}: grad-norm rel err {abs(gn - gn_o) / gn_o:.2e}")
+        assert gn == pytest.approx(gn_o, rel=1e-3)       # north_star tolerance on BOTH datapaths, at the reference's clip range 1e-4
     finally:
         L.DATAPATH = old
         L.PACKED.clear()
