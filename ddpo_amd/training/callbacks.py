@@ -65,13 +65,14 @@ def neg_jpeg_fn(*a, **kw):
 
 # ------------------------------------------------------------------------------------------------ LAION aesthetic
 def aesthetic_fn(devices=None, rng=0, cache="cache", jit=True, weights_dir=None):
-    """CLIP ViT-L/14 image features -> L2-normalise -> LAION aesthetic MLP (reference :60-95, ddpo/models/laion.py).
-    Runs on the GPU in torch on a private stream.  Without network access neither the CLIP checkpoint nor the MLP
-    weights can be fetched: pass `weights_dir` with `clip/` (HF format) and `sac+logos+ava1-l14-linearMSE.pth`;
-    otherwise deterministic random-init weights are used and the info dict says so."""
-    import torch
+    """CLIP ViT-L/14 image features -> L2-normalise -> LAION aesthetic MLP (reference :60-95, ddpo/models/laion.py), on the engine's
+    own kernels (models/clip_vision.py, models/laion.py), on a private HIP stream.  Weights: `weights_dir` or $DDPO_AESTHETIC_WEIGHTS
+    (`clip/` in HF format + `sac+logos+ava1-l14-linearMSE.pth`), else the HF cache and `<repo>/<cache>/` where the reference keeps the
+    `.pth`; nothing is downloaded.  Missing weights RAISE — an `a_*` run must not silently optimise a random reward — unless
+    DDPO_ALLOW_SYNTHETIC=1, in which case info['synthetic_weights'] is True."""
+    del devices, jit
     from ..models.laion import AestheticScorer
-    scorer = AestheticScorer(weights_dir=weights_dir, seed=rng)
+    scorer = AestheticScorer(weights_dir=weights_dir, cache=cache, seed=rng)
 
     def _wrapper(images, prompts, metadata):
         del prompts, metadata

@@ -184,3 +184,21 @@ def test_train_fuse_default_is_capped_by_the_validated_activation_footprint(monk
     assert train_fuse_default(4, 96 * 96) == 25
     monkeypatch.setenv("DDPO_TRAIN_FUSE", "0")
     assert train_fuse_default() == 1
+
+
+def test_aesthetic_reward_refuses_to_score_without_weights(monkeypatch, tmp_path):
+    """every `a_*` run used to optimise a random-init reward model silently.  Without weights the factory now raises (no GPU
+    needed to find that out) unless DDPO_ALLOW_SYNTHETIC=1."""
+    import pytest
+    from ddpo_amd.models import laion
+    monkeypatch.delenv("DDPO_ALLOW_SYNTHETIC", raising=False)
+    monkeypatch.delenv("DDPO_AESTHETIC_WEIGHTS", raising=False)
+    monkeypatch.setenv("HF_HOME", str(tmp_path))
+    with pytest.raises(FileNotFoundError, match="DDPO_ALLOW_SYNTHETIC"):
+        laion.AestheticScorer(cache=str(tmp_path / "cache"))
+    # the reference's own location for the MLP file is honoured: <cache>/sac+logos+ava1-l14-linearMSE.pth
+    (tmp_path / "cache").mkdir()
+    (tmp_path / "cache" / laion.MLP_FILE).write_bytes(b"x")
+    assert laion.find_weights(None, str(tmp_path / "cache"))[1] == str(tmp_path / "cache" / laion.MLP_FILE)
+    (tmp_path / "w" / "clip").mkdir(parents=True)
+    assert laion.find_weights(str(tmp_path / "w"), str(tmp_path / "cache"))[0] == str(tmp_path / "w" / "clip")
