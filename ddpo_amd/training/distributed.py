@@ -53,6 +53,20 @@ def allgather_array(x):
     return torch.cat(out, 0).cpu().numpy()
 
 
+def allgather_tensor(t):
+    """Concatenate equally-shaped per-rank tensors along axis 0 on every rank, staying on the tensor's device when the backend can
+    (nccl = RCCL: one all_gather_into_tensor over xGMI; gloo: through host memory)."""
+    if process_count() == 1:
+        return t
+    src = t.contiguous()
+    cd = _comm_device()
+    if src.device != cd:
+        src = src.to(cd)
+    out = torch.empty((process_count() * src.shape[0],) + tuple(src.shape[1:]), dtype=src.dtype, device=cd)
+    dist.all_gather_into_tensor(out, src)
+    return out.to(t.device)
+
+
 def allgather_strings(strings):
     strings = list(strings)
     if process_count() == 1:

@@ -12,7 +12,8 @@ PPO-clip updates on the stored log-probs (HIP forward/backward, one RCCL all-red
 Mirrors /root/reference/pipeline/policy_gradient.py:45-480 step for step (same flags, same artefacts under
 logs/<savepath>/, same Python/numpy RNG call order for prompts and shuffles, same JAX key tree for the noise).
 Data parallelism follows the reference's multi-host mode with ONE local device per process: seed + rank
-(ddpo/utils/parser.py:177), per-process prompts, rewards all-gathered, this rank's slice of the advantages.
+(ddpo/utils/parser.py:177), per-process prompts, rewards all-gathered, this rank's slice of the advantages;
+DDPO_DP_SEMANTICS=single_host reproduces the single-host N-device run instead (ddpo_amd/training/dp.py).
 Differences, all deliberate: trajectories stay in HBM instead of round-tripping through host numpy (:292-295,:415-423);
 gradients are all-reduced once per optimizer update instead of every micro-step (ddpo/training/policy_gradient.py:141);
 `info` is fetched once per inner epoch instead of a blocking device_get + assert_equal per step (:442-445).
@@ -33,6 +34,7 @@ import torch
 
 from ddpo_amd import training, utils
 from ddpo_amd.training import distributed as D
+from ddpo_amd.training.dp import DataParallel
 from ddpo_amd.training.policy_gradient import (AccumulatingTrainState, AdamWConfig, train_fuse_default, train_step,
                                                train_steps_fused)
 from ddpo_amd.utils import prng
@@ -58,7 +60,10 @@ def main(argv=None):
     from ddpo_amd import lib as L
     L.DATAPATH = os.environ.get("DDPO_DATAPATH", "bf16x3")
 
-    args = Parser(argv).parse_args("pg", process_index=worker_id)
+    # which reference run the ranks reproduce: one PROCESS each (default) or one DEVICE each of a single-host run
+    # (DDPO_DP_SEMANTICS=single_host: identical seeds, global prompt / permutation streams, trajectories all-gathered; training/dp.py)
+    dp = DataParallel(rank=worker_id, world=n_workers)
+    args = Parser(argv).parse_args("pg", process_index=dp.seed_process_index)
     utils.init_logging("policy_gradient", args.verbose)
 
     rng = prng.PRNGKey(args.seed)
@@ -151,17 +156,17 @@ def main(argv=None):
         samples = []
         for i in range(args.num_sample_batches_per_epoch):
             # ----------------------------- make prompts ----------------------------- #
-            sample_prompts, training_prompts, prompt_metadata = training.make_prompts(
+            sample_prompts, training_prompts, prompt_metadata = dp.make_prompts(
                 args.prompt_fn, n_devices * args.sample_batch_size, args.identical_batch, evaluate=args.evaluate, **args.prompt_kwargs)
             # ----------------------------- sample ----------------------------- #
             sample_rng, sample_seed = prng.split(sample_rng)
-            sample_seeds = prng.split(sample_seed, n_devices)
+            sample_seeds = prng.split(sample_seed, dp.n_key_devices)
             sample_prompt_ids = pipeline.prepare_inputs(sample_prompts)
             sample_prompt_embeds = text_encode(sample_prompt_ids)
             timer()
             final_latents, latents, next_latents, log_probs, ts = pipeline(
                 sample_prompt_embeds, sample_uncond_prompt_embeds, {"unet": state.params, "scheduler": sampling_scheduler_params},
-                sample_seeds[0], args.n_inference_steps, jit=True, height=args.resolution, width=args.resolution,
+                dp.sample_key(sample_seeds), args.n_inference_steps, jit=True, height=args.resolution, width=args.resolution,
                 guidance_scale=args.guidance_scale, eta=args.eta)
             # ----------------------------- decode latents ----------------------------- #
             images = vae.decode(final_latents).cpu().numpy()
@@ -183,15 +188,14 @@ def main(argv=None):
         devs = {k: torch.cat([s[k] for s in samples]) for k in ("embeds", "latents", "next_latents", "log_probs", "ts")}
 
         # allgather rewards (for multi-process training)
-        rewards = D.allgather_array(host["rewards"])
+        rewards, prompts = dp.gather_rewards(host["rewards"], host["prompts"].tolist(), args.num_sample_batches_per_epoch)
         if per_prompt_stats is not None:
-            prompts = np.array(D.allgather_strings(host["prompts"].tolist()))
             advantages = per_prompt_stats.update(prompts, rewards)
             if worker_id == 0:
                 np.save(utils.fs.join_and_create(localpath, f"per_prompt_stats/{worker_id}_{epoch}.npy"), per_prompt_stats.get_stats())
         else:
             advantages = (rewards - np.mean(rewards)) / np.std(rewards)
-        advantages = D.local_slice(advantages, worker_id, n_workers)
+        advantages = dp.local_advantages(advantages)
         print(f"mean reward: {np.mean(rewards):.4f}")
         mean_rewards.append(float(np.mean(rewards)))
         std_rewards.append(float(np.std(rewards)))
@@ -201,25 +205,23 @@ def main(argv=None):
         np.save(utils.fs.join_and_create(localpath, f"rewards/{worker_id}_{epoch}.npy"), host["rewards"])
         np.save(utils.fs.join_and_create(localpath, f"prompts/{worker_id}_{epoch}.npy"), host["prompts"])
         np.save(utils.fs.join_and_create(localpath, f"callback_info/{worker_id}_{epoch}.npy"), callback_info)
-        devs["advantages"] = torch.as_tensor(np.asarray(advantages, dtype=np.float32)).to(dev)
+        devs["advantages"] = torch.as_tensor(np.asarray(advantages, dtype=np.float32).reshape(-1)).to(dev)
+        devs = dp.gather_global(devs, args.num_sample_batches_per_epoch)      # single_host: the per-epoch trajectory exchange
 
         for inner_epoch in range(args.num_inner_epochs):
             total_batch_size, num_timesteps = devs["log_probs"].shape
-            assert total_batch_size == args.num_sample_batches_per_epoch * n_devices * args.sample_batch_size
+            assert total_batch_size == args.num_sample_batches_per_epoch * n_devices * args.sample_batch_size * (n_workers if dp.single_host else 1)
             assert num_timesteps == args.n_inference_steps
-            # shuffle samples along the batch dimension, then along time independently for each sample
-            perm = torch.as_tensor(np.random.permutation(total_batch_size), device=dev)
-            devs = {k: v[perm] for k, v in devs.items()}
-            perms = torch.as_tensor(np.array([np.random.permutation(num_timesteps) for _ in range(total_batch_size)]), device=dev)
-            rows = torch.arange(total_batch_size, device=dev)[:, None]
-            for key in ("latents", "next_latents", "log_probs", "ts"):
-                devs[key] = devs[key][rows, perms]
+            # shuffle samples along the batch dimension, then along time independently for each sample; keep this rank's rows
+            devs = dp.shuffle(devs)
+            mine = dp.my_rows(devs, args.train_batch_size)
+            total_batch_size = mine["log_probs"].shape[0]
             num_train_ts = int(num_timesteps * args.train_timestep_ratio)
             n_mini = total_batch_size // (n_devices * args.train_batch_size)
             all_infos = []
             do_opt_update = False
             train_fuse = train_fuse_default(args.train_batch_size * (2 if args.train_cfg else 1),
-                                            devs["latents"].shape[-1] * devs["latents"].shape[-2])
+                                            mine["latents"].shape[-1] * mine["latents"].shape[-2])
             t_train = time.time()
             for i in range(n_mini):
                 sl = slice(i * args.train_batch_size, (i + 1) * args.train_batch_size)
@@ -227,10 +229,10 @@ def main(argv=None):
                     # DDPO_TRAIN_FUSE=k (default 10): k consecutive timesteps of this mini-batch (same parameters: the optimizer only
                     # steps at the last timestep) as one U-Net forward/backward over k micro-batches (train_steps_fused)
                     js = range(j0, min(j0 + train_fuse, num_train_ts))
-                    batches = [{"prompt_embeds": devs["embeds"][sl], "uncond_embeds": train_uncond_prompt_embeds,
-                                "advantages": devs["advantages"][sl], "latents": devs["latents"][sl, j],
-                                "next_latents": devs["next_latents"][sl, j], "log_probs": devs["log_probs"][sl, j],
-                                "ts": devs["ts"][sl, j]} for j in js]
+                    batches = [{"prompt_embeds": mine["embeds"][sl], "uncond_embeds": train_uncond_prompt_embeds,
+                                "advantages": mine["advantages"][sl], "latents": mine["latents"][sl, j],
+                                "next_latents": mine["next_latents"][sl, j], "log_probs": mine["log_probs"][sl, j],
+                                "ts": mine["ts"][sl, j]} for j in js]
                     do_opt_update = (js[-1] == num_train_ts - 1) and ((i + 1) % args.train_accumulation_steps == 0)
                     if do_opt_update:
                         print(f"opt update at {i}, {js[-1]}")
@@ -238,10 +240,10 @@ def main(argv=None):
                                                        args.guidance_scale, args.eta, args.ppo_clip_range, do_opt_update)
                     all_infos += [torch.stack([info["approx_kl"], info["clipfrac"], info["loss"]]) for info in infos_k]
                 for j in (range(num_train_ts) if train_fuse <= 1 else ()):
-                    batch = {"prompt_embeds": devs["embeds"][sl], "uncond_embeds": train_uncond_prompt_embeds,
-                             "advantages": devs["advantages"][sl], "latents": devs["latents"][sl, j],
-                             "next_latents": devs["next_latents"][sl, j], "log_probs": devs["log_probs"][sl, j],
-                             "ts": devs["ts"][sl, j]}
+                    batch = {"prompt_embeds": mine["embeds"][sl], "uncond_embeds": train_uncond_prompt_embeds,
+                             "advantages": mine["advantages"][sl], "latents": mine["latents"][sl, j],
+                             "next_latents": mine["next_latents"][sl, j], "log_probs": mine["log_probs"][sl, j],
+                             "ts": mine["ts"][sl, j]}
                     # update at the last timestep of a sequence once enough samples are accumulated
                     do_opt_update = (j == num_train_ts - 1) and ((i + 1) % args.train_accumulation_steps == 0)
                     if do_opt_update:

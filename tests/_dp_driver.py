@@ -33,6 +33,7 @@ except BaseException:
     raise
 from ddpo_amd.utils.serialization import latest_checkpoint
 shutil.copy(os.path.join(res["localpath"], f"rewards/{rank}_0.npy"), os.path.join(out, f"rewards_{rank}.npy"))
+shutil.copy(os.path.join(res["localpath"], f"prompts/{rank}_0.npy"), os.path.join(out, f"prompts_{rank}.npy"))
 flat = res["state"].params.flat.detach().cpu().numpy()
 info = np.load(os.path.join(res["localpath"], "train_info/0_0_0.npy"), allow_pickle=True).item() if rank == 0 else None
 if rank == 0:

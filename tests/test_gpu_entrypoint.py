@@ -52,12 +52,13 @@ def test_entrypoint_single_process(tmp_path, monkeypatch):
 
 
 @pytest.mark.timeout(600)
-def test_entrypoint_two_ranks_share_one_gpu(tmp_path):
+@pytest.mark.parametrize("semantics", ["multi_host", "single_host"])
+def test_entrypoint_two_ranks_share_one_gpu(tmp_path, semantics):
     """Data-parallel run with 2 processes (gloo carries the collectives because both ranks sit on the single test GPU;
     on a multi-GPU node the same code path runs over RCCL).  Both ranks must end with bit-identical weights."""
-    env = dict(os.environ, DDPO_MODEL_CONFIG="tiny", DDPO_DIST_BACKEND="gloo", PYTHONPATH=ROOT)
+    env = dict(os.environ, DDPO_MODEL_CONFIG="tiny", DDPO_DIST_BACKEND="gloo", PYTHONPATH=ROOT, DDPO_DP_SEMANTICS=semantics)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29571", os.path.join(ROOT, "tests", "_dp_driver.py"), str(tmp_path)]
+           "--master-port", "29571" if semantics == "multi_host" else "29573", os.path.join(ROOT, "tests", "_dp_driver.py"), str(tmp_path)]
     p = subprocess.run(cmd, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=580)
     errs = "".join(open(tmp_path / f).read() for f in os.listdir(tmp_path) if f.startswith("error_"))
     assert p.returncode == 0, errs + p.stderr[-1500:]
@@ -66,7 +67,16 @@ def test_entrypoint_two_ranks_share_one_gpu(tmp_path):
     assert h0 == h1
     r0 = np.load(tmp_path / "rewards_0.npy")
     r1 = np.load(tmp_path / "rewards_1.npy")
-    assert r0.shape == (2, 1) and not np.array_equal(r0, r1)                         # different seeds -> different samples
+    assert r0.shape == (2, 1) and not np.array_equal(r0, r1)                         # different seeds / device keys -> different samples
+    if semantics == "single_host":
+        # the ranks are the two DEVICES of one reference process: their prompts are the two halves of ONE `random` stream seeded
+        # with args.seed (no rank offset), drawn for the global batch (reference pipeline/policy_gradient.py:235-241)
+        import random
+        from ddpo_amd.training.prompts import make_prompts
+        random.seed(0)
+        want = make_prompts("imagenet_animals", 4, False, evaluate=False)[0]          # compressed_animals' prompt_fn
+        got = [str(x) for r in (0, 1) for x in np.load(tmp_path / f"prompts_{r}.npy")]
+        assert got == want
 
 
 def test_entrypoint_llava_bertscore_with_stub_server(tmp_path, monkeypatch):
