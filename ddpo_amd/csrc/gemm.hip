@@ -395,7 +395,7 @@ extern "C" int ddpo_gemm_conv_fwd(const ddpo_gemm_desc* dp, void* stream) {
   if (!dp) return DDPO_EINVAL;
   const ddpo_gemm_desc& d = *dp;
   if (!d.src || !d.w || !d.out || d.M <= 0 || d.N <= 0 || d.K <= 0) return DDPO_EINVAL;
-  if (d.epilogue != 0) return DDPO_EINVAL;                 // fused output stages exist on the bf16 datapath only
+  if (d.epilogue != 0 || d.out_hi || d.out_lo) return DDPO_EINVAL;     // fused / plane-emitting output stages exist on the bf16 datapath only
   if ((d.ld_src & 3) || (reinterpret_cast<uintptr_t>(d.src) & 15) || (reinterpret_cast<uintptr_t>(d.w) & 15)) return DDPO_EINVAL;
   if (d.ksize > 0) {
     if (d.ksize != 1 && d.ksize != 3) return DDPO_EINVAL;

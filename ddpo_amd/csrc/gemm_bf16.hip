@@ -27,6 +27,14 @@ __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t&
 
 __device__ __forceinline__ int swz_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }   // bytes
 
+// plane-emitting output stage: 4 consecutive output values -> 4 bf16 hi + 4 bf16 lo (the split the fp32-fed loader would apply)
+__device__ __forceinline__ void store_planes4(const ddpo_gemm_desc& d, int64_t row, int col, const float4 v) {
+  uint2 h, l;
+  split4(v, h, l);
+  *reinterpret_cast<uint2*>(d.out_hi + row * d.ld_planes + col) = h;
+  *reinterpret_cast<uint2*>(d.out_lo + row * d.ld_planes + col) = l;
+}
+
 // AFFINE: no upsampling / zero-insert in the gather, so the source address of tap (ky,kx) is rowptr + (ky*W + kx)*ld + ci
 // and all per-k-tile work is a mask test and one 64-bit add per row (the generic path recomputes coordinates).
 template <int BM, int BN, int NPASS, bool AFFINE>
@@ -900,7 +908,8 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
             const float4 rs = *reinterpret_cast<const float4*>(d.residual + (int64_t)row * d.ld_res + col);
             v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w;
           }
-          *reinterpret_cast<float4*>(d.out + (int64_t)row * d.ld_out + col) = v;
+          if (d.out) *reinterpret_cast<float4*>(d.out + (int64_t)row * d.ld_out + col) = v;
+          if (d.out_hi) store_planes4(d, row, col, v);
         }
       }
       return;
@@ -935,7 +944,8 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
         float4 o;
         o.x = (a.x + ba.x) * gelu_tanh_f(g.x + bg.x); o.y = (a.y + ba.y) * gelu_tanh_f(g.y + bg.y);
         o.z = (a.z + ba.z) * gelu_tanh_f(g.z + bg.z); o.w = (a.w + ba.w) * gelu_tanh_f(g.w + bg.w);
-        *reinterpret_cast<float4*>(d.out + (int64_t)row * d.ld_out + q * 32 + gc) = o;
+        if (d.out) *reinterpret_cast<float4*>(d.out + (int64_t)row * d.ld_out + q * 32 + gc) = o;
+        if (d.out_hi) store_planes4(d, row, q * 32 + gc, o);
       }
       return;
     }
@@ -964,7 +974,8 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
           const float4 rs = *reinterpret_cast<const float4*>(d.residual + (int64_t)row * d.ld_res + col);
           v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w;
         }
-        *reinterpret_cast<float4*>(d.out + (int64_t)row * d.ld_out + col) = v;
+        if (d.out) *reinterpret_cast<float4*>(d.out + (int64_t)row * d.ld_out + col) = v;
+        if (d.out_hi) store_planes4(d, row, col, v);
       }
     }
     return;
@@ -1023,9 +1034,25 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const ddpo_gemm_desc
       float x = d.alpha * v[e] + (d.bias ? d.bias[col + e] : 0.f);
       if (d.rowbias) x += d.rowbias[(int64_t)(row / d.rows_per_batch) * d.ld_rowbias + col + e];
       if (d.residual) x += d.residual[(int64_t)row * d.ld_res + col + e];
-      d.out[(int64_t)row * d.ld_out + col + e] = x;
+      v[e] = x;
+      if (d.out) d.out[(int64_t)row * d.ld_out + col + e] = x;
     }
+    if (d.out_hi) store_planes4(d, row, col, make_float4(v[0], v[1], v[2], v[3]));
   }
+}
+
+// plane-emitting output stage: only the vector output stage of the buffer-addressed kernels (and the split-K reduce) writes planes
+static bool planes_out_ok(const ddpo_gemm_desc& d) {
+  if (!d.out_hi) return d.out != nullptr && !d.out_lo;
+  if (!d.out_lo || d.ld_planes <= 0 || (d.ld_planes & 3)) return false;
+  if ((reinterpret_cast<uintptr_t>(d.out_hi) | reinterpret_cast<uintptr_t>(d.out_lo)) & 7) return false;
+  const int ncols = d.epilogue == 1 ? d.N / 2 : d.N;
+  if (d.ld_planes < ncols || (d.N & 3)) return false;
+  if (d.out && ((d.ld_out & 3) || (reinterpret_cast<uintptr_t>(d.out) & 15))) return false;
+  if (d.residual && ((d.ld_res & 3) || (reinterpret_cast<uintptr_t>(d.residual) & 15))) return false;
+  if (d.rowbias && ((d.ld_rowbias & 3) || (reinterpret_cast<uintptr_t>(d.rowbias) & 15))) return false;
+  if (d.bias && (reinterpret_cast<uintptr_t>(d.bias) & 15)) return false;
+  return true;
 }
 
 // buffer-addressed fast path: k-tiles never straddle a tap and every byte offset fits the 31-bit buffer range
@@ -1243,8 +1270,9 @@ extern "C" int ddpo_gemm_conv_fwd_bf16(const ddpo_gemm_desc* dp, const uint16_t*
   const ddpo_gemm_desc& d = *dp;
   if (npass != 1 && npass != 3) return DDPO_EINVAL;
   if (npass == 3 && !w_lo) return DDPO_EINVAL;
-  if (!d.src || !d.out || d.M <= 0 || d.N <= 0 || d.K <= 0 || (d.ld_src & 3) || (reinterpret_cast<uintptr_t>(d.src) & 15)) return DDPO_EINVAL;
+  if (!d.src || d.M <= 0 || d.N <= 0 || d.K <= 0 || (d.ld_src & 3) || (reinterpret_cast<uintptr_t>(d.src) & 15)) return DDPO_EINVAL;
   if ((reinterpret_cast<uintptr_t>(w_hi) & 15) || (w_lo && (reinterpret_cast<uintptr_t>(w_lo) & 15))) return DDPO_EINVAL;
+  if (!planes_out_ok(d) || (d.out_hi && !buf_path_ok(d, ldw))) return DDPO_EINVAL;
   if (d.ksize > 0) {
     if (d.ksize != 1 && d.ksize != 3) return DDPO_EINVAL;
     if ((d.Cin & 7) || d.K != d.ksize * d.ksize * d.Cin || d.M != d.B * d.OH * d.OW) return DDPO_EINVAL;
@@ -1266,7 +1294,7 @@ extern "C" int ddpo_gemm_conv_fwd_bf16_planes(const ddpo_gemm_desc* dp, const ui
                                               void* stream) {
   if (!dp || !a_hi || !a_lo || !w_hi || !w_lo) return DDPO_EINVAL;
   ddpo_gemm_desc d = *dp;
-  if (!d.out || d.M <= 0 || d.N <= 0 || d.K <= 0 || lda <= 0 || (lda & 7) || d.w_dgrad) return DDPO_EINVAL;
+  if (d.M <= 0 || d.N <= 0 || d.K <= 0 || lda <= 0 || (lda & 7) || d.w_dgrad || !planes_out_ok(d)) return DDPO_EINVAL;
   if (((reinterpret_cast<uintptr_t>(a_hi) | reinterpret_cast<uintptr_t>(a_lo) | reinterpret_cast<uintptr_t>(w_hi) |
         reinterpret_cast<uintptr_t>(w_lo)) & 15) || ldw < d.K || (ldw & 7)) return DDPO_EINVAL;
   if (d.ksize > 0) {
@@ -1384,7 +1412,15 @@ __device__ __forceinline__ bf16x8 lds_frag(const uint32_t* base, int row, int dw
   return __builtin_bit_cast(bf16x8, make_uint4(a.x, a.y, b.x, b.y));
 }
 
-__global__ void __launch_bounds__(BF_THREADS) gemm_wgrad_bf16_kernel(const ddpo_gemm_desc d, int tiles_n, int m_per_split) {
+// APLN / BPLN: that operand arrives ALREADY split into bf16 hi / lo planes ((rows, ld) bf16, same element offsets as the fp32
+// tensor: the activation planes a forward GroupNorm / LayerNorm wrote, or dY planes from a plane-emitting output stage) — the
+// loader then only has to pair pixels m / m+1 of a channel into a dword (one v_perm_b32 per plane dword) instead of running the
+// fp32 -> bf16 split (2 v_cvt_pk + 2 v_sub + 2 mask / shift per pair): the split was ~2/3 of this kernel's VALU work, which
+// bounds it (profiles/r01_train_fuse10_kernel_stats.md).  Same values reach the MFMAs: results are identical to the fp32-fed form.
+template <bool APLN, bool BPLN>
+__global__ void __launch_bounds__(BF_THREADS) gemm_wgrad_bf16_kernel(const ddpo_gemm_desc d, int tiles_n, int m_per_split,
+                                                                   const uint16_t* __restrict__ a_hi, const uint16_t* __restrict__ a_lo,
+                                                                   const uint16_t* __restrict__ b_hi, const uint16_t* __restrict__ b_lo) {
   constexpr int BM = 128, BN = 128, BK = 32;
   constexpr int PLANE = BM * WG_PITCH;                 // dwords per plane (BM == BN)
   __shared__ __attribute__((aligned(16))) uint32_t smem[2][4 * PLANE];     // per stage: A_hi | A_lo | B_hi | B_lo
@@ -1429,7 +1465,10 @@ __global__ void __launch_bounds__(BF_THREADS) gemm_wgrad_bf16_kernel(const ddpo_
     }
   const int64_t tap_off = conv ? ((int64_t)dky * d.W + dkx) * d.ld_src + ci : kg;
 
-  float4 ra[2][2], rb[2][2];
+  float4 ra[2][2], rb[2][2];          // fp32 operands; a plane operand keeps (hi.x, hi.y, lo.x, lo.y) raw bits in the same registers
+  auto as_f4 = [](const uint2 h, const uint2 l) {
+    return make_float4(__uint_as_float(h.x), __uint_as_float(h.y), __uint_as_float(l.x), __uint_as_float(l.y));
+  };
   auto load_tile = [&](int kt) {
 #pragma unroll
     for (int p = 0; p < 2; ++p)
@@ -1448,8 +1487,15 @@ __global__ void __launch_bounds__(BF_THREADS) gemm_wgrad_bf16_kernel(const ddpo_
               aoff = ((int64_t)(pb[p][e] * d.H + sy) * d.W + sx) * d.ld_src + ci;
             }
           }
-          if (ok) va = *reinterpret_cast<const float4*>(d.src + aoff);
-          if (nvalid) vb = *reinterpret_cast<const float4*>(d.w + (int64_t)m * d.ld_w + ng);
+          if (ok) {
+            if (APLN) va = as_f4(*reinterpret_cast<const uint2*>(a_hi + aoff), *reinterpret_cast<const uint2*>(a_lo + aoff));
+            else va = *reinterpret_cast<const float4*>(d.src + aoff);
+          }
+          if (nvalid) {
+            const int64_t boff = (int64_t)m * d.ld_w + ng;
+            if (BPLN) vb = as_f4(*reinterpret_cast<const uint2*>(b_hi + boff), *reinterpret_cast<const uint2*>(b_lo + boff));
+            else vb = *reinterpret_cast<const float4*>(d.w + boff);
+          }
         }
         ra[p][e] = va;
         rb[p][e] = vb;
@@ -1467,13 +1513,20 @@ __global__ void __launch_bounds__(BF_THREADS) gemm_wgrad_bf16_kernel(const ddpo_
       const int dw = pp + 8 * p;                        // dword (= pixel pair) index within the row
       const float* a0 = &ra[p][0].x; const float* a1 = &ra[p][1].x;
       const float* b0 = &rb[p][0].x; const float* b1 = &rb[p][1].x;
+      // plane operand: registers hold [ch0|ch1, ch2|ch3] (hi) and the same for lo, per pixel; pair channel j of pixels m, m+1
+      auto pair = [](const float* p0, const float* p1, int j, int plane) {
+        const uint32_t w0 = __float_as_uint(p0[2 * plane + (j >> 1)]), w1 = __float_as_uint(p1[2 * plane + (j >> 1)]);
+        return __builtin_amdgcn_perm(w1, w0, (j & 1) ? 0x07060302u : 0x05040100u);
+      };
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         uint32_t hi, lo;
-        split2(a0[j], a1[j], hi, lo);                   // (pixel m, pixel m+1) of channel k+j
+        if (APLN) { hi = pair(a0, a1, j, 0); lo = pair(a0, a1, j, 1); }
+        else split2(a0[j], a1[j], hi, lo);              // (pixel m, pixel m+1) of channel k+j
         st[(arow + j) * WG_PITCH + dw] = hi;
         st[PLANE + (arow + j) * WG_PITCH + dw] = lo;
-        split2(b0[j], b1[j], hi, lo);
+        if (BPLN) { hi = pair(b0, b1, j, 0); lo = pair(b0, b1, j, 1); }
+        else split2(b0[j], b1[j], hi, lo);
         st[2 * PLANE + (arow + j) * WG_PITCH + dw] = hi;
         st[3 * PLANE + (arow + j) * WG_PITCH + dw] = lo;
       }
@@ -1535,12 +1588,17 @@ __global__ void __launch_bounds__(BF_THREADS) gemm_wgrad_bf16_kernel(const ddpo_
     }
 }
 
-extern "C" int ddpo_gemm_conv_wgrad_bf16x3(const ddpo_gemm_desc* dp, void* stream) {
+static int wgrad_bf16x3(const ddpo_gemm_desc* dp, const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* b_hi, const uint16_t* b_lo,
+                       void* stream) {
   if (!dp) return DDPO_EINVAL;
   ddpo_gemm_desc d = *dp;
-  if (!d.src || !d.w || !d.out || d.M <= 0 || d.N <= 0 || d.K <= 0) return DDPO_EINVAL;
+  if ((!d.src && !a_hi) || (!d.w && !b_hi) || !d.out || d.M <= 0 || d.N <= 0 || d.K <= 0) return DDPO_EINVAL;
+  if ((a_hi && !a_lo) || (b_hi && !b_lo)) return DDPO_EINVAL;
   if ((d.ld_src & 3) || (d.ld_w & 3) || (d.N & 3) || (d.K & 3)) return DDPO_EINVAL;
-  if ((reinterpret_cast<uintptr_t>(d.src) | reinterpret_cast<uintptr_t>(d.w)) & 15) return DDPO_EINVAL;
+  if (!a_hi && (reinterpret_cast<uintptr_t>(d.src) & 15)) return DDPO_EINVAL;
+  if (!b_hi && (reinterpret_cast<uintptr_t>(d.w) & 15)) return DDPO_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(a_hi) | reinterpret_cast<uintptr_t>(a_lo) | reinterpret_cast<uintptr_t>(b_hi) | reinterpret_cast<uintptr_t>(b_lo)) & 7)
+    return DDPO_EINVAL;
   if (d.ksize > 0) {
     if (d.ksize != 1 && d.ksize != 3) return DDPO_EINVAL;
     if ((d.Cin & 3) || d.K != d.ksize * d.ksize * d.Cin || d.M != d.B * d.OH * d.OW) return DDPO_EINVAL;
@@ -1569,7 +1627,24 @@ extern "C" int ddpo_gemm_conv_wgrad_bf16x3(const ddpo_gemm_desc* dp, void* strea
   int mps = (d.M + splits - 1) / splits;
   mps = (mps + 31) / 32 * 32;
   splits = (d.M + mps - 1) / mps;
-  hipLaunchKernelGGL(gemm_wgrad_bf16_kernel, dim3(tiles, splits), dim3(BF_THREADS), 0, as_stream(stream), d, tiles_n, mps);
+  hipStream_t st = as_stream(stream);
+  const dim3 grid(tiles, splits), blk(BF_THREADS);
+  if (a_hi && b_hi) hipLaunchKernelGGL((gemm_wgrad_bf16_kernel<true, true>), grid, blk, 0, st, d, tiles_n, mps, a_hi, a_lo, b_hi, b_lo);
+  else if (a_hi) hipLaunchKernelGGL((gemm_wgrad_bf16_kernel<true, false>), grid, blk, 0, st, d, tiles_n, mps, a_hi, a_lo, b_hi, b_lo);
+  else if (b_hi) hipLaunchKernelGGL((gemm_wgrad_bf16_kernel<false, true>), grid, blk, 0, st, d, tiles_n, mps, a_hi, a_lo, b_hi, b_lo);
+  else hipLaunchKernelGGL((gemm_wgrad_bf16_kernel<false, false>), grid, blk, 0, st, d, tiles_n, mps, a_hi, a_lo, b_hi, b_lo);
   DDPO_LAUNCH_CHECK();
   return DDPO_OK;
+}
+
+extern "C" int ddpo_gemm_conv_wgrad_bf16x3(const ddpo_gemm_desc* dp, void* stream) {
+  return wgrad_bf16x3(dp, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+/* Same contraction with one or both operands pre-split into bf16 hi / lo planes (NULL pair = that operand is fp32 in the descriptor):
+ * a_* replace d->src (row stride d->ld_src ELEMENTS), dy_* replace d->w (row stride d->ld_w elements). */
+extern "C" int ddpo_gemm_conv_wgrad_bf16x3_planes(const ddpo_gemm_desc* dp, const uint16_t* a_hi, const uint16_t* a_lo,
+                                                  const uint16_t* dy_hi, const uint16_t* dy_lo, void* stream) {
+  if (!a_hi && !dy_hi) return DDPO_EINVAL;
+  return wgrad_bf16x3(dp, a_hi, a_lo, dy_hi, dy_lo, stream);
 }

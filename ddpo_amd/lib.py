@@ -33,10 +33,11 @@ class GemmDesc(ctypes.Structure):
                 ("ksize", c_int), ("stride", c_int), ("pad", c_int), ("upsample", c_int),
                 ("B", c_int), ("H", c_int), ("W", c_int), ("Cin", c_int),
                 ("OH", c_int), ("OW", c_int),
-                ("w_dgrad", c_int), ("ld_w", c_int), ("splits", c_int), ("accumulate", c_int), ("epilogue", c_int)]
+                ("w_dgrad", c_int), ("ld_w", c_int), ("splits", c_int), ("accumulate", c_int), ("epilogue", c_int),
+                ("out_hi", c_void_p), ("out_lo", c_void_p), ("ld_planes", c_int)]
 
 
-ABI_VERSION = 4          # must equal ddpo_abi_version() of the loaded library (include/ddpo_hip.h)
+ABI_VERSION = 5          # must equal ddpo_abi_version() of the loaded library (include/ddpo_hip.h)
 
 _SIGS = {
     "ddpo_abi_version": (c_int, []),
@@ -63,6 +64,7 @@ _SIGS = {
     "ddpo_gemm_conv_wgrad": (c_int, [POINTER(GemmDesc), c_void_p]),
     "ddpo_gemm_conv_fwd_bf16": (c_int, [POINTER(GemmDesc), c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "ddpo_gemm_conv_wgrad_bf16x3": (c_int, [POINTER(GemmDesc), c_void_p]),
+    "ddpo_gemm_conv_wgrad_bf16x3_planes": (c_int, [POINTER(GemmDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ddpo_gemm_conv_fwd_bf16_planes": (c_int, [POINTER(GemmDesc), c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_size_t,
                                                c_void_p]),
     "ddpo_split_planes_bf16": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p]),
@@ -119,6 +121,11 @@ PACKED = {}          # data_ptr of an fp32 weight tensor -> dict(fwd=(hi, lo, Kp
 # off): on one box, back to back, the sampling bench went 3.222 / 3.243 (off) -> 3.268 (k-loop mode 6) -> 3.297 (mode 7, three
 # weight stages) -> 3.344 images/s (mode 7 + 256x320 tiles at the 64x64 level), profiles/r02_planes_ab.md.
 PLANES = os.environ.get("DDPO_PLANES", "1") == "1"
+# The TRAINING forward writes its GroupNorm / LayerNorm results as planes too (they are consumed only by the layer's GEMM and by
+# its weight gradient, ddpo_gemm_conv_wgrad_bf16x3_planes): plane-fed forward GEMMs and no activation split in the wgrad loader.
+TRAIN_PLANES = os.environ.get("DDPO_TRAIN_PLANES", "1") == "1"
+# GEMM output stages that emit planes for a following GEMM (GEGLU -> FF2, block output -> down / up-sampler convolution)
+PLANES_OUT = os.environ.get("DDPO_PLANES_OUT", "1") == "1"
 
 
 class Planes:
@@ -152,6 +159,19 @@ def planes_ok(w, cin, rows):
     (pack_weights), 32-channel k-tiles that never straddle a tap, and 31-bit byte offsets (the conditions of the
     buffer-addressed kernel, buf_path_ok() in csrc/gemm_bf16.hip — the VAE's 512x512 levels at batch 8 exceed them)."""
     if not (PLANES and DATAPATH == "bf16x3" and cin % 32 == 0):
+        return False
+    ent = PACKED.get(w.data_ptr())
+    if ent is None:
+        return False
+    lim = 0x7FFFFFFF
+    return rows * cin * 4 < lim and ent["N"] * ent["fwd"][2] * 2 < lim
+
+
+def planes_out_ok(w, cin, rows, N):
+    """True when the GEMM / conv with weight `w` (reduction channels per tap `cin`, `rows` source rows, N output columns) runs on a
+    buffer-addressed bf16x3 kernel, i.e. can emit its result as planes (ddpo_gemm_desc.out_hi): the conditions of planes_ok()
+    except that the ACTIVATION may be fp32 (then only K % 32 and the 31-bit offsets matter), plus N % 4 == 0."""
+    if not (PLANES and PLANES_OUT and DATAPATH == "bf16x3" and cin % 32 == 0 and N % 4 == 0):
         return False
     ent = PACKED.get(w.data_ptr())
     if ent is None:
@@ -418,9 +438,10 @@ def pack_weights_geglu(w, bias):
     return True
 
 
-def linear_geglu(x, w, out=None):
+def linear_geglu(x, w, out=None, planes_out=False):
     """(x @ w + b)[:, :F] * gelu_tanh((x @ w + b)[:, F:]) in one launch; w must have been registered by pack_weights_geglu.
-    Returns None when it was not (caller falls back to linear + geglu)."""
+    Returns None when it was not (caller falls back to linear + geglu).  planes_out: the result comes back as `Planes` only
+    (for a plane-fed second feed-forward GEMM)."""
     ent = PACKED.get(w.data_ptr())
     if DATAPATH == "fp32" or ent is None or "geglu" not in ent or ent["geglu"]["stale"]:
         return None
@@ -432,12 +453,19 @@ def linear_geglu(x, w, out=None):
     pl = x if isinstance(x, Planes) else None
     if pl is not None and (DATAPATH != "bf16x3" or K % 32):
         raise DdpoHipError("plane-fed linear_geglu needs the bf16x3 datapath and K % 32 == 0 (check planes_ok before asking for planes)")
-    if out is None:
-        out = torch.empty(M, N // 2, dtype=torch.float32, device=x.device)
     d = GemmDesc()
+    opl = None
+    if planes_out:
+        if DATAPATH != "bf16x3":
+            raise DdpoHipError("plane-emitting linear_geglu needs the bf16x3 datapath")
+        opl = Planes(M, N // 2, x.device)
+        d.out_hi, d.out_lo, d.ld_planes = opl.hi.data_ptr(), opl.lo.data_ptr(), N // 2
+    else:
+        if out is None:
+            out = torch.empty(M, N // 2, dtype=torch.float32, device=x.device)
+        d.out = out.data_ptr(); d.ld_out = N // 2
     d.src = x.data_ptr(); d.ld_src = K
     d.bias = g["bias"].data_ptr()
-    d.out = out.data_ptr(); d.ld_out = N // 2
     d.alpha = 1.0
     d.M, d.N, d.K = int(M), int(N), int(K)
     d.epilogue = 1
@@ -453,7 +481,7 @@ def linear_geglu(x, w, out=None):
     if PROFILE is not None:
         e1.record()
         PROFILE.append((e0, e1, 2.0 * M * N * K, DATAPATH, 4.0 * (M * K + K * N + M * N // 2)))
-    return out
+    return opl if planes_out else out
 
 
 def _bf16_route(w, K, N, conv, dgrad):
@@ -477,8 +505,11 @@ def _bf16_route(w, K, N, conv, dgrad):
 
 
 def gemm_conv(src, w, *, M, N, K, bias=None, rowbias=None, rows_per_batch=0, residual=None, out=None, alpha=1.0,
-              w_trans=False, ld_src=None, ld_out=None, ld_res=None, conv=None):
-    """Generic entry: conv = dict(ksize, stride, pad, upsample, B, H, W, Cin, OH, OW) or None for a dense GEMM."""
+              w_trans=False, ld_src=None, ld_out=None, ld_res=None, conv=None, planes_out=None):
+    """Generic entry: conv = dict(ksize, stride, pad, upsample, B, H, W, Cin, OH, OW) or None for a dense GEMM.
+    planes_out: None -> returns the fp32 result; "both" -> (fp32, Planes) from ONE launch (the output stage also writes the
+    bf16 hi / lo planes a plane-fed consumer reads); "only" -> Planes (no fp32 tensor is written).  Check
+    planes_out_ok() first: only the buffer-addressed bf16x3 kernels have the plane-emitting output stage."""
     pl = src if isinstance(src, Planes) else None
     d = GemmDesc()
     d.src = src.data_ptr(); d.ld_src = int(ld_src if ld_src is not None else (conv["Cin"] if conv else K))
@@ -486,17 +517,26 @@ def gemm_conv(src, w, *, M, N, K, bias=None, rowbias=None, rows_per_batch=0, res
     d.bias = bias.data_ptr() if bias is not None else None
     if rowbias is not None:
         d.rowbias = rowbias.data_ptr(); d.rows_per_batch = int(rows_per_batch); d.ld_rowbias = int(rowbias.shape[-1])
-    if out is None:
+    opl = None
+    if planes_out is not None:
+        if planes_out not in ("both", "only"):
+            raise ValueError(planes_out)
+        opl = Planes(M, N, src.device)
+        d.out_hi, d.out_lo, d.ld_planes = opl.hi.data_ptr(), opl.lo.data_ptr(), N
+    if out is None and planes_out != "only":
         out = torch.empty(M, N, dtype=torch.float32, device=src.device)
     if residual is not None:
         d.residual = residual.data_ptr(); d.ld_res = int(ld_res if ld_res is not None else N)
-    d.out = out.data_ptr(); d.ld_out = int(ld_out if ld_out is not None else N)
+    if out is not None:
+        d.out = out.data_ptr(); d.ld_out = int(ld_out if ld_out is not None else N)
     d.alpha = float(alpha)
     d.M, d.N, d.K = int(M), int(N), int(K)
     if conv:
         for k in ("ksize", "stride", "pad", "upsample", "B", "H", "W", "Cin", "OH", "OW"):
             setattr(d, k, int(conv[k]))
     route = None if w_trans else _bf16_route(w, K, N, conv, False)
+    if opl is not None and (route is None or route[3] != 3):
+        raise DdpoHipError("a plane-emitting GEMM needs the bf16x3 datapath and registered weight planes (check planes_out_ok)")
     if pl is not None and (route is None or route[3] != 3 or (conv["Cin"] if conv else K) % 32 or ld_src is not None):
         raise DdpoHipError("a plane-fed GEMM needs the bf16x3 datapath, registered weight planes and 32-channel k-tiles "
                            "(check planes_ok before asking a producer for planes)")
@@ -520,7 +560,9 @@ def gemm_conv(src, w, *, M, N, K, bias=None, rowbias=None, rows_per_batch=0, res
         w_bytes = (4.0 if route is None else (4.0 if DATAPATH == "bf16x3" else 2.0)) * K * N
         io_bytes = a_bytes + w_bytes + 4.0 * M * N * (2 if residual is not None else 1)
         PROFILE.append((e0, e1, 2.0 * M * N * K, "fp32" if route is None else DATAPATH, io_bytes))
-    return out
+    if planes_out == "only":
+        return opl
+    return (out, opl) if planes_out == "both" else out
 
 
 def conv2d(x, w, bias, B, H, W, Cin, Cout, ksize, stride=1, pad=None, upsample=False, **kw):
@@ -647,9 +689,24 @@ def linear_wgrad(x, dy, dw):
 
 
 def gemm_wgrad(src, dy, dw, *, M, N, K, conv=None, ld_src=None, ld_dy=None, accumulate=True, splits=0, alpha=1.0):
+    """dw += A^T dY.  `src` / `dy` may be `Planes` (the forward input as a plane-emitting norm wrote it, dY from a plane-emitting
+    output stage): the bf16x3 kernel then skips the fp32 -> bf16 split of that operand."""
+    fast = DATAPATH != "fp32" and accumulate and (conv is None or (conv["stride"] in (1, 2) and conv["upsample"] in (0, 1) and
+                                                                      conv["pad"] == conv["ksize"] // 2)) and K >= 64 and N >= 32
+    spl = src if isinstance(src, Planes) else None
+    dpl = dy if isinstance(dy, Planes) else None
+    if not fast or DATAPATH != "bf16x3":           # exact-fp32 / single-pass kernels take fp32 operands (small layers: conv_out, tests)
+        if spl is not None:
+            src, spl = spl.float(), None
+        if dpl is not None:
+            dy, dpl = dpl.float(), None
     d = GemmDesc()
-    d.src = src.data_ptr(); d.ld_src = int(ld_src if ld_src is not None else (conv["Cin"] if conv else K))
-    d.w = dy.data_ptr(); d.ld_w = int(ld_dy if ld_dy is not None else N)
+    if spl is None:
+        d.src = src.data_ptr()
+    if dpl is None:
+        d.w = dy.data_ptr()
+    d.ld_src = int(ld_src if ld_src is not None else (conv["Cin"] if conv else K))
+    d.ld_w = int(ld_dy if ld_dy is not None else N)
     d.out = dw.data_ptr(); d.ld_out = int(N)
     d.alpha = float(alpha)
     d.M, d.N, d.K = int(M), int(N), int(K)
@@ -657,9 +714,11 @@ def gemm_wgrad(src, dy, dw, *, M, N, K, conv=None, ld_src=None, ld_dy=None, accu
     if conv:
         for k in ("ksize", "stride", "pad", "upsample", "B", "H", "W", "Cin", "OH", "OW"):
             setattr(d, k, int(conv[k]))
-    fast = DATAPATH != "fp32" and accumulate and (conv is None or (conv["stride"] in (1, 2) and conv["upsample"] in (0, 1) and
-                                                                      conv["pad"] == conv["ksize"] // 2)) and K >= 64 and N >= 32
-    if fast:
+    if fast and (spl is not None or dpl is not None):
+        _check(load().ddpo_gemm_conv_wgrad_bf16x3_planes(byref(d), _p(spl.hi) if spl else None, _p(spl.lo) if spl else None,
+                                                         _p(dpl.hi) if dpl else None, _p(dpl.lo) if dpl else None, _stream()),
+               "ddpo_gemm_conv_wgrad_bf16x3_planes")
+    elif fast:
         _check(load().ddpo_gemm_conv_wgrad_bf16x3(byref(d), _stream()), "ddpo_gemm_conv_wgrad_bf16x3")
     else:
         _check(load().ddpo_gemm_conv_wgrad(byref(d), _stream()), "ddpo_gemm_conv_wgrad")

@@ -180,11 +180,12 @@ def unet_param_shapes(cfg: UNetConfig):
 
 
 class Act:
-    """An NHWC activation: rows (B*H*W, C)."""
-    __slots__ = ("t", "B", "H", "W", "C")
+    """An NHWC activation: rows (B*H*W, C).  `pl`: the same values as bf16 hi / lo planes when the producing GEMM's output stage
+    also emitted them (sampling only) — a plane-fed consumer (down / up-sampler convolution) reads those instead of `t`."""
+    __slots__ = ("t", "B", "H", "W", "C", "pl")
 
-    def __init__(self, t, B, H, W, C):
-        self.t, self.B, self.H, self.W, self.C = t, B, H, W, C
+    def __init__(self, t, B, H, W, C, pl=None):
+        self.t, self.B, self.H, self.W, self.C, self.pl = t, B, H, W, C, pl
 
     @property
     def HW(self):
@@ -195,13 +196,15 @@ class Act:
         return self.B * self.H * self.W
 
 
-def resnet_forward(P, name, x: Act, temb_act, groups, eps, tape=None):
-    """FlaxResnetBlock2D: GN-SiLU-conv3x3 (+time proj) - GN-SiLU-conv3x3 (+ shortcut)."""
+def resnet_forward(P, name, x: Act, temb_act, groups, eps, tape=None, emit_planes=False):
+    """FlaxResnetBlock2D: GN-SiLU-conv3x3 (+time proj) - GN-SiLU-conv3x3 (+ shortcut).
+    emit_planes (sampling): conv2's output stage also writes the block output as planes (Act.pl) for a plane-fed sampler conv."""
     cout = P[name + ".conv1.bias"].numel()
     # inference / sampling (no tape): the two GroupNorm+SiLU results feed only their convolution, so they are written as bf16
     # hi / lo planes and the convolutions run plane-fed (LDS-DMA operands; bit-identical to the fp32-fed kernels)
-    pl1 = tape is None and L.planes_ok(P[name + ".conv1.kernel"], x.C, x.M)
-    pl2 = tape is None and L.planes_ok(P[name + ".conv2.kernel"], cout, x.M)
+    # training (tape): the same, the planes are what the weight gradients of conv1 / conv2 read (lib.TRAIN_PLANES)
+    pl1 = (tape is None or L.TRAIN_PLANES) and L.planes_ok(P[name + ".conv1.kernel"], x.C, x.M)
+    pl2 = (tape is None or L.TRAIN_PLANES) and L.planes_ok(P[name + ".conv2.kernel"], cout, x.M)
     h1, st1 = L.groupnorm(x.t, x.B, x.HW, P[name + ".norm1.scale"], P[name + ".norm1.bias"], groups, eps, True, return_stats=True,
                           planes=pl1)
     rowbias = None
@@ -215,11 +218,16 @@ def resnet_forward(P, name, x: Act, temb_act, groups, eps, tape=None):
     shortcut = (name + ".conv_shortcut.kernel") in P
     if shortcut:
         res, _, _ = L.conv2d(x.t, P[name + ".conv_shortcut.kernel"], P[name + ".conv_shortcut.bias"], x.B, x.H, x.W, x.C, cout, 1)
-    out, _, _ = L.conv2d(h2, P[name + ".conv2.kernel"], P[name + ".conv2.bias"], x.B, x.H, x.W, cout, cout, 3, residual=res)
+    opl = None
+    if emit_planes and tape is None and L.planes_out_ok(P[name + ".conv2.kernel"], cout, x.M, cout):
+        (out, opl), _, _ = L.conv2d(h2, P[name + ".conv2.kernel"], P[name + ".conv2.bias"], x.B, x.H, x.W, cout, cout, 3, residual=res,
+                                    planes_out="both")
+    else:
+        out, _, _ = L.conv2d(h2, P[name + ".conv2.kernel"], P[name + ".conv2.bias"], x.B, x.H, x.W, cout, cout, 3, residual=res)
     if tape is not None:
         tape.append(("resnet", dict(name=name, x=x, st1=st1, h1=h1, c1=c1, st2=st2, h2=h2, cout=cout, shortcut=shortcut,
                                     temb=temb_act is not None, groups=groups)))
-    return Act(out, x.B, x.H, x.W, cout)
+    return Act(out, x.B, x.H, x.W, cout, opl)
 
 
 def resnet_backward(P, G, r, d_out, tctx):
@@ -299,16 +307,20 @@ class UNet2DCondition:
             d_x = L.linear_dgrad(dv, P[name + ".to_v.kernel"], residual=d_x)
         return d_x
 
-    def _transformer(self, name, x: Act, ctx, ctx_len, heads, tape=None):
+    def _transformer(self, name, x: Act, ctx, ctx_len, heads, tape=None, emit_planes=False):
         P, cfg = self.params, self.cfg
         C, B, N = x.C, x.B, x.HW
         rec = None if tape is None else dict(name=name, x=x, heads=heads, ctx=ctx, ctx_len=ctx_len)
         tb = name + ".transformer_blocks_0"
         inf = tape is None                         # plane-fed GEMMs behind the norms (see resnet_forward)
-        pl_in = inf and L.planes_ok(P[name + ".proj_in.kernel"], C, B * N)
-        pl_1 = inf and all(L.planes_ok(P[f"{tb}.attn1.{n}.kernel"], C, B * N) for n in ("to_q", "to_k", "to_v"))
-        pl_2 = inf and L.planes_ok(P[tb + ".attn2.to_q.kernel"], C, B * N)
-        pl_3 = inf and L.planes_ok(P[tb + ".ff.net_0.proj.kernel"], C, B * N)
+        npl = inf or L.TRAIN_PLANES                # norm outputs as planes: sampling, and training when the wgrads read planes
+        pl_in = npl and L.planes_ok(P[name + ".proj_in.kernel"], C, B * N)
+        pl_1 = npl and all(L.planes_ok(P[f"{tb}.attn1.{n}.kernel"], C, B * N) for n in ("to_q", "to_k", "to_v"))
+        pl_2 = npl and L.planes_ok(P[tb + ".attn2.to_q.kernel"], C, B * N)
+        pl_3 = npl and L.planes_ok(P[tb + ".ff.net_0.proj.kernel"], C, B * N)
+        F = P[tb + ".ff.net_2.kernel"].shape[0]
+        pl_ff2 = inf and L.PLANES_OUT and L.planes_ok(P[tb + ".ff.net_2.kernel"], F, B * N)       # GEGLU output stage -> planes -> plane-fed FF2
+        pl_out = inf and emit_planes and L.planes_out_ok(P[name + ".proj_out.kernel"], C, B * N, C)
         hn, st = L.groupnorm(x.t, B, N, P[name + ".norm.scale"], P[name + ".norm.bias"], cfg.norm_groups, 1e-5, False, return_stats=True,
                              planes=pl_in)
         if cfg.use_linear_projection:
@@ -326,19 +338,22 @@ class UNet2DCondition:
         h2 = L.linear(a2, P[tb + ".attn2.to_out_0.kernel"], P[tb + ".attn2.to_out_0.bias"], residual=h1)
         l3 = ln("norm3", h2, pl_3)
         f = None
-        gg = L.linear_geglu(l3, P[tb + ".ff.net_0.proj.kernel"]) if tape is None else None     # sampling: GEGLU fused into the GEMM epilogue
+        # sampling: GEGLU fused into the GEMM epilogue, written as planes when FF2 can take them
+        gg = L.linear_geglu(l3, P[tb + ".ff.net_0.proj.kernel"], planes_out=pl_ff2) if tape is None else None
         if gg is None:
             f = L.linear(l3, P[tb + ".ff.net_0.proj.kernel"], P[tb + ".ff.net_0.proj.bias"])
             gg = L.geglu(f)
         h3 = L.linear(gg, P[tb + ".ff.net_2.kernel"], P[tb + ".ff.net_2.bias"], residual=h2)
+        po = dict(planes_out="both") if pl_out else {}
         if cfg.use_linear_projection:
-            out = L.linear(h3, P[name + ".proj_out.kernel"], P[name + ".proj_out.bias"], residual=x.t)
+            out = L.linear(h3, P[name + ".proj_out.kernel"], P[name + ".proj_out.bias"], residual=x.t, **po)
         else:
-            out, _, _ = L.conv2d(h3, P[name + ".proj_out.kernel"], P[name + ".proj_out.bias"], B, x.H, x.W, C, C, 1, residual=x.t)
+            out, _, _ = L.conv2d(h3, P[name + ".proj_out.kernel"], P[name + ".proj_out.bias"], B, x.H, x.W, C, C, 1, residual=x.t, **po)
+        out, opl = out if pl_out else (out, None)
         if rec is not None:
             rec.update(st=st, hn=hn, h0=h0, l1=l1, a1r=a1r, h1=h1, l2=l2, a2r=a2r, h2=h2, l3=l3, f=f, gg=gg, h3=h3)
             tape.append(("transformer", rec))
-        return Act(out, B, x.H, x.W, C)
+        return Act(out, B, x.H, x.W, C, opl)
 
     def _transformer_backward(self, r, d_out):
         P, G, cfg = self.params, self.grads, self.cfg
@@ -429,15 +444,20 @@ class UNet2DCondition:
                     r = resnet_forward(P, "down_blocks_0.resnets_0", h_half, temb_act[:Bh], G, 1e-5, None)
                     h = Act(twice(r.t), B, r.H, r.W, r.C)
                 else:
-                    h = resnet_forward(P, f"down_blocks_{i}.resnets_{j}", h, temb_act, G, 1e-5, tape)
+                    # the level's last block feeds the down-sampler convolution: its output stage also emits planes (sampling)
+                    emit = tape is None and i < nlev - 1 and j == cfg.layers_per_block - 1
+                    h = resnet_forward(P, f"down_blocks_{i}.resnets_{j}", h, temb_act, G, 1e-5, tape,
+                                       emit_planes=emit and not cfg.cross_attn_down[i])
                 if cfg.cross_attn_down[i]:
-                    h = self._transformer(f"down_blocks_{i}.attentions_{j}", h, ctx, Lc, cfg.num_heads[i], tape)
+                    h = self._transformer(f"down_blocks_{i}.attentions_{j}", h, ctx, Lc, cfg.num_heads[i], tape,
+                                          emit_planes=tape is None and i < nlev - 1 and j == cfg.layers_per_block - 1)
                 skips.append(h)
                 if tape is not None:
                     tape.append(("skip_push", None))
             if i < nlev - 1:
                 name = f"down_blocks_{i}.downsamplers_0.conv"
-                t, OH, OW = L.conv2d(h.t, P[name + ".kernel"], P[name + ".bias"], B, h.H, h.W, h.C, h.C, 3, stride=2, pad=1)
+                src = h.pl if (h.pl is not None and L.planes_ok(P[name + ".kernel"], h.C, h.M)) else h.t
+                t, OH, OW = L.conv2d(src, P[name + ".kernel"], P[name + ".bias"], B, h.H, h.W, h.C, h.C, 3, stride=2, pad=1)
                 if tape is not None:
                     tape.append(("down", dict(name=name, x=h)))
                     tape.append(("skip_push", None))
@@ -455,12 +475,15 @@ class UNet2DCondition:
                 L.copy_cols(s.t, cat, h.C, B * h.HW, s.C)
                 if tape is not None:
                     tape.append(("concat", dict(c0=h.C, c1=s.C)))
-                h = resnet_forward(P, f"up_blocks_{i}.resnets_{j}", Act(cat, B, h.H, h.W, h.C + s.C), temb_act, G, 1e-5, tape)
+                emit = tape is None and i < nlev - 1 and j == cfg.layers_per_block      # feeds the up-sampler convolution
+                h = resnet_forward(P, f"up_blocks_{i}.resnets_{j}", Act(cat, B, h.H, h.W, h.C + s.C), temb_act, G, 1e-5, tape,
+                                   emit_planes=emit and not cfg.cross_attn_down[lvl])
                 if cfg.cross_attn_down[lvl]:
-                    h = self._transformer(f"up_blocks_{i}.attentions_{j}", h, ctx, Lc, cfg.num_heads[lvl], tape)
+                    h = self._transformer(f"up_blocks_{i}.attentions_{j}", h, ctx, Lc, cfg.num_heads[lvl], tape, emit_planes=emit)
             if i < nlev - 1:
                 name = f"up_blocks_{i}.upsamplers_0.conv"
-                t, OH, OW = L.conv2d(h.t, P[name + ".kernel"], P[name + ".bias"], B, h.H, h.W, h.C, h.C, 3, upsample=True)
+                src = h.pl if (h.pl is not None and L.planes_ok(P[name + ".kernel"], h.C, h.M)) else h.t
+                t, OH, OW = L.conv2d(src, P[name + ".kernel"], P[name + ".bias"], B, h.H, h.W, h.C, h.C, 3, upsample=True)
                 if tape is not None:
                     tape.append(("up", dict(name=name, x=h)))
                 h = Act(t, B, OH, OW, h.C)

@@ -155,6 +155,13 @@ typedef struct {
                                         [a_0 | gate_0 | a_1 | gate_1 ...]; out has N/2 columns,
                                         out[:, 32q + c] = (acc_a + bias_a) * gelu_tanh(acc_gate + bias_gate);
                                         needs N % 128 == 0, K % 32 == 0, no rowbias / residual, alpha == 1 */
+  /* plane-emitting output stage (ddpo_gemm_conv_fwd_bf16 / _planes on the buffer-addressed kernels only; NULL elsewhere).
+   * When out_hi != NULL the final value v of every output element is ALSO written as bf16 hi / lo planes
+   * (hi = bf16(v), lo = bf16(v - hi): the operand format of ddpo_gemm_conv_fwd_bf16_planes, bit for bit what the
+   * fp32-fed loader would split v into), rows of ld_planes elements (% 4 == 0, planes 8-byte aligned).  `out` may then be
+   * NULL (planes only).  Needs the vector output stage (N, ld_out, ld_res, ld_rowbias % 4 == 0, 16-byte aligned
+   * pointers); DDPO_EINVAL otherwise.  With epilogue == 1 the planes hold the N/2 GEGLU outputs. */
+  uint16_t* out_hi; uint16_t* out_lo; int ld_planes;
 } ddpo_gemm_desc;
 int ddpo_gemm_conv_fwd(const ddpo_gemm_desc* d, void* stream);
 /* Data gradients reuse ddpo_gemm_conv_fwd: src = dY, w = forward kernel with w_trans=1, w_dgrad=1, and for the
@@ -191,6 +198,12 @@ int ddpo_split_planes_bf16(const float* x, int ldx, uint16_t* hi, uint16_t* lo, 
  * atomics).  Dense, or convolutions with pad = ksize/2, stride 1 or 2, optionally over a nearest-2x upsampled input
  * (returns DDPO_EINVAL otherwise - callers fall back to ddpo_gemm_conv_wgrad). */
 int ddpo_gemm_conv_wgrad_bf16x3(const ddpo_gemm_desc* d, void* stream);
+/* The same weight gradient with one or both operands given as bf16 hi / lo planes (the format of
+ * ddpo_gemm_conv_fwd_bf16_planes): a_hi / a_lo replace d->src (the forward input; rows of d->ld_src ELEMENTS), dy_hi / dy_lo
+ * replace d->w (dY; rows of d->ld_w elements).  A NULL pair means that operand is fp32 in the descriptor.  Same values reach
+ * the MFMAs as in the fp32-fed form (the planes ARE its split), so the result differs only by the atomics' summation order. */
+int ddpo_gemm_conv_wgrad_bf16x3_planes(const ddpo_gemm_desc* d, const uint16_t* a_hi, const uint16_t* a_lo,
+                                       const uint16_t* dy_hi, const uint16_t* dy_lo, void* stream);
 /* fp32 W (K,N) -> bf16 hi/lo planes: fwd_* (N, Kp) k-contiguous (Kp = K rounded up to 8, zero padded) and, if
  * bwd_hi != NULL, bwd_* (K, N).  Call after every optimizer update (weights only change there). */
 int ddpo_pack_weights_bf16(const float* w, int K, int N, int Kp, uint16_t* fwd_hi, uint16_t* fwd_lo,

@@ -110,6 +110,99 @@ def test_linear_geglu_planes_bit_identical():
     assert y is not None and torch.equal(y, z)
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,ks,stride,ups,fed", [
+    (16, 64, 64, 320, 320, 1, 1, False, "planes"),   # 256x320 tall tiles (plane-fed only)
+    (4, 32, 32, 320, 320, 3, 1, False, "fp32"),      # 128x320 tiles, fp32-fed
+    (4, 32, 32, 320, 640, 3, 1, False, "planes"),    # 128x320 tiles, plane-fed
+    (2, 16, 16, 128, 128, 3, 1, False, "fp32"),      # 128x128 / 128x64
+    (1, 8, 8, 1280, 1280, 3, 1, False, "planes"),    # split-K: the reduce kernel writes the planes
+    (2, 16, 16, 64, 64, 3, 2, False, "fp32"), (2, 8, 8, 64, 64, 3, 1, True, "planes")])
+def test_gemm_output_stage_emits_the_loader_split_of_its_result(B, H, W, Cin, Cout, ks, stride, ups, fed):
+    """ddpo_gemm_desc.out_hi / out_lo: the planes a GEMM's output stage writes are, bit for bit, split_planes() of the fp32 result
+    it writes next to them (so a plane-fed consumer sees what an fp32-fed consumer would split on the fly) — and "only" mode
+    (no fp32 tensor) writes the same planes."""
+    _bf16x3()
+    g = torch.Generator(device=DEV).manual_seed(13)
+    x = torch.randn(B * H * W, Cin, device=DEV, generator=g)
+    w = torch.randn(ks, ks, Cin, Cout, device=DEV, generator=g) / (ks * ks * Cin) ** 0.5
+    b = torch.randn(Cout, device=DEV, generator=g)
+    L.pack_weights(w, bwd=False)
+    assert L.planes_out_ok(w, Cin, B * H * W, Cout)
+    src = L.split_planes(x) if fed == "planes" else x
+    y0, OH, OW = L.conv2d(src, w, b, B, H, W, Cin, Cout, ks, stride=stride, upsample=ups)
+    res = torch.randn_like(y0)
+    rb = torch.randn(B, Cout, device=DEV, generator=g)
+    kw = dict(stride=stride, upsample=ups, residual=res, rowbias=rb, rows_per_batch=OH * OW)
+    y1, _, _ = L.conv2d(src, w, b, B, H, W, Cin, Cout, ks, **kw)
+    (z1, pl), _, _ = L.conv2d(src, w, b, B, H, W, Cin, Cout, ks, planes_out="both", **kw)
+    only, _, _ = L.conv2d(src, w, b, B, H, W, Cin, Cout, ks, planes_out="only", **kw)
+    ref = L.split_planes(y1)
+    assert torch.equal(z1, y1)
+    assert torch.equal(pl.hi, ref.hi) and torch.equal(pl.lo, ref.lo)
+    assert torch.equal(only.hi, ref.hi) and torch.equal(only.lo, ref.lo)
+
+
+def test_linear_geglu_emits_planes_for_ff2():
+    _bf16x3()
+    g = torch.Generator(device=DEV).manual_seed(14)
+    M, K, F = 1000, 320, 1280
+    x = torch.randn(M, K, device=DEV, generator=g)
+    w = torch.randn(K, 2 * F, device=DEV, generator=g) / K ** 0.5
+    b = torch.randn(2 * F, device=DEV, generator=g)
+    w2 = torch.randn(F, K, device=DEV, generator=g) / F ** 0.5
+    L.pack_weights(w, bwd=False)
+    L.pack_weights(w2, bwd=False)
+    assert L.pack_weights_geglu(w, b)
+    y = L.linear_geglu(L.split_planes(x), w)
+    pl = L.linear_geglu(L.split_planes(x), w, planes_out=True)
+    ref = L.split_planes(y)
+    assert isinstance(pl, L.Planes) and torch.equal(pl.hi, ref.hi) and torch.equal(pl.lo, ref.lo)
+    assert torch.equal(L.linear(pl, w2), L.linear(y, w2))                 # FF2 plane-fed == fp32-fed
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,ks,stride,ups", [
+    (4, 32, 32, 320, 320, 3, 1, False), (2, 16, 16, 128, 96, 3, 1, False), (2, 16, 16, 64, 64, 3, 2, False),
+    (2, 8, 8, 64, 64, 3, 1, True), (3, 12, 20, 96, 160, 1, 1, False), (0, 777, 1, 320, 1280, 0, 1, False)])     # last: dense (M = 777)
+@pytest.mark.parametrize("which", ["a", "dy", "both"])
+def test_wgrad_from_planes_equals_wgrad_from_fp32(B, H, W, Cin, Cout, ks, stride, ups, which):
+    """ddpo_gemm_conv_wgrad_bf16x3_planes: the weight gradient read from pre-split planes (forward input and / or dY) is the one
+    the fp32-fed kernel computes — the planes ARE its on-the-fly split, only the fp32 atomics' order differs between launches."""
+    _bf16x3()
+    g = torch.Generator(device=DEV).manual_seed(21)
+    if ks == 0:
+        M, K, N = H, Cin, Cout
+        x = torch.randn(M, K, device=DEV, generator=g)
+        dy = torch.randn(M, N, device=DEV, generator=g)
+        run = lambda a, b: L.linear_wgrad(a, b, torch.zeros(K, N, device=DEV))
+    else:
+        x = torch.randn(B * H * W, Cin, device=DEV, generator=g)
+        pad = ks // 2
+        VH, VW = (2 * H, 2 * W) if ups else (H, W)
+        OH, OW = (VH + 2 * pad - ks) // stride + 1, (VW + 2 * pad - ks) // stride + 1
+        dy = torch.randn(B * OH * OW, Cout, device=DEV, generator=g)
+        run = lambda a, b: L.conv2d_wgrad(a, b, torch.zeros(ks, ks, Cin, Cout, device=DEV), B, H, W, Cin, Cout, ks, stride=stride, upsample=ups)
+    ref = run(x, dy)
+    a = L.split_planes(x) if which in ("a", "both") else x
+    b = L.split_planes(dy) if which in ("dy", "both") else dy
+    got = run(a, b)
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) <= 2e-6 * scale + 1e-7
+
+
+def test_plane_emitting_stage_rejected_off_the_buffer_addressed_kernels():
+    _bf16x3()
+    x = torch.randn(64, 40, device=DEV)                 # K % 32 != 0 -> generic loader: no plane-emitting output stage
+    w = torch.randn(40, 64, device=DEV)
+    L.pack_weights(w, bwd=False)
+    assert not L.planes_out_ok(w, 40, 64, 64)
+    with pytest.raises(L.DdpoHipError):
+        L.linear(x, w, planes_out="both")
+    L.DATAPATH = "fp32"
+    w3 = torch.randn(64, 64, device=DEV)
+    with pytest.raises(L.DdpoHipError):
+        L.linear(torch.randn(64, 64, device=DEV), w3, planes_out="both")
+
+
 def test_planes_rejected_where_the_fp32_entry_must_be_used():
     _bf16x3()
     x = torch.randn(64, 40, device=DEV)                 # K % 32 != 0
@@ -153,8 +246,13 @@ def test_unet_and_vae_forward_unchanged_by_planes(model, monkeypatch):
     assert counter["n"] > 20                                  # the plane-fed path really ran
     tape = []
     counter["n"] = 0
+    monkeypatch.setattr(L, "TRAIN_PLANES", False)
     y_train = unet.forward(x, t, ctx, tape=tape)
-    assert counter["n"] == 0
+    assert counter["n"] == 0                                  # DDPO_TRAIN_PLANES=0: the training forward keeps fp32 activations
+    monkeypatch.setattr(L, "TRAIN_PLANES", True)
+    y_train_pl = unet.forward(x, t, ctx, tape=[])
+    assert counter["n"] > 10 and torch.equal(y_train_pl, y_train)      # default: norm outputs as planes, same bits
+    counter["n"] = 0
     monkeypatch.setattr(L, "PLANES", False)
     y_fp = unet(x, t, ctx)
     assert counter["n"] == 0

@@ -287,7 +287,8 @@ static int probe_gemm2(int B, int iters) {
     ++ci;
   }
   const int dense[][3] = {{4096, 320, 320}, {4096, 320, 2560}, {4096, 1280, 320}, {1024, 640, 5120}, {1024, 2560, 640},
-                          {256, 1280, 10240}, {256, 5120, 1280}, {64, 1280, 1280}, {77, 768, 320}, {1, 1280, 1280}, {37, 96, 72}};
+                          {256, 1280, 10240}, {256, 5120, 1280}, {64, 1280, 1280}, {77, 768, 320}, {1, 1280, 1280}, {37, 96, 72},
+                          {1024, 640, 640}, {256, 1280, 1280}, {4096, 320, 960}};
   int di = 0;
   for (auto& g : dense) {
     if (!only || (only[0] == 'd' && di == only_i)) run_gemm2(B, g[0], g[1], g[2], 0, 1, 0, iters, ws, ws_bytes);

@@ -27,16 +27,17 @@ def rec(src, w, *, M, N, K, conv=None, **kw):
     return orig(src, w, M=M, N=N, K=K, conv=conv, **kw)
 L.gemm_conv = rec
 orig_geglu = L.linear_geglu
-def rec_geglu(x, w, out=None):
-    r = orig_geglu(x, w, out=out)
+def rec_geglu(x, w, out=None, **kw):
+    r = orig_geglu(x, w, out=out, **kw)
     if r is not None:
         shapes.append((x.shape[0], w.shape[1], x.shape[1], -1, 1, 0, isinstance(x, L.Planes)))      # ks = -1 marks the fused FF1 + GEGLU launch
     return r
 L.linear_geglu = rec_geglu
 
 
-def measure(planes, reps=3):
+def measure(planes, reps=3, planes_out=True):
     L.PLANES = planes
+    L.PLANES_OUT = planes_out
     agg = collections.defaultdict(lambda: [0, 0.0, 0.0, False])
     unet(x, t, c); torch.cuda.synchronize()
     for _ in range(reps):
@@ -58,6 +59,9 @@ if not AB:
     for sh, a in sorted(base.items(), key=lambda kv: -kv[1][1])[:28]:
         print(f"M={sh[0]:6d} N={sh[1]:5d} K={sh[2]:6d} ks={sh[3]} s={sh[4]} up={sh[5]} x{a[0]:3d}: {a[1]:7.2f} ms ({100*a[1]/tot:4.1f}%) {a[2]/a[1]/1e9:6.1f} TF")
 else:
+    pl0 = measure(True, planes_out=False)
+    t0 = sum(a[1] for a in pl0.values())
+    print(f"planes, no plane-emitting output stages: total gemm/conv ms {t0:.2f}; {sum(a[0] for a in pl0.values() if a[3])} launches plane-fed")
     pl = measure(True)
     tot2 = sum(a[1] for a in pl.values())
     print(f"planes  : total gemm/conv ms {tot2:.2f}; {sum(a[2] for a in pl.values())/tot2/1e9:.1f} TF avg; "
