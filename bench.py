@@ -464,11 +464,13 @@ def main(argv=None):
         traffic, traffic_note = None, None
         tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
         if os.path.exists(tpath):
-            tj = json.load(open(tpath)).get(dom)
+            tall = json.load(open(tpath))
+            tj = tall.get(dom + "_r02_unet") or tall.get(dom)        # r02: counters over exactly the launches of this event-timed pass
             if tj:
                 traffic = tj["traffic_bytes_per_launch"]
-                traffic_note = tj.get("note", "PMC (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes) per launch of this kernel family, from "
-                                              "profiles/roofline_traffic.json; not collectable inside this process")
+                traffic_note = tj.get("note", f"PMC (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes) per launch over {tj.get('launches')} "
+                                              "launches of this kernel family = the same eager U-Net forwards this pass event-times (tools/pmc_unet_traffic.sh), "
+                                              "from profiles/roofline_traffic.json; not collectable inside this process")
         roofline = {"bound": "mfma", "kernel": kname, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                     "frac": achieved / peak, "traffic": traffic, "traffic_note": traffic_note,
                     "algorithmic_bytes_per_launch": sum(r[4] for r in recs) / max(len(recs), 1),

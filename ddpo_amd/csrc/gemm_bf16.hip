@@ -1258,7 +1258,12 @@ static int dispatch_bf16(const ddpo_gemm_desc& d, const uint16_t* w_hi, const ui
   }
   const long t128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128);
   static const long big_min = [] { const char* e = getenv("DDPO_GEMM_BIG_MIN"); return e ? atol(e) : 256L; }();   // tuning knob (tools/)
-  const bool big = (d.N % 128 == 0) && t128 >= big_min;
+  // 128x128 tiles need >= 512 of them to fill both workgroup slots of every CU; a short reduction on 256..511 of them (the 16x16
+  // level's q / k / v / out projections: M = 4096, N = K = 1280 -> 320 tiles) runs ~15 % faster on 640 tiles of 128x64, three per CU
+  // (probe, cold weights: 0.084 -> 0.070 ms fp32-fed; profiles/r02_probe_tiles_small.log).  DDPO_GEMM_MID64=0 restores 128x128.
+  static const int mid64 = [] { const char* e = getenv("DDPO_GEMM_MID64"); return e ? atoi(e) : 1; }();
+  const bool mid_short = mid64 && t128 < 512 && d.K / BF_BK <= 64;
+  const bool big = (d.N % 128 == 0) && t128 >= big_min && !mid_short;
   if (npass == 3)
     return big ? launch_bf16<128, 128, 3, 2, 2, APL>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st) : launch_bf16<128, 64, 3, 2, 2, APL>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st);
   return big ? launch_bf16<128, 128, 1>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st) : launch_bf16<128, 64, 1>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st);
@@ -1417,8 +1422,8 @@ __device__ __forceinline__ bf16x8 lds_frag(const uint32_t* base, int row, int dw
 // loader then only has to pair pixels m / m+1 of a channel into a dword (one v_perm_b32 per plane dword) instead of running the
 // fp32 -> bf16 split (2 v_cvt_pk + 2 v_sub + 2 mask / shift per pair): the split was ~2/3 of this kernel's VALU work, which
 // bounds it (profiles/r01_train_fuse10_kernel_stats.md).  Same values reach the MFMAs: results are identical to the fp32-fed form.
-template <bool APLN, bool BPLN>
-__global__ void __launch_bounds__(BF_THREADS) gemm_wgrad_bf16_kernel(const ddpo_gemm_desc d, int tiles_n, int m_per_split,
+template <bool APLN, bool BPLN, bool DEEPW>
+__global__ void __launch_bounds__(BF_THREADS, 2) gemm_wgrad_bf16_kernel(const ddpo_gemm_desc d, int tiles_n, int m_per_split,
                                                                    const uint16_t* __restrict__ a_hi, const uint16_t* __restrict__ a_lo,
                                                                    const uint16_t* __restrict__ b_hi, const uint16_t* __restrict__ b_lo) {
   constexpr int BM = 128, BN = 128, BK = 32;
@@ -1465,54 +1470,58 @@ __global__ void __launch_bounds__(BF_THREADS) gemm_wgrad_bf16_kernel(const ddpo_
     }
   const int64_t tap_off = conv ? ((int64_t)dky * d.W + dkx) * d.ld_src + ci : kg;
 
-  float4 ra[2][2], rb[2][2];          // fp32 operands; a plane operand keeps (hi.x, hi.y, lo.x, lo.y) raw bits in the same registers
+  // Two register stages: the loads of k-tile kt + 2 are issued before the MFMAs of tile kt, the split / transpose / LDS store of
+  // tile kt + 1 runs after them (one stage covered only ~770 MFMA cycles of the ~2-3 k cycles an HBM / L2 round trip takes).
+  // Loads are UNCONDITIONAL (a masked element reads a clamped in-range address and is zeroed when it is staged): no branch stands
+  // between a load and its use, so the compiler keeps the full prefetch distance.
+  struct WStage { float4 a[2][2], b[2][2]; uint32_t mask; };     // plane operands keep (hi.x, hi.y, lo.x, lo.y) raw bits in the float4
   auto as_f4 = [](const uint2 h, const uint2 l) {
     return make_float4(__uint_as_float(h.x), __uint_as_float(h.y), __uint_as_float(l.x), __uint_as_float(l.y));
   };
-  auto load_tile = [&](int kt) {
+  auto load_tile = [&](int kt, WStage& sg) {
+    uint32_t mask = 0;
 #pragma unroll
     for (int p = 0; p < 2; ++p)
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         const int m = m_begin + kt * BK + 16 * p + 2 * pp + e;
-        float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
-        if (m < m_end) {
-          bool ok = kvalid;
-          int64_t aoff = (int64_t)m * d.ld_src + tap_off;
-          if (conv) {
-            const int iy = poy[p][e] * d.stride + dky, ix = pox[p][e] * d.stride + dkx;       // virtual (upsampled) coordinates
-            ok = ok && iy >= 0 && iy < VH && ix >= 0 && ix < VW;
-            if (!simple) {
-              const int sy = d.upsample ? (iy >> 1) : iy, sx = d.upsample ? (ix >> 1) : ix;
-              aoff = ((int64_t)(pb[p][e] * d.H + sy) * d.W + sx) * d.ld_src + ci;
-            }
-          }
-          if (ok) {
-            if (APLN) va = as_f4(*reinterpret_cast<const uint2*>(a_hi + aoff), *reinterpret_cast<const uint2*>(a_lo + aoff));
-            else va = *reinterpret_cast<const float4*>(d.src + aoff);
-          }
-          if (nvalid) {
-            const int64_t boff = (int64_t)m * d.ld_w + ng;
-            if (BPLN) vb = as_f4(*reinterpret_cast<const uint2*>(b_hi + boff), *reinterpret_cast<const uint2*>(b_lo + boff));
-            else vb = *reinterpret_cast<const float4*>(d.w + boff);
+        const bool inb = m < m_end;
+        bool ok = kvalid && inb;
+        int64_t aoff = (int64_t)m * d.ld_src + tap_off;
+        if (conv) {
+          const int iy = poy[p][e] * d.stride + dky, ix = pox[p][e] * d.stride + dkx;       // virtual (upsampled) coordinates
+          ok = ok && iy >= 0 && iy < VH && ix >= 0 && ix < VW;
+          if (!simple) {
+            const int sy = d.upsample ? (iy >> 1) : iy, sx = d.upsample ? (ix >> 1) : ix;
+            aoff = ((int64_t)(pb[p][e] * d.H + sy) * d.W + sx) * d.ld_src + ci;
           }
         }
-        ra[p][e] = va;
-        rb[p][e] = vb;
+        aoff = ok ? aoff : 0;
+        const bool bok = nvalid && inb;
+        const int64_t boff = bok ? (int64_t)m * d.ld_w + ng : 0;
+        if (APLN) sg.a[p][e] = as_f4(*reinterpret_cast<const uint2*>(a_hi + aoff), *reinterpret_cast<const uint2*>(a_lo + aoff));
+        else sg.a[p][e] = *reinterpret_cast<const float4*>(d.src + aoff);
+        if (BPLN) sg.b[p][e] = as_f4(*reinterpret_cast<const uint2*>(b_hi + boff), *reinterpret_cast<const uint2*>(b_lo + boff));
+        else sg.b[p][e] = *reinterpret_cast<const float4*>(d.w + boff);
+        mask |= (ok ? 1u : 0u) << (2 * p + e) | (bok ? 16u : 0u) << (2 * p + e);
         if (conv) {          // advance this pixel by BK
           pox[p][e] += BK;
           while (pox[p][e] >= d.OW) { pox[p][e] -= d.OW; ++poy[p][e]; }
           while (poy[p][e] >= d.OH) { poy[p][e] -= d.OH; ++pb[p][e]; }
         }
       }
+    sg.mask = mask;
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](int buf, const WStage& sg) {
     uint32_t* st = smem[buf];
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       const int dw = pp + 8 * p;                        // dword (= pixel pair) index within the row
-      const float* a0 = &ra[p][0].x; const float* a1 = &ra[p][1].x;
-      const float* b0 = &rb[p][0].x; const float* b1 = &rb[p][1].x;
+      const float4 va0 = (sg.mask >> (2 * p)) & 1u ? sg.a[p][0] : zero, va1 = (sg.mask >> (2 * p + 1)) & 1u ? sg.a[p][1] : zero;
+      const float4 vb0 = (sg.mask >> (4 + 2 * p)) & 1u ? sg.b[p][0] : zero, vb1 = (sg.mask >> (5 + 2 * p)) & 1u ? sg.b[p][1] : zero;
+      const float* a0 = &va0.x; const float* a1 = &va1.x;
+      const float* b0 = &vb0.x; const float* b1 = &vb1.x;
       // plane operand: registers hold [ch0|ch1, ch2|ch3] (hi) and the same for lo, per pixel; pair channel j of pixels m, m+1
       auto pair = [](const float* p0, const float* p1, int j, int plane) {
         const uint32_t w0 = __float_as_uint(p0[2 * plane + (j >> 1)]), w1 = __float_as_uint(p1[2 * plane + (j >> 1)]);
@@ -1543,12 +1552,7 @@ __global__ void __launch_bounds__(BF_THREADS) gemm_wgrad_bf16_kernel(const ddpo_
 
   const int nk = (m_end - m_begin + BK - 1) / BK;
   const int li = lane & 31, h = lane >> 5;
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) load_tile(kt + 1);
+  auto compute = [&](int cur) {
     const uint32_t* st = smem[cur];
 #pragma unroll
     for (int ms = 0; ms < 2; ++ms) {
@@ -1570,8 +1574,36 @@ __global__ void __launch_bounds__(BF_THREADS) gemm_wgrad_bf16_kernel(const ddpo_
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
     }
-    if (kt + 1 < nk) store_tile(cur ^ 1);
+  };
+  WStage s0;
+  load_tile(0, s0);
+  store_tile(0, s0);
+  if constexpr (!DEEPW) {           // one register stage (round 1's loop): tile kt + 1 loads behind the MFMAs of tile kt
     __syncthreads();
+#pragma unroll 1
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      if (kt + 1 < nk) load_tile(kt + 1, s0);
+      compute(cur);
+      if (kt + 1 < nk) store_tile(cur ^ 1, s0);
+      __syncthreads();
+    }
+  } else {
+  WStage s1;
+  if (nk > 1) load_tile(1, s0);
+  __syncthreads();
+#pragma unroll 1
+  for (int kt = 0; kt < nk; kt += 2) {
+    if (kt + 2 < nk) load_tile(kt + 2, s1);          // even step: MFMAs on LDS[0]; s0 holds tile kt + 1
+    compute(0);
+    if (kt + 1 < nk) store_tile(1, s0);
+    __syncthreads();
+    if (kt + 1 >= nk) break;
+    if (kt + 3 < nk) load_tile(kt + 3, s0);          // odd step: MFMAs on LDS[1]; s1 holds tile kt + 2
+    compute(1);
+    if (kt + 2 < nk) store_tile(0, s1);
+    __syncthreads();
+  }
   }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -1629,10 +1661,17 @@ static int wgrad_bf16x3(const ddpo_gemm_desc* dp, const uint16_t* a_hi, const ui
   splits = (d.M + mps - 1) / mps;
   hipStream_t st = as_stream(stream);
   const dim3 grid(tiles, splits), blk(BF_THREADS);
-  if (a_hi && b_hi) hipLaunchKernelGGL((gemm_wgrad_bf16_kernel<true, true>), grid, blk, 0, st, d, tiles_n, mps, a_hi, a_lo, b_hi, b_lo);
-  else if (a_hi) hipLaunchKernelGGL((gemm_wgrad_bf16_kernel<true, false>), grid, blk, 0, st, d, tiles_n, mps, a_hi, a_lo, b_hi, b_lo);
-  else if (b_hi) hipLaunchKernelGGL((gemm_wgrad_bf16_kernel<false, true>), grid, blk, 0, st, d, tiles_n, mps, a_hi, a_lo, b_hi, b_lo);
-  else hipLaunchKernelGGL((gemm_wgrad_bf16_kernel<false, false>), grid, blk, 0, st, d, tiles_n, mps, a_hi, a_lo, b_hi, b_lo);
+  static const int deep = [] { const char* e = getenv("DDPO_WGRAD_DEEP"); return e ? atoi(e) : 1; }();     // tuning knob: register stages
+#define WG_LAUNCH(A, B)                                                                                                               \
+  do {                                                                                                                                \
+    if (deep) hipLaunchKernelGGL((gemm_wgrad_bf16_kernel<A, B, true>), grid, blk, 0, st, d, tiles_n, mps, a_hi, a_lo, b_hi, b_lo);    \
+    else hipLaunchKernelGGL((gemm_wgrad_bf16_kernel<A, B, false>), grid, blk, 0, st, d, tiles_n, mps, a_hi, a_lo, b_hi, b_lo);        \
+  } while (0)
+  if (a_hi && b_hi) WG_LAUNCH(true, true);
+  else if (a_hi) WG_LAUNCH(true, false);
+  else if (b_hi) WG_LAUNCH(false, true);
+  else WG_LAUNCH(false, false);
+#undef WG_LAUNCH
   DDPO_LAUNCH_CHECK();
   return DDPO_OK;
 }

@@ -84,11 +84,17 @@ class StableDiffusionPipeline:
         cache_ctx = hasattr(self.unet, "precompute_context")
         # both CFG halves see the same latents and timestep: the layers in front of the first cross-attention run once
         dedupe = cache_ctx and os.environ.get("DDPO_CFG_DUP", "1") != "0"
+        # so is the time path per step (every sample is at the same timestep): embedding MLP + ResBlock projections once for all T
+        cache_t = hasattr(self.unet, "precompute_timesteps") and os.environ.get("DDPO_TEMB_CACHE", "1") != "0"
         if cache_ctx:
             self.unet.precompute_context(context)
+        if cache_t:
+            self.unet.precompute_timesteps(timesteps)
         try:
             for s in range(T):
                 x = traj[s]
+                if cache_t:
+                    self.unet.select_timestep(s)
                 lat2[:B].copy_(x)                                   # jnp.concatenate([old_latents] * 2)
                 lat2[B:].copy_(x)
                 noise_pred = unet_fwd(lat2, ts_dev[s], context, cfg_dup=True) if dedupe else unet_fwd(lat2, ts_dev[s], context)
@@ -98,6 +104,8 @@ class StableDiffusionPipeline:
         finally:
             if cache_ctx:
                 self.unet.release_context()
+            if cache_t:
+                self.unet.release_timesteps()
         final_latents = traj[T]
         ts = ts_dev[:, :B].transpose(0, 1)                          # (B, T)
         return (final_latents, traj[:T].transpose(0, 1), traj[1:].transpose(0, 1), log_probs.transpose(0, 1), ts)

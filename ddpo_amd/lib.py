@@ -126,6 +126,7 @@ PLANES = os.environ.get("DDPO_PLANES", "1") == "1"
 TRAIN_PLANES = os.environ.get("DDPO_TRAIN_PLANES", "1") == "1"
 # GEMM output stages that emit planes for a following GEMM (GEGLU -> FF2, block output -> down / up-sampler convolution)
 PLANES_OUT = os.environ.get("DDPO_PLANES_OUT", "1") == "1"
+PLANES_ALL = os.environ.get("DDPO_PLANES_ALL", "0") == "1"      # plane-feed every eligible layer, also where it is measured slower
 
 
 class Planes:
@@ -165,6 +166,18 @@ def planes_ok(w, cin, rows):
         return False
     lim = 0x7FFFFFFF
     return rows * cin * 4 < lim and ent["N"] * ent["fwd"][2] * 2 < lim
+
+
+def planes_pay(w, cin, rows):
+    """planes_ok() AND the plane-fed kernel is the faster one for this layer in the model (tools/unet_gemm_breakdown.py --ab,
+    profiles/r02_gemm_breakdown_ab.md): long reductions (every 3x3 convolution, FF2) gain 5-24 %, the 64x64-level linears 0-8 %;
+    the short reductions of the 32x32 / 16x16 levels (K <= 1280 with < 32768 rows: q / k / v / proj_in, FF1) lose 2-8 % to the
+    LDS-DMA loop's fill latency, so their norms keep writing fp32.  DDPO_PLANES_ALL=1 ignores the rule (tests of the kernels)."""
+    if not planes_ok(w, cin, rows):
+        return False
+    if PLANES_ALL:
+        return True
+    return PACKED[w.data_ptr()]["K"] >= 2560 or rows >= 32768
 
 
 def planes_out_ok(w, cin, rows, N):

@@ -203,15 +203,17 @@ def resnet_forward(P, name, x: Act, temb_act, groups, eps, tape=None, emit_plane
     # inference / sampling (no tape): the two GroupNorm+SiLU results feed only their convolution, so they are written as bf16
     # hi / lo planes and the convolutions run plane-fed (LDS-DMA operands; bit-identical to the fp32-fed kernels)
     # training (tape): the same, the planes are what the weight gradients of conv1 / conv2 read (lib.TRAIN_PLANES)
-    pl1 = (tape is None or L.TRAIN_PLANES) and L.planes_ok(P[name + ".conv1.kernel"], x.C, x.M)
-    pl2 = (tape is None or L.TRAIN_PLANES) and L.planes_ok(P[name + ".conv2.kernel"], cout, x.M)
+    pl1 = (tape is None or L.TRAIN_PLANES) and L.planes_pay(P[name + ".conv1.kernel"], x.C, x.M)
+    pl2 = (tape is None or L.TRAIN_PLANES) and L.planes_pay(P[name + ".conv2.kernel"], cout, x.M)
     h1, st1 = L.groupnorm(x.t, x.B, x.HW, P[name + ".norm1.scale"], P[name + ".norm1.bias"], groups, eps, True, return_stats=True,
                           planes=pl1)
-    rowbias = None
-    if temb_act is not None:
+    rowbias, rpb = None, x.HW
+    if isinstance(temb_act, dict):                 # sampling: this step's time projections were computed once for the whole call
+        rowbias, rpb = temb_act[name], x.M         # (1, cout): ONE row shared by every sample of the batch (same timestep)
+    elif temb_act is not None:
         rowbias = L.linear(temb_act, P[name + ".time_emb_proj.kernel"], P[name + ".time_emb_proj.bias"])
     c1, _, _ = L.conv2d(h1, P[name + ".conv1.kernel"], P[name + ".conv1.bias"], x.B, x.H, x.W, x.C, cout, 3,
-                        rowbias=rowbias, rows_per_batch=x.HW)
+                        rowbias=rowbias, rows_per_batch=rpb)
     h2, st2 = L.groupnorm(c1, x.B, x.HW, P[name + ".norm2.scale"], P[name + ".norm2.bias"], groups, eps, True, return_stats=True,
                           planes=pl2)
     res = x.t
@@ -269,6 +271,8 @@ class UNet2DCondition:
         self.grads = None
         self._ctx_kv = {}                 # (cross-attention name, context rows) -> (K, V) of the text context (precompute_context)
         self._ctx_kv_active = False
+        self._temb = None                 # time-projection table of a sampling call (precompute_timesteps)
+        self._temb_active = False
 
     def ensure_grads(self):
         """Flat fp32 gradient-accumulation buffer with the parameter layout (AccumulatingTrainState.grad_acc)."""
@@ -314,12 +318,12 @@ class UNet2DCondition:
         tb = name + ".transformer_blocks_0"
         inf = tape is None                         # plane-fed GEMMs behind the norms (see resnet_forward)
         npl = inf or L.TRAIN_PLANES                # norm outputs as planes: sampling, and training when the wgrads read planes
-        pl_in = npl and L.planes_ok(P[name + ".proj_in.kernel"], C, B * N)
-        pl_1 = npl and all(L.planes_ok(P[f"{tb}.attn1.{n}.kernel"], C, B * N) for n in ("to_q", "to_k", "to_v"))
-        pl_2 = npl and L.planes_ok(P[tb + ".attn2.to_q.kernel"], C, B * N)
-        pl_3 = npl and L.planes_ok(P[tb + ".ff.net_0.proj.kernel"], C, B * N)
+        pl_in = npl and L.planes_pay(P[name + ".proj_in.kernel"], C, B * N)
+        pl_1 = npl and all(L.planes_pay(P[f"{tb}.attn1.{n}.kernel"], C, B * N) for n in ("to_q", "to_k", "to_v"))
+        pl_2 = npl and L.planes_pay(P[tb + ".attn2.to_q.kernel"], C, B * N)
+        pl_3 = npl and L.planes_pay(P[tb + ".ff.net_0.proj.kernel"], C, B * N)
         F = P[tb + ".ff.net_2.kernel"].shape[0]
-        pl_ff2 = inf and L.PLANES_OUT and L.planes_ok(P[tb + ".ff.net_2.kernel"], F, B * N)       # GEGLU output stage -> planes -> plane-fed FF2
+        pl_ff2 = inf and L.PLANES_OUT and L.planes_pay(P[tb + ".ff.net_2.kernel"], F, B * N)       # GEGLU output stage -> planes -> plane-fed FF2
         pl_out = inf and emit_planes and L.planes_out_ok(P[name + ".proj_out.kernel"], C, B * N, C)
         hn, st = L.groupnorm(x.t, B, N, P[name + ".norm.scale"], P[name + ".norm.bias"], cfg.norm_groups, 1e-5, False, return_stats=True,
                              planes=pl_in)
@@ -422,11 +426,18 @@ class UNet2DCondition:
         ctx = context.reshape(B * Lc, context.shape[2]).contiguous()
         timesteps = timesteps.to(torch.int32)
 
-        emb = L.timestep_embedding(timesteps, boc[0])
-        t1 = L.linear(emb, P["time_embedding.linear_1.kernel"], P["time_embedding.linear_1.bias"])
-        s1 = L.silu(t1)
-        temb = L.linear(s1, P["time_embedding.linear_2.kernel"], P["time_embedding.linear_2.bias"])
-        temb_act = L.silu(temb)          # every ResBlock applies SiLU before its time_emb_proj
+        shared_t = self._temb_active and tape is None
+        if shared_t:
+            # sampling: every sample of the batch is at the same timestep and the time path depends on nothing else — its 27
+            # launches per step (embedding MLP + one projection per ResBlock) were run once for all steps by precompute_timesteps;
+            # select_timestep() put this step's row into the static buffer the views below point at
+            temb_act = self._temb["views"]
+        else:
+            emb = L.timestep_embedding(timesteps, boc[0])
+            t1 = L.linear(emb, P["time_embedding.linear_1.kernel"], P["time_embedding.linear_1.bias"])
+            s1 = L.silu(t1)
+            temb = L.linear(s1, P["time_embedding.linear_2.kernel"], P["time_embedding.linear_2.bias"])
+            temb_act = L.silu(temb)          # every ResBlock applies SiLU before its time_emb_proj
 
         dup = bool(cfg_dup) and tape is None and B % 2 == 0 and cfg.cross_attn_down[0]
         Bh = B // 2 if dup else B
@@ -441,7 +452,7 @@ class UNet2DCondition:
         for i in range(nlev):
             for j in range(cfg.layers_per_block):
                 if dup and i == 0 and j == 0:      # still in front of the first cross-attention: half the batch, then duplicate
-                    r = resnet_forward(P, "down_blocks_0.resnets_0", h_half, temb_act[:Bh], G, 1e-5, None)
+                    r = resnet_forward(P, "down_blocks_0.resnets_0", h_half, temb_act if shared_t else temb_act[:Bh], G, 1e-5, None)
                     h = Act(twice(r.t), B, r.H, r.W, r.C)
                 else:
                     # the level's last block feeds the down-sampler convolution: its output stage also emits planes (sampling)
@@ -456,7 +467,7 @@ class UNet2DCondition:
                     tape.append(("skip_push", None))
             if i < nlev - 1:
                 name = f"down_blocks_{i}.downsamplers_0.conv"
-                src = h.pl if (h.pl is not None and L.planes_ok(P[name + ".kernel"], h.C, h.M)) else h.t
+                src = h.pl if (h.pl is not None and L.planes_pay(P[name + ".kernel"], h.C, h.M)) else h.t
                 t, OH, OW = L.conv2d(src, P[name + ".kernel"], P[name + ".bias"], B, h.H, h.W, h.C, h.C, 3, stride=2, pad=1)
                 if tape is not None:
                     tape.append(("down", dict(name=name, x=h)))
@@ -482,13 +493,13 @@ class UNet2DCondition:
                     h = self._transformer(f"up_blocks_{i}.attentions_{j}", h, ctx, Lc, cfg.num_heads[lvl], tape, emit_planes=emit)
             if i < nlev - 1:
                 name = f"up_blocks_{i}.upsamplers_0.conv"
-                src = h.pl if (h.pl is not None and L.planes_ok(P[name + ".kernel"], h.C, h.M)) else h.t
+                src = h.pl if (h.pl is not None and L.planes_pay(P[name + ".kernel"], h.C, h.M)) else h.t
                 t, OH, OW = L.conv2d(src, P[name + ".kernel"], P[name + ".bias"], B, h.H, h.W, h.C, h.C, 3, upsample=True)
                 if tape is not None:
                     tape.append(("up", dict(name=name, x=h)))
                 h = Act(t, B, OH, OW, h.C)
         hn, st = L.groupnorm(h.t, B, h.HW, P["conv_norm_out.scale"], P["conv_norm_out.bias"], G, 1e-5, True, return_stats=True,
-                             planes=tape is None and L.planes_ok(P["conv_out.kernel"], h.C, h.M))
+                             planes=tape is None and L.planes_pay(P["conv_out.kernel"], h.C, h.M))
         t, _, _ = L.conv2d(hn, P["conv_out.kernel"], P["conv_out.bias"], B, h.H, h.W, h.C, cfg.out_channels, 3)
         if tape is not None:
             tape.append(("tail", dict(x=h, hn=hn, st=st)))
@@ -524,12 +535,58 @@ class UNet2DCondition:
     def release_context(self):
         self._ctx_kv_active = False
 
+    # -------------------------------------------------------------------------------- time-projection table (sampling)
+    def time_proj_names(self):
+        return [n[:-len(".time_emb_proj.kernel")] for n in self.params.views if n.endswith(".time_emb_proj.kernel")]
+
+    def precompute_timesteps(self, timesteps):
+        """Run the time path — sinusoidal embedding, the 2-layer MLP, SiLU and every ResBlock's time_emb_proj — ONCE for all T
+        timesteps of a sampling call (rows = steps) instead of once per step on B identical rows: 27 launch-bound GEMM /
+        elementwise launches per U-Net call disappear from the step loop.  Each row is bit-identical to what forward() computes
+        for that timestep (a GEMM row does not depend on the other rows; the tile / split-K choice depends on ceil(M / 128),
+        which is 1 either way — asserted).  `select_timestep(i)` copies row i into a static (1, sum cout) buffer whose column
+        slices are the `rowbias` operands of the ResBlocks' conv1 (stable addresses: captured HIP graphs keep reading them).
+        Valid until `release_timesteps()` or the next parameter update, like the text-context cache."""
+        P = self.params
+        ts = torch.as_tensor(timesteps, dtype=torch.int32, device=self.device).reshape(-1).contiguous()
+        T = ts.numel()
+        if T > 128:
+            raise ValueError("precompute_timesteps: more than 128 steps would change the GEMM tiling of the time path")
+        names = self.time_proj_names()
+        widths = [P[n + ".time_emb_proj.bias"].numel() for n in names]
+        total = sum(widths)
+        ent = self._temb
+        if ent is None or ent["table"].shape != (T, total):
+            row = torch.zeros(1, total, dtype=torch.float32, device=self.device) if ent is None else ent["row"]
+            views, off = {}, 0
+            for n, w in zip(names, widths):
+                views[n] = row[:, off:off + w]
+                off += w
+            ent = dict(table=torch.empty(T, total, dtype=torch.float32, device=self.device), row=row, views=views, names=names, widths=widths)
+            self._temb = ent
+        emb = L.timestep_embedding(ts, self.cfg.block_out_channels[0])
+        t1 = L.linear(emb, P["time_embedding.linear_1.kernel"], P["time_embedding.linear_1.bias"])
+        temb = L.linear(L.silu(t1), P["time_embedding.linear_2.kernel"], P["time_embedding.linear_2.bias"])
+        act = L.silu(temb)
+        off = 0
+        for n, w in zip(names, widths):
+            L.linear(act, P[n + ".time_emb_proj.kernel"], P[n + ".time_emb_proj.bias"], out=ent["table"][:, off:off + w], ld_out=total)
+            off += w
+        self._temb_active = True
+
+    def select_timestep(self, i):
+        """Make step i of the table current (one small device copy, stream-ordered with the U-Net launches / graph replay)."""
+        self._temb["row"].copy_(self._temb["table"][i:i + 1])
+
+    def release_timesteps(self):
+        self._temb_active = False
+
     def forward_graphed(self, sample, timesteps, context, cfg_dup=False):
         """Same as forward(), but the ~1000 kernel launches of one U-Net pass are captured once into a HIP graph (per
         input geometry) and replayed: the launch-bound host loop disappears from the sampling hot loop.  Inputs are copied
         into the graph's static buffers; the returned tensor is the graph's static output (valid until the next replay).
         Weights are read in place, so optimizer updates / re-packing are seen by later replays."""
-        key = (tuple(sample.shape), tuple(context.shape), L.DATAPATH, self._ctx_kv_active, bool(cfg_dup))
+        key = (tuple(sample.shape), tuple(context.shape), L.DATAPATH, self._ctx_kv_active, bool(cfg_dup), self._temb_active)
         if not hasattr(self, "_graphs"):
             self._graphs = {}
         ent = self._graphs.get(key)

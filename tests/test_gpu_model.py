@@ -92,6 +92,36 @@ def test_sampler_matches_oracle_config1(tiny):
     assert np.abs(img - oimg).max() < 5e-3
 
 
+def test_time_projection_table_is_bit_identical_to_per_step_time_path(tiny, monkeypatch):
+    """precompute_timesteps / select_timestep: the sampler runs the time path (embedding MLP + every ResBlock's time_emb_proj) once
+    per call for all T steps; trajectories and log-probs must not change by a bit, eagerly and under HIP-graph replay."""
+    op, unet, ovp, vae = tiny
+    sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", set_alpha_to_one=False, steps_offset=1)
+    pipe = StableDiffusionPipeline(unet, vae, sched)
+    state = sched.create_state(device=DEV)
+    g = torch.Generator().manual_seed(5)
+    emb = torch.randn(2, 77, 64, generator=g).to(DEV)
+    neg = torch.randn(1, 77, 64, generator=g).expand(2, -1, -1).contiguous().to(DEV)
+    key = OP.PRNGKey(11)
+    run = lambda jit: pipe(emb, neg, {"unet": unet.params, "scheduler": state}, key, 5, height=64, width=64, guidance_scale=5.0,
+                           eta=1.0, jit=jit)
+    monkeypatch.setenv("DDPO_TEMB_CACHE", "0")
+    ref = [t.clone() for t in run(False)]
+    monkeypatch.setenv("DDPO_TEMB_CACHE", "1")
+    for jit in (False, True, True):                      # second jit call replays the graph captured by the first
+        out = run(jit)
+        assert all(torch.equal(a, b) for a, b in zip(out, ref)), jit
+    assert unet._temb is not None and not unet._temb_active and unet._temb["table"].shape[0] == 5
+    # outside a sampling call forward() still computes the time path itself (training, per-sample timesteps)
+    x = torch.randn(3, 4, 8, 8, device=DEV)
+    t = torch.tensor([981, 21, 501], dtype=torch.int32, device=DEV)
+    c = torch.randn(3, 77, 64, device=DEV)
+    y0 = unet(x, t, c)
+    unet.precompute_timesteps([981, 21, 501])
+    unet.release_timesteps()
+    assert torch.equal(unet(x, t, c), y0)
+
+
 def test_graph_replay_survives_a_change_of_sampling_geometry(tiny):
     """the text-context K/V buffers are keyed by (layer, context rows) and never replaced, so a HIP graph captured
     for batch 2 still reads valid K/V after the same U-Net sampled batch 1 in between (it used to replay against freed memory)."""

@@ -20,6 +20,7 @@ DEV = "cuda"
 def _planes_on(monkeypatch):
     """The plane-fed path is opt-in (DDPO_PLANES=1); these tests exercise it whatever the environment says."""
     monkeypatch.setattr(L, "PLANES", True)
+    monkeypatch.setattr(L, "PLANES_ALL", True)       # plane-feed every eligible layer (the model's speed rule planes_pay() skips small ones)
 
 
 def _bf16x3():
