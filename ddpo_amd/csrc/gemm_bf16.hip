@@ -512,31 +512,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
         if (conv && tap < ntaps) set_tap(tap);
       }
     };
-    if constexpr (APL == 1) {
-      // Two LDS stages.  Per k-tile: wait for my pieces of tile kt, barrier (everybody's pieces landed AND everybody has finished
-      // reading the other stage), request tile kt + 1 into the other stage, then run the MFMAs of tile kt under that request.
-      auto step = [&](int kt, auto cur_c) {
-        constexpr int cur = decltype(cur_c)::value;
-        // vmcnt(0): my LDS-DMA pieces of tile kt are in LDS.  lgkmcnt(0): my fragment reads of the OTHER stage (tile kt - 1) have
-        // returned, so no wave can start overwriting that stage (below, after the barrier) while a read of it is in flight.
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (kt + 1 < nk) fill(cur ^ 1);
-        Frag g0, g1;
-        ldfrag(cur, 0, g0);
-        ldfrag(cur, 1, g1);
-        mma(g0, 0, TM * TN);
-        mma(g1, 0, TM * TN);
-      };
-      fill(0);
-      int kt = 0;
-#pragma unroll 1
-      for (; kt + 1 < nk; kt += 2) {
-        step(kt, std::integral_constant<int, 0>{});
-        step(kt + 1, std::integral_constant<int, 1>{});
-      }
-      if (kt < nk) step(kt, std::integral_constant<int, 0>{});
-    } else if constexpr (APL == 4) {
+    if constexpr (APL == 4) {
       // Plain schedule for the TALL 256x320 tile (64 x 160 per wave: 160 accumulator registers leave room for ONE fragment set;
       // the second wave of the SIMD covers the LDS latency).  28 fragment reads and 9 LDS-DMA pieces feed 60 MFMAs per wave and
       // k-tile, against 24 + 7 for 30 MFMAs on the 128x320 tile: 36 % fewer L2 and 42 % fewer LDS bytes per MFMA.
@@ -651,10 +627,6 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
       // to have landed and for its own reads of tile kt's stage to have returned, the barrier publishes both facts, tile kt + 2 is
       // requested into the stage just freed, the ks = 0 fragments of tile kt + 1 are requested and the ks = 1 MFMAs run under them.
       const bool late = d.splits != 0 && wv >= NW / 2;          // staggered request (see DDPO_APL_MODE)
-      // APL == 5: the same loop with s_setprio 1 around the MFMA clusters — with the staggered request the two waves of a SIMD
-      // are in different phases (one issuing LDS-DMA / fragment reads, one in MFMAs), which is when the priority hint has
-      // something to arbitrate (programming guide T5).  A separate instantiation, so APL == 2's code is untouched.
-      constexpr bool PRIO = (APL == 5);
       Frag g0, g1;
       fill(0);
       if (nk > 1) fill(1);
@@ -665,23 +637,17 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
         constexpr int cur = decltype(cur_c)::value;
         ldfrag(cur, 1, g1);
         __builtin_amdgcn_sched_barrier(0);
-        if (PRIO) __builtin_amdgcn_s_setprio(1);
         mma(g0, 0, TM * TN);
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (kt + 2 < nk && !late) fill(cur);
         if (kt + 1 < nk) ldfrag(cur ^ 1, 0, g0);
         __builtin_amdgcn_sched_barrier(0);
-        if (PRIO) __builtin_amdgcn_s_setprio(1);
         mma(g1, 0, (TM * TN) / 2);
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         if (kt + 2 < nk && late) fill(cur);
-        if (PRIO) __builtin_amdgcn_s_setprio(1);
         mma(g1, (TM * TN) / 2, TM * TN);
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
       };
       int kt = 0;
@@ -1141,10 +1107,10 @@ static int wide_splits(const ddpo_gemm_desc& d, bool have_ws, size_t ws_bytes) {
   return splits;
 }
 
-template <int NPASS, int APL = 0, int WM = 4>
+template <int NPASS, int APL = 0>
 static int launch_bf16_wide(const ddpo_gemm_desc& d, const uint16_t* w_hi, const uint16_t* w_lo, int ldw, float* ws, size_t ws_bytes,
                             hipStream_t st) {
-  constexpr int BM = 128, BN = 320, WN = 2;      // WM = 4: 8 waves of 32x160 (two per SIMD); WM = 2: 4 waves of 64x160 (one per SIMD, 512 registers)
+  constexpr int BM = 128, BN = 320, WM = 4, WN = 2;      // 8 waves of 32x160, two per SIMD
   const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;
   const int nblk = tiles_m * tiles_n;
   const int nk_total = d.K / BF_BK;
@@ -1248,12 +1214,6 @@ static int dispatch_bf16(const ddpo_gemm_desc& d, const uint16_t* w_hi, const ui
   if (wide_mode && d.N % 320 == 0 && d.M >= 512 && buf_path_ok(d, ldw) && !(d.K / BF_BK < 16 && d.N > 1280) &&
       (long)((d.M + 127) / 128) * (d.N / 320) * wsplits >= 200 &&
       !(wsplits > 1 && d.K / BF_BK < 64)) {     // a split short reduction only adds the reduce pass (measured equal to 128x128 unsplit)
-    if constexpr (APL == 2) {
-      // DDPO_APL_W4=1 (tuning knob): the same tile on FOUR waves of 64x160, one per SIMD with the whole 512-entry register file —
-      // 0.47 fragment reads per MFMA instead of 0.8 and no second wave competing for the SIMD's matrix pipe
-      static const int w4_mode = [] { const char* e = getenv("DDPO_APL_W4"); return e ? atoi(e) : 0; }();
-      if (w4_mode) return launch_bf16_wide<3, 2, 2>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st);
-    }
     return npass == 3 ? launch_bf16_wide<3, APL>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st) : launch_bf16_wide<1>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st);
   }
   const long t128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128);
@@ -1312,22 +1272,18 @@ extern "C" int ddpo_gemm_conv_fwd_bf16_planes(const ddpo_gemm_desc* dp, const ui
   d.w = reinterpret_cast<const float*>(a_lo);
   d.ld_src = lda;
   if (!buf_path_ok(d, ldw)) return DDPO_EINVAL;      // Cin (K) % 32 == 0 and 31-bit byte offsets: callers keep such layers on the fp32-fed entry
-  // DDPO_APL_MODE (tuning knob, read once): 1 = plain two-stage loop (wait, barrier, request, compute); 2 = barrier in the
-  // middle of the k-tile with the fragment reads software-pipelined across it; +4 = the upper half of the waves requests its
-  // pieces half a k-tile later than the lower half (the two waves of a SIMD then alternate between DMA issue and MFMAs).
-  // 3 = mode 2 with the weight operand three LDS stages deep (requested two k-tiles ahead, counted vmcnt); 7 = 3 + stagger;
-  // +8 on mode 2 / 6 (10 / 14) = s_setprio 1 around the MFMA clusters.
-  // Measured on the SD-1.5 layers at batch 16 (profiles/r01_probe_gemm_planes_modes.md, r02_planes_ab.md): warm, 6 ~ 7 ~ 14 > 1 ~ 2
-  // > fp32-fed; with the caches flushed before every launch (weights cold = the in-model condition) 7 keeps its gain (400 TF on
-  // conv 960->320 @ 64^2) while 6 drops to 359.  7 is the default; every mode is bit-identical to the fp32-fed kernel on hardware.
+  // DDPO_APL_MODE (tuning knob, read once): 2 = two LDS stages, barrier in the middle of the k-tile with the fragment reads
+  // software-pipelined across it; 3 = the same with the weight operand three LDS stages deep (requested two k-tiles ahead, counted
+  // vmcnt); +4 (6 / 7) = the upper half of the waves requests its pieces half a k-tile later than the lower half, so the two waves of a
+  // SIMD alternate between DMA issue and MFMAs.  Measured on the SD-1.5 layers at batch 16 (profiles/r01_probe_gemm_planes_modes.md and
+  // round 2): warm, 6 ~ 7 > 2; with the caches flushed before every launch (weights cold = the in-model condition) 7 keeps its gain
+  // (400 TF on conv 960->320 @ 64^2) while 6 drops to 359.  7 is the default.  Rejected after measurement and removed in round 2: the
+  // plain wait / barrier / request / compute loop (mode 1), s_setprio around the MFMA clusters (10 / 14: no effect), the four-wave
+  // 128x320 tile (slower), a 128x160 tile with two workgroups per CU for short reductions (no gain, profiles/r02_probe_n160.log).
   static const int apl_mode = [] { const char* e = getenv("DDPO_APL_MODE"); return e ? atoi(e) : 7; }();
   d.splits = (apl_mode & 4) ? 1 : 0;                 // `splits` is a wgrad-only field: the forward kernel reads it as the stagger flag
-  if ((apl_mode & 11) == 10) return dispatch_bf16<5>(d, w_hi, w_lo, ldw, 3, ws, ws_bytes, as_stream(stream));   // 2 + 8: s_setprio (10 / 14)
-  switch (apl_mode & 3) {
-    case 1: return dispatch_bf16<1>(d, w_hi, w_lo, ldw, 3, ws, ws_bytes, as_stream(stream));
-    case 3: return dispatch_bf16<3>(d, w_hi, w_lo, ldw, 3, ws, ws_bytes, as_stream(stream));      // three weight stages (7 = + stagger)
-    default: return dispatch_bf16<2>(d, w_hi, w_lo, ldw, 3, ws, ws_bytes, as_stream(stream));
-  }
+  if ((apl_mode & 3) == 3) return dispatch_bf16<3>(d, w_hi, w_lo, ldw, 3, ws, ws_bytes, as_stream(stream));      // three weight stages (7 = + stagger)
+  return dispatch_bf16<2>(d, w_hi, w_lo, ldw, 3, ws, ws_bytes, as_stream(stream));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1421,9 +1377,11 @@ __device__ __forceinline__ bf16x8 lds_frag(const uint32_t* base, int row, int dw
 // tensor: the activation planes a forward GroupNorm / LayerNorm wrote, or dY planes from a plane-emitting output stage) — the
 // loader then only has to pair pixels m / m+1 of a channel into a dword (one v_perm_b32 per plane dword) instead of running the
 // fp32 -> bf16 split (2 v_cvt_pk + 2 v_sub + 2 mask / shift per pair): the split was ~2/3 of this kernel's VALU work, which
-// bounds it (profiles/r01_train_fuse10_kernel_stats.md).  Same values reach the MFMAs: results are identical to the fp32-fed form.
-template <bool APLN, bool BPLN, bool DEEPW>
-__global__ void __launch_bounds__(BF_THREADS, 2) gemm_wgrad_bf16_kernel(const ddpo_gemm_desc d, int tiles_n, int m_per_split,
+// looked like its bound (measured in round 2: +0.5 % on the train step, so it is not).  Same values reach the MFMAs as in the fp32-fed form.
+// Also measured and rejected in round 2: unconditional loads + a second register stage (two k-tiles of prefetch): 256 VGPRs with
+// 12-24 spilled at two waves per SIMD, train step 9 % SLOWER (profiles/r02_ab_wgrad_deep.log).
+template <bool APLN, bool BPLN>
+__global__ void __launch_bounds__(BF_THREADS) gemm_wgrad_bf16_kernel(const ddpo_gemm_desc d, int tiles_n, int m_per_split,
                                                                    const uint16_t* __restrict__ a_hi, const uint16_t* __restrict__ a_lo,
                                                                    const uint16_t* __restrict__ b_hi, const uint16_t* __restrict__ b_lo) {
   constexpr int BM = 128, BN = 128, BK = 32;
@@ -1470,58 +1428,54 @@ __global__ void __launch_bounds__(BF_THREADS, 2) gemm_wgrad_bf16_kernel(const dd
     }
   const int64_t tap_off = conv ? ((int64_t)dky * d.W + dkx) * d.ld_src + ci : kg;
 
-  // Two register stages: the loads of k-tile kt + 2 are issued before the MFMAs of tile kt, the split / transpose / LDS store of
-  // tile kt + 1 runs after them (one stage covered only ~770 MFMA cycles of the ~2-3 k cycles an HBM / L2 round trip takes).
-  // Loads are UNCONDITIONAL (a masked element reads a clamped in-range address and is zeroed when it is staged): no branch stands
-  // between a load and its use, so the compiler keeps the full prefetch distance.
-  struct WStage { float4 a[2][2], b[2][2]; uint32_t mask; };     // plane operands keep (hi.x, hi.y, lo.x, lo.y) raw bits in the float4
+  float4 ra[2][2], rb[2][2];          // fp32 operands; a plane operand keeps (hi.x, hi.y, lo.x, lo.y) raw bits in the same registers
   auto as_f4 = [](const uint2 h, const uint2 l) {
     return make_float4(__uint_as_float(h.x), __uint_as_float(h.y), __uint_as_float(l.x), __uint_as_float(l.y));
   };
-  auto load_tile = [&](int kt, WStage& sg) {
-    uint32_t mask = 0;
+  auto load_tile = [&](int kt) {
 #pragma unroll
     for (int p = 0; p < 2; ++p)
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         const int m = m_begin + kt * BK + 16 * p + 2 * pp + e;
-        const bool inb = m < m_end;
-        bool ok = kvalid && inb;
-        int64_t aoff = (int64_t)m * d.ld_src + tap_off;
-        if (conv) {
-          const int iy = poy[p][e] * d.stride + dky, ix = pox[p][e] * d.stride + dkx;       // virtual (upsampled) coordinates
-          ok = ok && iy >= 0 && iy < VH && ix >= 0 && ix < VW;
-          if (!simple) {
-            const int sy = d.upsample ? (iy >> 1) : iy, sx = d.upsample ? (ix >> 1) : ix;
-            aoff = ((int64_t)(pb[p][e] * d.H + sy) * d.W + sx) * d.ld_src + ci;
+        float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
+        if (m < m_end) {
+          bool ok = kvalid;
+          int64_t aoff = (int64_t)m * d.ld_src + tap_off;
+          if (conv) {
+            const int iy = poy[p][e] * d.stride + dky, ix = pox[p][e] * d.stride + dkx;       // virtual (upsampled) coordinates
+            ok = ok && iy >= 0 && iy < VH && ix >= 0 && ix < VW;
+            if (!simple) {
+              const int sy = d.upsample ? (iy >> 1) : iy, sx = d.upsample ? (ix >> 1) : ix;
+              aoff = ((int64_t)(pb[p][e] * d.H + sy) * d.W + sx) * d.ld_src + ci;
+            }
+          }
+          if (ok) {
+            if (APLN) va = as_f4(*reinterpret_cast<const uint2*>(a_hi + aoff), *reinterpret_cast<const uint2*>(a_lo + aoff));
+            else va = *reinterpret_cast<const float4*>(d.src + aoff);
+          }
+          if (nvalid) {
+            const int64_t boff = (int64_t)m * d.ld_w + ng;
+            if (BPLN) vb = as_f4(*reinterpret_cast<const uint2*>(b_hi + boff), *reinterpret_cast<const uint2*>(b_lo + boff));
+            else vb = *reinterpret_cast<const float4*>(d.w + boff);
           }
         }
-        aoff = ok ? aoff : 0;
-        const bool bok = nvalid && inb;
-        const int64_t boff = bok ? (int64_t)m * d.ld_w + ng : 0;
-        if (APLN) sg.a[p][e] = as_f4(*reinterpret_cast<const uint2*>(a_hi + aoff), *reinterpret_cast<const uint2*>(a_lo + aoff));
-        else sg.a[p][e] = *reinterpret_cast<const float4*>(d.src + aoff);
-        if (BPLN) sg.b[p][e] = as_f4(*reinterpret_cast<const uint2*>(b_hi + boff), *reinterpret_cast<const uint2*>(b_lo + boff));
-        else sg.b[p][e] = *reinterpret_cast<const float4*>(d.w + boff);
-        mask |= (ok ? 1u : 0u) << (2 * p + e) | (bok ? 16u : 0u) << (2 * p + e);
+        ra[p][e] = va;
+        rb[p][e] = vb;
         if (conv) {          // advance this pixel by BK
           pox[p][e] += BK;
           while (pox[p][e] >= d.OW) { pox[p][e] -= d.OW; ++poy[p][e]; }
           while (poy[p][e] >= d.OH) { poy[p][e] -= d.OH; ++pb[p][e]; }
         }
       }
-    sg.mask = mask;
   };
-  auto store_tile = [&](int buf, const WStage& sg) {
+  auto store_tile = [&](int buf) {
     uint32_t* st = smem[buf];
-    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       const int dw = pp + 8 * p;                        // dword (= pixel pair) index within the row
-      const float4 va0 = (sg.mask >> (2 * p)) & 1u ? sg.a[p][0] : zero, va1 = (sg.mask >> (2 * p + 1)) & 1u ? sg.a[p][1] : zero;
-      const float4 vb0 = (sg.mask >> (4 + 2 * p)) & 1u ? sg.b[p][0] : zero, vb1 = (sg.mask >> (5 + 2 * p)) & 1u ? sg.b[p][1] : zero;
-      const float* a0 = &va0.x; const float* a1 = &va1.x;
-      const float* b0 = &vb0.x; const float* b1 = &vb1.x;
+      const float* a0 = &ra[p][0].x; const float* a1 = &ra[p][1].x;
+      const float* b0 = &rb[p][0].x; const float* b1 = &rb[p][1].x;
       // plane operand: registers hold [ch0|ch1, ch2|ch3] (hi) and the same for lo, per pixel; pair channel j of pixels m, m+1
       auto pair = [](const float* p0, const float* p1, int j, int plane) {
         const uint32_t w0 = __float_as_uint(p0[2 * plane + (j >> 1)]), w1 = __float_as_uint(p1[2 * plane + (j >> 1)]);
@@ -1552,7 +1506,12 @@ __global__ void __launch_bounds__(BF_THREADS, 2) gemm_wgrad_bf16_kernel(const dd
 
   const int nk = (m_end - m_begin + BK - 1) / BK;
   const int li = lane & 31, h = lane >> 5;
-  auto compute = [&](int cur) {
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) load_tile(kt + 1);
     const uint32_t* st = smem[cur];
 #pragma unroll
     for (int ms = 0; ms < 2; ++ms) {
@@ -1574,36 +1533,8 @@ __global__ void __launch_bounds__(BF_THREADS, 2) gemm_wgrad_bf16_kernel(const dd
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
     }
-  };
-  WStage s0;
-  load_tile(0, s0);
-  store_tile(0, s0);
-  if constexpr (!DEEPW) {           // one register stage (round 1's loop): tile kt + 1 loads behind the MFMAs of tile kt
+    if (kt + 1 < nk) store_tile(cur ^ 1);
     __syncthreads();
-#pragma unroll 1
-    for (int kt = 0; kt < nk; ++kt) {
-      const int cur = kt & 1;
-      if (kt + 1 < nk) load_tile(kt + 1, s0);
-      compute(cur);
-      if (kt + 1 < nk) store_tile(cur ^ 1, s0);
-      __syncthreads();
-    }
-  } else {
-  WStage s1;
-  if (nk > 1) load_tile(1, s0);
-  __syncthreads();
-#pragma unroll 1
-  for (int kt = 0; kt < nk; kt += 2) {
-    if (kt + 2 < nk) load_tile(kt + 2, s1);          // even step: MFMAs on LDS[0]; s0 holds tile kt + 1
-    compute(0);
-    if (kt + 1 < nk) store_tile(1, s0);
-    __syncthreads();
-    if (kt + 1 >= nk) break;
-    if (kt + 3 < nk) load_tile(kt + 3, s0);          // odd step: MFMAs on LDS[1]; s1 holds tile kt + 2
-    compute(1);
-    if (kt + 2 < nk) store_tile(0, s1);
-    __syncthreads();
-  }
   }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -1661,17 +1592,10 @@ static int wgrad_bf16x3(const ddpo_gemm_desc* dp, const uint16_t* a_hi, const ui
   splits = (d.M + mps - 1) / mps;
   hipStream_t st = as_stream(stream);
   const dim3 grid(tiles, splits), blk(BF_THREADS);
-  static const int deep = [] { const char* e = getenv("DDPO_WGRAD_DEEP"); return e ? atoi(e) : 1; }();     // tuning knob: register stages
-#define WG_LAUNCH(A, B)                                                                                                               \
-  do {                                                                                                                                \
-    if (deep) hipLaunchKernelGGL((gemm_wgrad_bf16_kernel<A, B, true>), grid, blk, 0, st, d, tiles_n, mps, a_hi, a_lo, b_hi, b_lo);    \
-    else hipLaunchKernelGGL((gemm_wgrad_bf16_kernel<A, B, false>), grid, blk, 0, st, d, tiles_n, mps, a_hi, a_lo, b_hi, b_lo);        \
-  } while (0)
-  if (a_hi && b_hi) WG_LAUNCH(true, true);
-  else if (a_hi) WG_LAUNCH(true, false);
-  else if (b_hi) WG_LAUNCH(false, true);
-  else WG_LAUNCH(false, false);
-#undef WG_LAUNCH
+  if (a_hi && b_hi) hipLaunchKernelGGL((gemm_wgrad_bf16_kernel<true, true>), grid, blk, 0, st, d, tiles_n, mps, a_hi, a_lo, b_hi, b_lo);
+  else if (a_hi) hipLaunchKernelGGL((gemm_wgrad_bf16_kernel<true, false>), grid, blk, 0, st, d, tiles_n, mps, a_hi, a_lo, b_hi, b_lo);
+  else if (b_hi) hipLaunchKernelGGL((gemm_wgrad_bf16_kernel<false, true>), grid, blk, 0, st, d, tiles_n, mps, a_hi, a_lo, b_hi, b_lo);
+  else hipLaunchKernelGGL((gemm_wgrad_bf16_kernel<false, false>), grid, blk, 0, st, d, tiles_n, mps, a_hi, a_lo, b_hi, b_lo);
   DDPO_LAUNCH_CHECK();
   return DDPO_OK;
 }
