@@ -181,7 +181,9 @@ class Comm:
         self.dev = torch.device("cuda", self.local_rank) if on_gpu else torch.device("cpu")
         if on_gpu:
             torch.cuda.set_device(self.local_rank)
-        if self.world > 1:
+        # DDPO_FORCE_DIST=1: build the process group even for ONE rank — the only way to execute the RCCL path (communicator
+        # bound to the device, all_reduce, barrier) on a 1-GPU box (tests/test_gpu_rccl_single_rank.py)
+        if self.world > 1 or os.environ.get("DDPO_FORCE_DIST") == "1":
             import torch.distributed as dist
             self.dist = dist
             self.backend = args.backend or ("nccl" if on_gpu else "gloo")

@@ -1207,7 +1207,11 @@ static int dispatch_bf16(const ddpo_gemm_desc& d, const uint16_t* w_hi, const ui
     // 256x320 tiles where they still give every CU a workgroup (the 64x64-latent level): 345 / 428 TF against 320 / 390 for the
     // 128x320 tile on conv 320->320 / 960->320 (bit-identical; round-2 probe).  DDPO_APL_TALL=0 switches them off.
     static const int tall_mode = [] { const char* e = getenv("DDPO_APL_TALL"); return e ? atoi(e) : 1; }();
-    if (tall_mode && d.N % 320 == 0 && d.epilogue == 0 && (long)((d.M + 255) / 256) * (d.N / 320) >= 200)
+    // ... and where their last round of 256 is not much emptier than the 128x320 grid's: 256 tall tiles (SD-1.5, 64x64 latents at batch 16)
+    // are exactly one round; 576 (SD-2.1, 96x96) are 2.25 rounds = 3 rounds of time, where 1152 wide tiles waste half a round of five
+    const long ntall = (long)((d.M + 255) / 256) * (d.N / 320), nwide = (long)((d.M + 127) / 128) * (d.N / 320);
+    const double eff_tall = (double)ntall / (double)(((ntall + 255) / 256) * 256), eff_wide = (double)nwide / (double)(((nwide + 255) / 256) * 256);
+    if (tall_mode && d.N % 320 == 0 && d.epilogue == 0 && ntall >= 200 && (tall_mode == 2 || eff_tall * 1.08 >= eff_wide))     // DDPO_APL_TALL=2: without the round rule (A/B)
       return launch_bf16_tall(d, w_hi, w_lo, ldw, st);
   }
   const int wsplits = wide_splits(d, wsf != nullptr, ws_bytes);

@@ -18,7 +18,8 @@ import torch.distributed as dist
 def init(backend=None):
     """Initialise from torchrun-style env (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*); no-op for a single process."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1 and not dist.is_initialized():
+    # DDPO_FORCE_DIST=1 builds the group for a single rank too (RCCL smoke test on a 1-GPU box)
+    if (world > 1 or os.environ.get("DDPO_FORCE_DIST") == "1") and not dist.is_initialized():
         if backend is None:
             backend = os.environ.get("DDPO_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         kw = {}
@@ -38,6 +39,11 @@ def process_count():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+def _through_backend():
+    """True when collectives must go through torch.distributed: more than one rank, or a forced single-rank group (smoke test)."""
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("DDPO_FORCE_DIST") == "1")
+
+
 def _comm_device():
     return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
 
@@ -45,7 +51,7 @@ def _comm_device():
 def allgather_array(x):
     """process_allgather(x, tiled=True): concatenate equally-shaped per-rank numpy arrays along axis 0, on every rank."""
     x = np.asarray(x)
-    if process_count() == 1:
+    if not _through_backend():
         return x
     t = torch.from_numpy(np.ascontiguousarray(x)).to(_comm_device())
     out = [torch.empty_like(t) for _ in range(process_count())]
@@ -56,7 +62,7 @@ def allgather_array(x):
 def allgather_tensor(t):
     """Concatenate equally-shaped per-rank tensors along axis 0 on every rank, staying on the tensor's device when the backend can
     (nccl = RCCL: one all_gather_into_tensor over xGMI; gloo: through host memory)."""
-    if process_count() == 1:
+    if not _through_backend():
         return t
     src = t.contiguous()
     cd = _comm_device()
@@ -69,7 +75,7 @@ def allgather_tensor(t):
 
 def allgather_strings(strings):
     strings = list(strings)
-    if process_count() == 1:
+    if not _through_backend():
         return strings
     out = [None] * process_count()
     dist.all_gather_object(out, strings)
@@ -79,9 +85,9 @@ def allgather_strings(strings):
 def pmean_info(info):
     """Mean over ranks of a dict of scalars (device tensors or floats) with ONE small all-reduce."""
     keys = sorted(info)
-    vals = torch.stack([torch.as_tensor(info[k], dtype=torch.float32).reshape(()).to(_comm_device() if process_count() > 1 else "cpu")
+    vals = torch.stack([torch.as_tensor(info[k], dtype=torch.float32).reshape(()).to(_comm_device() if _through_backend() else "cpu")
                         for k in keys])
-    if process_count() > 1:
+    if _through_backend():
         dist.all_reduce(vals, op=dist.ReduceOp.SUM)
         vals = vals / process_count()
     return {k: float(v) for k, v in zip(keys, vals.cpu())}
@@ -89,7 +95,7 @@ def pmean_info(info):
 
 def allreduce_sum_(flat, group=None):
     """In-place sum over ranks of a flat buffer (the gradient all-reduce)."""
-    if process_count() > 1:
+    if _through_backend():
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     return flat
 
@@ -102,5 +108,5 @@ def local_slice(global_array, rank=None, world=None):
 
 
 def barrier():
-    if process_count() > 1:
+    if _through_backend():
         dist.barrier()
