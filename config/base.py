@@ -20,6 +20,10 @@ _PG_DEFAULTS = (
     ("ppo_clip_range", 1e-4), ("train_cfg", True), ("learning_rate", 1e-5), ("beta1", 0.9), ("beta2", 0.999),
     ("weight_decay", 1e-4), ("epsilon", 1e-8), ("max_grad_norm", 1.0), ("save_freq", 10), ("optimizer", "adamw"),
     ("train_timestep_ratio", 1.0), ("prompt_kwargs", {}), ("per_prompt_stats_bufsize", 32), ("per_prompt_stats_min_count", 16),
+    # engine-specific addition (not a reference flag): how optax.adamw(mu_dtype=bfloat16) forms `b1 * mu` — True: in bf16, what JAX's
+    # weak-type promotion does (scalar x bf16 array stays bf16: b1 -> 0.8984375, product rounded before the f32 term is added);
+    # False: decay in f32, one rounding when mu is stored.  optax is not installable here, so the reading is a derivation, not a measurement.
+    ("mu_decay_in_bf16", True),
 )
 
 base = {"pg": dict(_PG_DEFAULTS)}

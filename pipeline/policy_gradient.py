@@ -43,6 +43,13 @@ from ddpo_amd.utils.stat_tracking import PerPromptStatTracker
 from ddpo_amd.models.text import make_uncond_text
 
 
+def _flag(value, default):
+    """CLI flags arrive as strings ("False", "0"); None = not given."""
+    if value is None:
+        return default
+    return value if isinstance(value, bool) else str(value).lower() not in ("0", "false", "no")
+
+
 class Parser(utils.Parser):
     config: str = "config.base"
     dataset: str = "consistent_imagenet"
@@ -105,7 +112,14 @@ def main(argv=None):
         raise NotImplementedError("only the adamw optimizer of the reference configs is implemented")
     state = AccumulatingTrainState(unet, AdamWConfig(learning_rate=args.learning_rate, b1=args.beta1, b2=args.beta2,
                                                      eps=args.epsilon, weight_decay=args.weight_decay,
-                                                     max_grad_norm=args.max_grad_norm))
+                                                     max_grad_norm=args.max_grad_norm,
+                                                     # optax.adamw(mu_dtype=bfloat16) forms `b1 * mu` with mu in bf16: JAX's weak-type
+                                                     # promotion keeps the ARRAY's dtype, so the product (and b1 itself, 0.9 -> 0.8984375) is
+                                                     # rounded to bf16 before the f32 `(1 - b1) * g` is added — the default here and in
+                                                     # oracle/optim.py.  `--mu_decay_in_bf16 False` / DDPO_MU_DECAY_IN_BF16=0 selects the all-f32
+                                                     # reading (decay in f32, one rounding at the store) should a real optax run disagree.
+                                                     mu_decay_in_bf16=_flag(getattr(args, "mu_decay_in_bf16", None),
+                                                                            os.environ.get("DDPO_MU_DECAY_IN_BF16", "1") != "0")))
     sampling_scheduler_params = params["scheduler"]
 
     timer = utils.Timer()
