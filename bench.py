@@ -59,8 +59,8 @@ def parse(argv=None):
                          "epoch: one sample batch + its PPO micro-steps + optimizer updates (gradient all-reduce included); "
                          "comm: only the gradient all-reduce")
     ap.add_argument("--train-batch-size", type=int, default=2)
-    ap.add_argument("--train-fuse", type=int, default=int(os.environ.get("DDPO_TRAIN_FUSE", "10")),
-                    help="micro-steps per U-Net forward/backward (train_steps_fused, the entrypoint's default is 10); 1 = unfused")
+    ap.add_argument("--train-fuse", type=int, default=int(os.environ.get("DDPO_TRAIN_FUSE", "16")),
+                    help="micro-steps per U-Net forward/backward (train_steps_fused, the entrypoint's default is 16); 1 = unfused")
     ap.add_argument("--backend", default=os.environ.get("DDPO_DIST_BACKEND"), help="nccl (= RCCL, default on GPUs) | gloo (CPU tests of --mode comm)")
     ap.add_argument("--comm-mib", type=float, default=None, help="--mode comm: buffer size in MiB (default: the flat fp32 gradient, 3.44 GB)")
     ap.add_argument("--no-graph", action="store_true", help="launch the U-Net kernels eagerly instead of replaying a HIP graph")
@@ -288,9 +288,10 @@ def make_train_batch(args, comm, emb, neg, b):
             "prompt_embeds": emb[:b].contiguous(), "uncond_embeds": neg[:b].contiguous()}
 
 
-def measure_train(args, comm, L, unet, sched, state, emb, neg, steps, warmup, update_every=4):
-    """`steps` timed launches of `train_fuse` fused micro-steps of `train_batch_size` sample-timesteps (train_cfg=True), every
-    `update_every`-th closing with the optimizer (gradient all-reduce over ranks + fused AdamW + weight re-pack)."""
+def measure_train(args, comm, L, unet, sched, state, emb, neg, steps, warmup):
+    """`steps` timed launches of `train_fuse` fused micro-steps of `train_batch_size` sample-timesteps (train_cfg=True); every
+    n_inference_steps micro-steps (one mini-batch of the entrypoint) close with the optimizer (gradient all-reduce over ranks +
+    fused AdamW + weight re-pack)."""
     from ddpo_amd.training.policy_gradient import AccumulatingTrainState, AdamWConfig, train_step, train_steps_fused
     if L.DATAPATH != "fp32":
         unet.params.pack_bf16(bwd=True)
@@ -300,11 +301,14 @@ def measure_train(args, comm, L, unet, sched, state, emb, neg, steps, warmup, up
     tstate = AccumulatingTrainState(unet, AdamWConfig())
     fuse = max(1, args.train_fuse)
     k = 0
+    T = int(args.n_inference_steps)      # the entrypoint closes a mini-batch (one optimizer update) after its T timesteps
 
     def one():
         nonlocal k
-        k += 1
-        upd = (k % update_every == 0)
+        k += fuse
+        upd = k >= T
+        if upd:
+            k -= T
         if fuse == 1:
             train_step(tstate, batch, st, sched, True, 5.0, 1.0, 1e-4, do_opt_update=upd)
         else:
@@ -321,7 +325,7 @@ def measure_train(args, comm, L, unet, sched, state, emb, neg, steps, warmup, up
     key = (args.model, args.resolution)
     tf = value * 6 * UNET_FWD_TFLOP[key] if key in UNET_FWD_TFLOP else None
     return {"metric": "PPO train sample-timesteps/sec (train_cfg)", "value": value, "unit": "sample-timesteps/sec", "steps": steps, "warmup": warmup,
-            "ms_per_step": dt / steps * 1e3, "train_batch_size": b, "micro_steps_per_launch": fuse, "optimizer_update_every": update_every,
+            "ms_per_step": dt / steps * 1e3, "train_batch_size": b, "micro_steps_per_launch": fuse, "optimizer_update_every_micro_steps": T,
             "end_to_end_tflops": tf,
             "roofline": None if tf is None else {"bound": "mfma", "achieved": tf / comm.world, "peak": BF16_MFMA_PEAK_TFLOPS if args.datapath != "fp32" else FP32_MFMA_PEAK_TFLOPS,
                                                  "unit": "TFLOP/s", "frac": tf / comm.world / (BF16_MFMA_PEAK_TFLOPS if args.datapath != "fp32" else FP32_MFMA_PEAK_TFLOPS),
@@ -337,7 +341,7 @@ def bench_train(args, comm):
                           "n_gpus": comm.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.datapath, "data": "synthetic",
                           "config": {"workload": f"train_step, {args.model}, train_batch_size {args.train_batch_size}/GPU, train_cfg, "
-                                                 f"{res['micro_steps_per_launch']} micro-step(s) per U-Net forward/backward, optimizer update every 4 steps",
+                                                 f"{res['micro_steps_per_launch']} micro-step(s) per U-Net forward/backward, optimizer update every {res['optimizer_update_every_micro_steps']} micro-steps",
                                      "parallelism": f"dp{comm.world}"},
                           "end_to_end_tflops": res["end_to_end_tflops"], "roofline": res["roofline"],
                           "rccl_ranks": comm.world if comm.dist is not None else None, "allreduce": ar}), flush=True)

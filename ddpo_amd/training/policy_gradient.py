@@ -19,22 +19,24 @@ import torch
 from .. import lib as L
 
 ADV_CLIP_MAX = 10.0
-# PPO micro-steps per U-Net forward/backward in the entrypoint's training loop (train_steps_fused).  10 divides the default
-# 50 timesteps and turns the U-Net batch of 4 (2 samples x CFG) into 40 rows-of-latents: 28 -> 42 sample-timesteps/s on one
-# MI355X (profiles/r01_train_fuse.md).  DDPO_TRAIN_FUSE=1 restores one launch per micro-step.
-DEFAULT_TRAIN_FUSE = 10
+# PPO micro-steps per U-Net forward/backward in the entrypoint's training loop (train_steps_fused).  16 turns the U-Net batch of 4
+# (2 samples x CFG) into 64 rows-of-latents = 1024 of the 256x320 GEMM tiles at the 64x64 level = exactly 4 rounds of the 256 CUs;
+# round 1's default of 10 (batch 40 = 2.5 rounds) sat in a quantisation hole: 42.4 (k = 10) vs 44.1 (k = 8) vs 45.1 (k = 16)
+# sample-timesteps/s on one box (profiles/r02_ab_train_fuse.log; k = 1: 28).  The default 50 timesteps run as 16 + 16 + 16 + 2.
+# DDPO_TRAIN_FUSE=1 restores one launch per micro-step.
+DEFAULT_TRAIN_FUSE = 16
 
 
 def train_fuse_default(unet_rows_per_micro_step=None, latent_pixels=None):
-    """Micro-steps per launch.  An explicit DDPO_TRAIN_FUSE is taken as is; the default of 10 is reduced for geometries whose
-    activation tape would outgrow the footprint validated on hardware (U-Net batch 40 at 64x64 latents = 163,840 latent pixels
-    per launch): SD-2.1 at 96x96 latents fuses 4 micro-steps."""
+    """Micro-steps per launch.  An explicit DDPO_TRAIN_FUSE is taken as is; the default of 16 is reduced for geometries whose
+    activation tape would outgrow the footprint run on hardware (U-Net batch 64 at 64x64 latents = 262,144 latent pixels per
+    launch): SD-2.1 at 96x96 latents fuses 7 micro-steps."""
     import os
     if "DDPO_TRAIN_FUSE" in os.environ:
         return max(1, int(os.environ["DDPO_TRAIN_FUSE"]))
     k = DEFAULT_TRAIN_FUSE
     if unet_rows_per_micro_step and latent_pixels:
-        k = min(k, max(1, (40 * 4096) // (int(unet_rows_per_micro_step) * int(latent_pixels))))
+        k = min(k, max(1, (64 * 4096) // (int(unet_rows_per_micro_step) * int(latent_pixels))))
     return k
 
 

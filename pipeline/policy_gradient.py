@@ -240,7 +240,7 @@ def main(argv=None):
             for i in range(n_mini):
                 sl = slice(i * args.train_batch_size, (i + 1) * args.train_batch_size)
                 for j0 in (range(0, num_train_ts, train_fuse) if train_fuse > 1 else ()):
-                    # DDPO_TRAIN_FUSE=k (default 10): k consecutive timesteps of this mini-batch (same parameters: the optimizer only
+                    # DDPO_TRAIN_FUSE=k (default 16): k consecutive timesteps of this mini-batch (same parameters: the optimizer only
                     # steps at the last timestep) as one U-Net forward/backward over k micro-batches (train_steps_fused)
                     js = range(j0, min(j0 + train_fuse, num_train_ts))
                     batches = [{"prompt_embeds": mine["embeds"][sl], "uncond_embeds": train_uncond_prompt_embeds,

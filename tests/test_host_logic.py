@@ -175,11 +175,11 @@ def test_lds_dma_piece_map_reproduces_the_swizzled_lds_image(BM, BN, NW):
 def test_train_fuse_default_is_capped_by_the_validated_activation_footprint(monkeypatch):
     from ddpo_amd.training.policy_gradient import train_fuse_default
     monkeypatch.delenv("DDPO_TRAIN_FUSE", raising=False)
-    assert train_fuse_default() == 10
-    assert train_fuse_default(4, 64 * 64) == 10          # defaults: 2 samples x CFG at 64x64 latents -> U-Net batch 40 per launch
-    assert train_fuse_default(4, 96 * 96) == 4           # SD-2.1 at 768^2: same number of latent pixels per launch
+    assert train_fuse_default() == 16
+    assert train_fuse_default(4, 64 * 64) == 16          # defaults: 2 samples x CFG at 64x64 latents -> U-Net batch 64 per launch (4 whole rounds of 256x320 tiles)
+    assert train_fuse_default(4, 96 * 96) == 7           # SD-2.1 at 768^2: no more latent pixels per launch than that
     assert train_fuse_default(16, 96 * 96) == 1
-    assert train_fuse_default(4, 8 * 8) == 10
+    assert train_fuse_default(4, 8 * 8) == 16
     monkeypatch.setenv("DDPO_TRAIN_FUSE", "25")          # an explicit request is taken as is
     assert train_fuse_default(4, 96 * 96) == 25
     monkeypatch.setenv("DDPO_TRAIN_FUSE", "0")
