@@ -11,6 +11,15 @@ import torch
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
+def _free_port():
+    import socket
+    so = socket.socket()
+    so.bind(("127.0.0.1", 0))
+    p = so.getsockname()[1]
+    so.close()
+    return p
+
+
 FLAGS = ["--dataset", "compressed-animals", "--resolution", "64", "--n_inference_steps", "4", "--sample_batch_size", "2",
          "--train_batch_size", "2", "--num_train_epochs", "2", "--save_freq", "1", "--per_prompt_stats_min_count", "2",
          "--learning_rate", "1e-4"]
@@ -58,7 +67,7 @@ def test_entrypoint_two_ranks_share_one_gpu(tmp_path, semantics):
     on a multi-GPU node the same code path runs over RCCL).  Both ranks must end with bit-identical weights."""
     env = dict(os.environ, DDPO_MODEL_CONFIG="tiny", DDPO_DIST_BACKEND="gloo", PYTHONPATH=ROOT, DDPO_DP_SEMANTICS=semantics)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29571" if semantics == "multi_host" else "29573", os.path.join(ROOT, "tests", "_dp_driver.py"), str(tmp_path)]
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_dp_driver.py"), str(tmp_path)]
     p = subprocess.run(cmd, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=580)
     errs = "".join(open(tmp_path / f).read() for f in os.listdir(tmp_path) if f.startswith("error_"))
     assert p.returncode == 0, errs + p.stderr[-1500:]

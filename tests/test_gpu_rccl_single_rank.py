@@ -14,7 +14,17 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _launch(script_args, port):
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _launch(script_args, port=None):
+    port = port or _free_port()
     env = dict(os.environ, DDPO_FORCE_DIST="1", PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     env.pop("DDPO_DIST_BACKEND", None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
@@ -24,7 +34,7 @@ def _launch(script_args, port):
 
 @pytest.mark.timeout(600)
 def test_collectives_through_rccl_with_one_rank():
-    p = _launch([os.path.join(ROOT, "tests", "_rccl_driver.py")], 29581)
+    p = _launch([os.path.join(ROOT, "tests", "_rccl_driver.py")])
     assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-2500:]
     line = [l for l in p.stdout.splitlines() if l.startswith("RCCL_SMOKE ")][-1]
     out = json.loads(line[len("RCCL_SMOKE "):])
@@ -36,7 +46,7 @@ def test_collectives_through_rccl_with_one_rank():
 
 @pytest.mark.timeout(600)
 def test_bench_comm_mode_reports_the_rccl_world():
-    p = _launch([os.path.join(ROOT, "bench.py"), "--gpus", "1", "--mode", "comm", "--comm-mib", "256", "--steps", "2", "--warmup", "1"], 29583)
+    p = _launch([os.path.join(ROOT, "bench.py"), "--gpus", "1", "--mode", "comm", "--comm-mib", "256", "--steps", "2", "--warmup", "1"])
     assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-2500:]
     d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert d["rccl_ranks"] == 1 and d["allreduce"]["backend"] == "nccl" and d["allreduce"]["sum_correct"]
