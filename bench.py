@@ -59,8 +59,9 @@ def parse(argv=None):
                          "epoch: one sample batch + its PPO micro-steps + optimizer updates (gradient all-reduce included); "
                          "comm: only the gradient all-reduce")
     ap.add_argument("--train-batch-size", type=int, default=2)
-    ap.add_argument("--train-fuse", type=int, default=int(os.environ.get("DDPO_TRAIN_FUSE", "16")),
-                    help="micro-steps per U-Net forward/backward (train_steps_fused, the entrypoint's default is 16); 1 = unfused")
+    ap.add_argument("--train-fuse", type=int, default=None,
+                    help="micro-steps per U-Net forward/backward (train_steps_fused); default: what the entrypoint uses for this geometry "
+                         "(train_fuse_default: 16 at 64x64 latents, fewer for larger latents; DDPO_TRAIN_FUSE overrides); 1 = unfused")
     ap.add_argument("--backend", default=os.environ.get("DDPO_DIST_BACKEND"), help="nccl (= RCCL, default on GPUs) | gloo (CPU tests of --mode comm)")
     ap.add_argument("--comm-mib", type=float, default=None, help="--mode comm: buffer size in MiB (default: the flat fp32 gradient, 3.44 GB)")
     ap.add_argument("--no-graph", action="store_true", help="launch the U-Net kernels eagerly instead of replaying a HIP graph")
@@ -70,6 +71,9 @@ def parse(argv=None):
     args = ap.parse_args(argv)
     if args.resolution is None:
         args.resolution = {"sd15": 512, "sd21": 768}.get(args.model, 64)
+    if args.train_fuse is None:
+        from ddpo_amd.training.policy_gradient import train_fuse_default
+        args.train_fuse = train_fuse_default(args.train_batch_size * 2, (args.resolution // 8) ** 2)      # train_cfg: 2 U-Net rows per sample
     return args
 
 
