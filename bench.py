@@ -341,7 +341,7 @@ def bench_train(args, comm):
     res = measure_train(args, comm, L, unet, sched, state, emb, neg, args.steps, args.warmup)
     ar = time_allreduce(comm, unet.params.flat.numel()) if comm.dist is not None else None
     if comm.rank == 0:
-        print(json.dumps({"metric": "PPO train sample-timesteps/sec (train_cfg, 512^2)", "value": res["value"], "unit": "sample-timesteps/sec",
+        print(json.dumps({"metric": f"PPO train sample-timesteps/sec (train_cfg, {args.resolution}^2)", "value": res["value"], "unit": "sample-timesteps/sec",
                           "n_gpus": comm.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.datapath, "data": "synthetic",
                           "config": {"workload": f"train_step, {args.model}, train_batch_size {args.train_batch_size}/GPU, train_cfg, "
