@@ -7,6 +7,7 @@
 // in registers to the B operand of the second product: for lane half h the 8 k-slots of MFMA step u are the keys
 // 16u + 4h + {0,1,2,3, 8,9,10,11} (exactly the rows that half holds), and the V^T fragment is read with the same map.
 #include "common.h"
+#include <cstdlib>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -404,6 +405,203 @@ __global__ void __launch_bounds__(256, (DVP <= 32 ? 4 : (DKP <= 48 ? 3 : 2))) at
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// LDS-DMA variant of the packed-image kernel (DDPO_ATTN_DMA=1; images whose K part and V part are whole KiB: d = 40, 64).
+// The image of a key tile is already the exact LDS layout, lane-linear — so instead of 16-byte loads into registers one tile ahead
+// and a ds_write_b128 pass behind two barriers, the K part and the V part go global -> LDS directly (buffer_load_dwordx4 ... lds,
+// 1 KiB per wave instruction): no staging registers (32 VGPRs), no LDS write instructions.  Three LDS regions keep three workgroups
+// per CU: K double-buffered (the next tile's K streams in during the whole current tile), V single (requested right after the
+// barrier that retires the previous tile's P V reads, needed only after this tile's score + softmax phase).
+//   per tile t:  wait all, BARRIER 1 (K(t) visible to everybody; everybody is done with V(t-1))
+//                request V(t) -> V region, K(t+1) -> the other K region
+//                S^T = K Q^T, softmax                       (K(t) region)
+//                wait all, BARRIER 2 (V(t) visible)
+//                O^T += V^T P^T                             (V region)
+// Same arithmetic in the same order as attn_fwd_bf16_pk_kernel: bit-identical results.
+// ------------------------------------------------------------------------------------------------
+typedef unsigned int u32x4_a __attribute__((ext_vector_type(4)));
+
+// QB: 32-query blocks per wave.  QB = 2: a workgroup covers 256 queries, every V^T fragment read from LDS feeds the MFMAs of two
+// blocks and half as many workgroups stream the images; the score + softmax phases run one block after the other (their K fragments
+// are re-read: both blocks' score accumulators at once do not fit two waves per SIMD).  Per-query arithmetic and order unchanged.
+template <int D, int DKP, int DVP, int QB>
+__global__ void __launch_bounds__(256, (QB == 2 ? 2 : (DVP <= 32 ? 4 : (DKP <= 48 ? 3 : 2)))) attn_fwd_bf16_dma_kernel(const float* __restrict__ q, int ldq, const uint4* __restrict__ img,
+                                                               float* __restrict__ o, int ldo, float* __restrict__ lse, int heads,
+                                                               int Nq, int Nk, int ntiles, float scale_log2e) {
+  using I = AttnImg<D, DKP, DVP>;
+  constexpr int KT = I::KT, LDK = I::LDK, LDVT = I::LDVT;
+  constexpr int NKS = DKP / 16, NDT = DVP / 32;
+  constexpr int KP = 2 * I::K_BYTES, VP = 2 * I::VT_BYTES;          // K part (hi | lo) and V^T part (hi | lo) of an image
+  static_assert(KP % 1024 == 0 && VP % 1024 == 0, "LDS-DMA moves whole KiB pieces");
+  constexpr int NPK = KP / 1024, NPV = VP / 1024;
+  __shared__ __attribute__((aligned(1024))) char smem[2 * KP + VP];  // [K region 0 | K region 1 | V region]
+
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+  const int wv = __builtin_amdgcn_readfirstlane(wid);
+  const int li = lane & 31, h = lane >> 5;
+  const int bh = blockIdx.y, b = bh / heads, hd = bh - b * heads;
+  const int q0 = blockIdx.x * (128 * QB) + wid * (32 * QB);          // this wave's queries: q0 + 32 * qb + li
+
+  bf16x8 qh[QB][NKS], ql[QB][NKS];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const int qrow = min(q0 + 32 * qb + li, Nq - 1);
+    const float* qp = q + ((int64_t)b * Nq + qrow) * ldq + hd * D;
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) {
+      uint32_t hi[4], lo[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int dk = 16 * s + 8 * h + 2 * e;
+        const float a = dk < D ? qp[dk] * scale_log2e : 0.f;
+        const float c = dk + 1 < D ? qp[dk + 1] * scale_log2e : 0.f;
+        split2(a, c, hi[e], lo[e]);
+      }
+      qh[qb][s] = __builtin_bit_cast(bf16x8, make_uint4(hi[0], hi[1], hi[2], hi[3]));
+      ql[qb][s] = __builtin_bit_cast(bf16x8, make_uint4(lo[0], lo[1], lo[2], lo[3]));
+    }
+  }
+
+  f32x16 oacc[QB][NDT];
+  float m_run[QB], l_run[QB];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    m_run[qb] = -INFINITY; l_run[qb] = 0.f;
+#pragma unroll
+    for (int n = 0; n < NDT; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[qb][n][r] = 0.f;
+  }
+
+  // this (batch, head)'s images as a buffer resource; piece p of a part = 1 KiB = lane-linear 16 bytes per lane
+  const uint64_t base = reinterpret_cast<uint64_t>(img + (int64_t)bh * ntiles * I::CHUNKS);
+  const u32x4_a rs = {(uint32_t)base, (uint32_t)(base >> 32) & 0xFFFFu, 0x7FFFFFFFu, 0x00020000u};
+  const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
+  const uint32_t lane16 = (uint32_t)lane * 16u;
+  auto fill = [&](uint32_t lds_region, uint32_t img_off, int npieces, int tile) {      // wave wv moves pieces wv, wv + 4, ...
+    const uint32_t so = (uint32_t)tile * (uint32_t)I::BYTES + img_off;
+    for (int p = wv; p < npieces; p += 4)
+      asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                   :: "s"(lds0 + lds_region + (uint32_t)p * 1024u), "v"(lane16 + (uint32_t)p * 1024u), "s"(rs), "s"(so) : "memory");
+  };
+
+  fill(0, 0, NPK, 0);                      // K(0) -> K region 0
+  for (int tile = 0; tile < ntiles; ++tile) {
+    const int kt0 = tile * KT;
+    const uint32_t kreg = (tile & 1) ? KP : 0;
+    const char* Khi = smem + kreg; const char* Klo = Khi + I::K_BYTES;
+    const char* Vhi = smem + 2 * KP; const char* Vlo = Vhi + I::VT_BYTES;
+    // K(tile) has landed (requested a whole tile ago) and my P V reads of the previous tile have returned
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    fill(2 * KP, KP, NPV, tile);                                   // V(tile) -> V region (nobody reads V(tile - 1) any more)
+    if (tile + 1 < ntiles) fill((tile & 1) ? 0 : KP, 0, NPK, tile + 1);   // K(tile + 1) -> the other K region
+
+    bf16x8 ph[QB][4], pl[QB][4];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      f32x16 sacc[2];
+  #pragma unroll
+      for (int j = 0; j < 2; ++j)
+  #pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[j][r] = 0.f;
+  #pragma unroll
+      for (int s = 0; s < NKS; ++s) {
+  #pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int off = ((j * 32 + li) * LDK + 16 * s + 8 * h) * 2;
+          const bf16x8 kh = *reinterpret_cast<const bf16x8*>(Khi + off);
+          const bf16x8 kl = *reinterpret_cast<const bf16x8*>(Klo + off);
+          sacc[j] = MFMA32(kl, qh[qb][s], sacc[j]);
+          sacc[j] = MFMA32(kh, ql[qb][s], sacc[j]);
+          sacc[j] = MFMA32(kh, qh[qb][s], sacc[j]);
+        }
+      }
+      if (kt0 + KT > Nk) {                   // only the last tile can hold padded keys (uniform branch)
+  #pragma unroll
+        for (int j = 0; j < 2; ++j)
+  #pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (kt0 + 32 * j + (r & 3) + 8 * (r >> 2) + 4 * h >= Nk) sacc[j][r] = -INFINITY;
+      }
+      float mx = sacc[0][0];
+  #pragma unroll
+      for (int j = 0; j < 2; ++j)
+  #pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[j][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run[qb], mx);
+      const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_new);
+      const bool grew = m_new > m_run[qb];
+      m_run[qb] = m_new;
+      float ls = 0.f;
+  #pragma unroll
+      for (int j = 0; j < 2; ++j) {
+  #pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          uint32_t hi[4], lo[4];
+  #pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float p0 = __builtin_amdgcn_exp2f(sacc[j][8 * half + 2 * e] - m_new);
+            const float p1 = __builtin_amdgcn_exp2f(sacc[j][8 * half + 2 * e + 1] - m_new);
+            ls += p0 + p1;
+            split2(p0, p1, hi[e], lo[e]);
+          }
+          ph[qb][2 * j + half] = __builtin_bit_cast(bf16x8, make_uint4(hi[0], hi[1], hi[2], hi[3]));
+          pl[qb][2 * j + half] = __builtin_bit_cast(bf16x8, make_uint4(lo[0], lo[1], lo[2], lo[3]));
+        }
+      }
+      l_run[qb] = l_run[qb] * alpha + ls;
+      if (__any(grew)) {
+  #pragma unroll
+        for (int n = 0; n < NDT; ++n)
+  #pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[qb][n][r] *= alpha;
+      }
+    }
+    // V(tile) (and K(tile + 1)) have landed; my K fragment reads have returned
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int n = 0; n < NDT; ++n) {
+        const int off = ((32 * n + li) * LDVT + 16 * u + 4 * h) * 2;
+        const uint2 a0 = *reinterpret_cast<const uint2*>(Vhi + off), a1 = *reinterpret_cast<const uint2*>(Vhi + off + 16);
+        const uint2 c0 = *reinterpret_cast<const uint2*>(Vlo + off), c1 = *reinterpret_cast<const uint2*>(Vlo + off + 16);
+        const bf16x8 vh = __builtin_bit_cast(bf16x8, make_uint4(a0.x, a0.y, a1.x, a1.y));
+        const bf16x8 vl = __builtin_bit_cast(bf16x8, make_uint4(c0.x, c0.y, c1.x, c1.y));
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {          // one V^T fragment, QB query blocks
+          oacc[qb][n] = MFMA32(vl, ph[qb][u], oacc[qb][n]);
+          oacc[qb][n] = MFMA32(vh, pl[qb][u], oacc[qb][n]);
+          oacc[qb][n] = MFMA32(vh, ph[qb][u], oacc[qb][n]);
+        }
+      }
+    }
+  }
+
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const int qi = q0 + 32 * qb + li;
+    const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (lse && h == 0 && qi < Nq) lse[(int64_t)bh * Nq + qi] = m_run[qb] + log2f(l_tot);
+    if (qi < Nq) {
+      float* op = o + ((int64_t)b * Nq + qi) * ldo + hd * D;
+#pragma unroll
+      for (int n = 0; n < NDT; ++n) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int dc = 32 * n + 8 * g + 4 * h;
+          if (dc < D) *reinterpret_cast<float4*>(op + dc) =
+              make_float4(oacc[qb][n][4 * g] * inv, oacc[qb][n][4 * g + 1] * inv, oacc[qb][n][4 * g + 2] * inv, oacc[qb][n][4 * g + 3] * inv);
+        }
+      }
+    }
+  }
+}
+
 #define ATTN_PK_MIN_NK 256      /* shorter key sequences (cross-attention over 77 tokens) stay on the self-staging kernel */
 
 template <int D, int DKP, int DVP>
@@ -417,6 +615,22 @@ static int launch_attn_bf16(const float* q, int ldq, const float* k, int ldk, co
     uint4* img = reinterpret_cast<uint4*>(ws);
     hipLaunchKernelGGL((attn_pack_kv_kernel<D, DKP, DVP>), dim3(ntiles, B * heads), dim3(256), 0, st, k, ldk, v, ldv, img, heads, Nk, ntiles);
     DDPO_LAUNCH_CHECK();
+    // DDPO_ATTN_DMA: 1 (default) = LDS-DMA image streaming (1.50 -> 1.42 ms on 4096^2, d = 40, batch 16: profiles/r02_probe_attn_dma.log);
+    // 0 = the register-staged kernel; 2 = DMA + two query blocks per wave (1.40 ms, but 256 VGPRs with a few spilled: not the default)
+    static const int dma_mode = [] { const char* e = getenv("DDPO_ATTN_DMA"); return e ? atoi(e) : 1; }();
+    if constexpr ((2 * I::K_BYTES) % 1024 == 0 && (2 * I::VT_BYTES) % 1024 == 0) {
+      if (dma_mode && (int64_t)ntiles * I::BYTES < 0x7FFFFFFF) {
+        // DDPO_ATTN_DMA=2: two query blocks per wave where that still leaves >= 512 workgroups (two per CU)
+        if (dma_mode == 2 && Nq >= 512 && (long)((Nq + 255) / 256) * B * heads >= 512)
+          hipLaunchKernelGGL((attn_fwd_bf16_dma_kernel<D, DKP, DVP, 2>), dim3((Nq + 255) / 256, B * heads), dim3(256), 0, st, q, ldq, img, o, ldo, lse,
+                             heads, Nq, Nk, ntiles, scale * 1.4426950408889634f);
+        else
+          hipLaunchKernelGGL((attn_fwd_bf16_dma_kernel<D, DKP, DVP, 1>), grid, dim3(256), 0, st, q, ldq, img, o, ldo, lse, heads, Nq, Nk, ntiles,
+                             scale * 1.4426950408889634f);
+        DDPO_LAUNCH_CHECK();
+        return DDPO_OK;
+      }
+    }
     hipLaunchKernelGGL((attn_fwd_bf16_pk_kernel<D, DKP, DVP>), grid, dim3(256), 0, st, q, ldq, img, o, ldo, lse, heads, Nq, Nk, ntiles,
                        scale * 1.4426950408889634f);
     DDPO_LAUNCH_CHECK();
