@@ -605,6 +605,44 @@ __global__ void __launch_bounds__(256, (QB == 2 ? 2 : (DVP <= 32 ? 4 : (DKP <= 4
 #define ATTN_PK_MIN_NK 256      /* shorter key sequences (cross-attention over 77 tokens) stay on the self-staging kernel */
 
 template <int D, int DKP, int DVP>
+static int launch_pack_kv(const float* k, int ldk, const float* v, int ldv, uint4* img, int B, int heads, int Nk, hipStream_t st) {
+  using I = AttnImg<D, DKP, DVP>;
+  const int ntiles = (Nk + I::KT - 1) / I::KT;
+  hipLaunchKernelGGL((attn_pack_kv_kernel<D, DKP, DVP>), dim3(ntiles, B * heads), dim3(256), 0, st, k, ldk, v, ldv, img, heads, Nk, ntiles);
+  DDPO_LAUNCH_CHECK();
+  return DDPO_OK;
+}
+
+// attention from pre-packed K / V^T images (one image per 64-key tile and (batch, head))
+template <int D, int DKP, int DVP>
+static int launch_attn_images(const float* q, int ldq, const uint4* img, float* o, int ldo, float* lse, int B, int heads, int Nq, int Nk,
+                              float scale, hipStream_t st) {
+  using I = AttnImg<D, DKP, DVP>;
+  dim3 grid((Nq + 127) / 128, B * heads);
+  const int ntiles = (Nk + I::KT - 1) / I::KT;
+  // DDPO_ATTN_DMA: 1 (default) = LDS-DMA image streaming (1.50 -> 1.42 ms on 4096^2, d = 40, batch 16: profiles/r02_probe_attn_dma.log);
+  // 0 = the register-staged kernel; 2 = DMA + two query blocks per wave (1.40 ms, but 256 VGPRs with a few spilled: not the default)
+  static const int dma_mode = [] { const char* e = getenv("DDPO_ATTN_DMA"); return e ? atoi(e) : 1; }();
+  if constexpr ((2 * I::K_BYTES) % 1024 == 0 && (2 * I::VT_BYTES) % 1024 == 0) {
+    if (dma_mode && (int64_t)ntiles * I::BYTES < 0x7FFFFFFF) {
+      // DDPO_ATTN_DMA=2: two query blocks per wave where that still leaves >= 512 workgroups (two per CU)
+      if (dma_mode == 2 && Nq >= 512 && (long)((Nq + 255) / 256) * B * heads >= 512)
+        hipLaunchKernelGGL((attn_fwd_bf16_dma_kernel<D, DKP, DVP, 2>), dim3((Nq + 255) / 256, B * heads), dim3(256), 0, st, q, ldq, img, o, ldo, lse,
+                           heads, Nq, Nk, ntiles, scale * 1.4426950408889634f);
+      else
+        hipLaunchKernelGGL((attn_fwd_bf16_dma_kernel<D, DKP, DVP, 1>), grid, dim3(256), 0, st, q, ldq, img, o, ldo, lse, heads, Nq, Nk, ntiles,
+                           scale * 1.4426950408889634f);
+      DDPO_LAUNCH_CHECK();
+      return DDPO_OK;
+    }
+  }
+  hipLaunchKernelGGL((attn_fwd_bf16_pk_kernel<D, DKP, DVP>), grid, dim3(256), 0, st, q, ldq, img, o, ldo, lse, heads, Nq, Nk, ntiles,
+                     scale * 1.4426950408889634f);
+  DDPO_LAUNCH_CHECK();
+  return DDPO_OK;
+}
+
+template <int D, int DKP, int DVP>
 static int launch_attn_bf16(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo, float* lse,
                             int B, int heads, int Nq, int Nk, float scale, void* ws, size_t ws_bytes, hipStream_t st) {
   using I = AttnImg<D, DKP, DVP>;
@@ -613,28 +651,9 @@ static int launch_attn_bf16(const float* q, int ldq, const float* k, int ldk, co
   const size_t need = (size_t)B * heads * ntiles * I::BYTES;
   if (Nk >= ATTN_PK_MIN_NK && ws && ws_bytes >= need && !(reinterpret_cast<uintptr_t>(ws) & 15)) {
     uint4* img = reinterpret_cast<uint4*>(ws);
-    hipLaunchKernelGGL((attn_pack_kv_kernel<D, DKP, DVP>), dim3(ntiles, B * heads), dim3(256), 0, st, k, ldk, v, ldv, img, heads, Nk, ntiles);
-    DDPO_LAUNCH_CHECK();
-    // DDPO_ATTN_DMA: 1 (default) = LDS-DMA image streaming (1.50 -> 1.42 ms on 4096^2, d = 40, batch 16: profiles/r02_probe_attn_dma.log);
-    // 0 = the register-staged kernel; 2 = DMA + two query blocks per wave (1.40 ms, but 256 VGPRs with a few spilled: not the default)
-    static const int dma_mode = [] { const char* e = getenv("DDPO_ATTN_DMA"); return e ? atoi(e) : 1; }();
-    if constexpr ((2 * I::K_BYTES) % 1024 == 0 && (2 * I::VT_BYTES) % 1024 == 0) {
-      if (dma_mode && (int64_t)ntiles * I::BYTES < 0x7FFFFFFF) {
-        // DDPO_ATTN_DMA=2: two query blocks per wave where that still leaves >= 512 workgroups (two per CU)
-        if (dma_mode == 2 && Nq >= 512 && (long)((Nq + 255) / 256) * B * heads >= 512)
-          hipLaunchKernelGGL((attn_fwd_bf16_dma_kernel<D, DKP, DVP, 2>), dim3((Nq + 255) / 256, B * heads), dim3(256), 0, st, q, ldq, img, o, ldo, lse,
-                             heads, Nq, Nk, ntiles, scale * 1.4426950408889634f);
-        else
-          hipLaunchKernelGGL((attn_fwd_bf16_dma_kernel<D, DKP, DVP, 1>), grid, dim3(256), 0, st, q, ldq, img, o, ldo, lse, heads, Nq, Nk, ntiles,
-                             scale * 1.4426950408889634f);
-        DDPO_LAUNCH_CHECK();
-        return DDPO_OK;
-      }
-    }
-    hipLaunchKernelGGL((attn_fwd_bf16_pk_kernel<D, DKP, DVP>), grid, dim3(256), 0, st, q, ldq, img, o, ldo, lse, heads, Nq, Nk, ntiles,
-                       scale * 1.4426950408889634f);
-    DDPO_LAUNCH_CHECK();
-    return DDPO_OK;
+    const int rc = launch_pack_kv<D, DKP, DVP>(k, ldk, v, ldv, img, B, heads, Nk, st);
+    if (rc != DDPO_OK) return rc;
+    return launch_attn_images<D, DKP, DVP>(q, ldq, img, o, ldo, lse, B, heads, Nq, Nk, scale, st);
   }
   hipLaunchKernelGGL((attn_fwd_bf16_kernel<D, DKP, DVP>), grid, dim3(256), 0, st, q, ldq, k, ldk, v, ldv, o, ldo, lse, heads, Nq, Nk,
                      scale * 1.4426950408889634f);
@@ -643,10 +662,14 @@ static int launch_attn_bf16(const float* q, int ldq, const float* k, int ldk, co
 }
 
 template <int D, int DKP, int DVP>
-static size_t attn_ws(int B, int heads, int Nk) {
+static size_t attn_img_bytes(int B, int heads, int Nk) {
   using I = AttnImg<D, DKP, DVP>;
-  if (Nk < ATTN_PK_MIN_NK) return 0;
   return (size_t)B * heads * ((Nk + I::KT - 1) / I::KT) * I::BYTES;
+}
+template <int D, int DKP, int DVP>
+static size_t attn_ws(int B, int heads, int Nk) {
+  if (Nk < ATTN_PK_MIN_NK) return 0;
+  return attn_img_bytes<D, DKP, DVP>(B, heads, Nk);
 }
 
 extern "C" size_t ddpo_attention_fwd_bf16x3_ws_bytes(int B, int heads, int Nk, int d) {
@@ -676,5 +699,58 @@ extern "C" int ddpo_attention_fwd_bf16x3(const float* q, int ldq, const float* k
     case 64: return launch_attn_bf16<64, 64, 64>(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, heads, Nq, Nk, scale, ws, ws_bytes, st);
     case 80: return launch_attn_bf16<80, 80, 96>(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, heads, Nq, Nk, scale, ws, ws_bytes, st);
     default: return DDPO_EINVAL;      // other head dims stay on the exact-fp32 kernel
+  }
+}
+
+/* K / V of a (batch, head) set packed ONCE into the per-64-key-tile LDS images the attention kernels stream (any Nk), for callers whose
+ * keys / values are constant over many attention calls — the text context of the cross-attention layers over the 50 DDIM steps of a
+ * sampling call.  ddpo_attention_kv_images_bytes gives the image size; ddpo_attention_fwd_bf16x3_images runs the attention from them
+ * (same kernels as ddpo_attention_fwd_bf16x3 with a workspace: identical results). */
+extern "C" size_t ddpo_attention_kv_images_bytes(int B, int heads, int Nk, int d) {
+  if (B <= 0 || heads <= 0 || Nk <= 0) return 0;
+  switch (d) {
+    case 8:  return attn_img_bytes<8, 16, 32>(B, heads, Nk);
+    case 16: return attn_img_bytes<16, 16, 32>(B, heads, Nk);
+    case 40: return attn_img_bytes<40, 48, 64>(B, heads, Nk);
+    case 64: return attn_img_bytes<64, 64, 64>(B, heads, Nk);
+    case 80: return attn_img_bytes<80, 80, 96>(B, heads, Nk);
+    default: return 0;
+  }
+}
+
+extern "C" int ddpo_attention_pack_kv_bf16x3(const float* k, int ldk, const float* v, int ldv, void* images, size_t images_bytes, int B, int heads,
+                                             int Nk, int d, void* stream) {
+  if (!k || !v || !images || B <= 0 || heads <= 0 || Nk <= 0 || (ldk & 3) || (ldv & 3) || (long)B * heads > 65535) return DDPO_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(images)) & 15) return DDPO_EINVAL;
+  const size_t need = ddpo_attention_kv_images_bytes(B, heads, Nk, d);
+  if (need == 0 || images_bytes < need) return DDPO_EINVAL;
+  hipStream_t st = as_stream(stream);
+  uint4* img = reinterpret_cast<uint4*>(images);
+  switch (d) {
+    case 8:  return launch_pack_kv<8, 16, 32>(k, ldk, v, ldv, img, B, heads, Nk, st);
+    case 16: return launch_pack_kv<16, 16, 32>(k, ldk, v, ldv, img, B, heads, Nk, st);
+    case 40: return launch_pack_kv<40, 48, 64>(k, ldk, v, ldv, img, B, heads, Nk, st);
+    case 64: return launch_pack_kv<64, 64, 64>(k, ldk, v, ldv, img, B, heads, Nk, st);
+    case 80: return launch_pack_kv<80, 80, 96>(k, ldk, v, ldv, img, B, heads, Nk, st);
+    default: return DDPO_EINVAL;
+  }
+}
+
+extern "C" int ddpo_attention_fwd_bf16x3_images(const float* q, int ldq, const void* images, size_t images_bytes, float* o, int ldo, float* lse,
+                                                int B, int heads, int Nq, int Nk, int d, float scale, void* stream) {
+  if (!q || !images || !o || B <= 0 || heads <= 0 || Nq <= 0 || Nk <= 0) return DDPO_EINVAL;
+  if ((ldq & 3) || (ldo & 3) || (long)B * heads > 65535) return DDPO_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(images) | reinterpret_cast<uintptr_t>(o)) & 15) return DDPO_EINVAL;
+  const size_t need = ddpo_attention_kv_images_bytes(B, heads, Nk, d);
+  if (need == 0 || images_bytes < need) return DDPO_EINVAL;
+  hipStream_t st = as_stream(stream);
+  const uint4* img = reinterpret_cast<const uint4*>(images);
+  switch (d) {
+    case 8:  return launch_attn_images<8, 16, 32>(q, ldq, img, o, ldo, lse, B, heads, Nq, Nk, scale, st);
+    case 16: return launch_attn_images<16, 16, 32>(q, ldq, img, o, ldo, lse, B, heads, Nq, Nk, scale, st);
+    case 40: return launch_attn_images<40, 48, 64>(q, ldq, img, o, ldo, lse, B, heads, Nq, Nk, scale, st);
+    case 64: return launch_attn_images<64, 64, 64>(q, ldq, img, o, ldo, lse, B, heads, Nq, Nk, scale, st);
+    case 80: return launch_attn_images<80, 80, 96>(q, ldq, img, o, ldo, lse, B, heads, Nq, Nk, scale, st);
+    default: return DDPO_EINVAL;
   }
 }

@@ -74,6 +74,10 @@ _SIGS = {
     "ddpo_pack_weights_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ddpo_attention_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int,
                                    c_int, c_int, c_int, c_float, c_void_p]),
+    "ddpo_attention_kv_images_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "ddpo_attention_pack_kv_bf16x3": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_void_p]),
+    "ddpo_attention_fwd_bf16x3_images": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                                 c_float, c_void_p]),
     "ddpo_attention_fwd_bf16x3": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int,
                                           c_int, c_int, c_int, c_float, c_void_p, c_size_t, c_void_p]),
     "ddpo_attention_fwd_bf16x3_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
@@ -611,6 +615,33 @@ def attention(q, k, v, B, heads, Nq, Nk, d, scale=None, out=None, ldq=None, ldk=
     else:
         _check(load().ddpo_attention_fwd(_p(q), int(ldq or C), _p(k), int(ldk or C), _p(v), int(ldv or C), _p(out), int(ldo or C),
                                          _p(lse), B, heads, Nq, Nk, d, sc, _stream()), "ddpo_attention_fwd")
+    return (out, lse) if return_lse else out
+
+
+def attention_kv_images(k, v, B, heads, Nk, d, out=None, ldk=None, ldv=None):
+    """Pack K / V (B*Nk, heads*d) once into the per-tile images of the bf16x3 attention kernels (uint8 tensor), for keys / values that
+    stay constant over many attention calls (the text context over the DDIM steps).  Returns None where the datapath / head dim has no
+    image kernel (the caller keeps k, v)."""
+    if DATAPATH == "fp32" or d not in (8, 16, 40, 64, 80):
+        return None
+    C = heads * d
+    nb = int(load().ddpo_attention_kv_images_bytes(B, heads, Nk, d))
+    if out is None or out.numel() < nb:
+        out = torch.empty(nb, dtype=torch.uint8, device=k.device)
+    _check(load().ddpo_attention_pack_kv_bf16x3(_p(k), int(ldk or C), _p(v), int(ldv or C), _p(out), out.numel(), B, heads, Nk, d, _stream()),
+           "ddpo_attention_pack_kv_bf16x3")
+    return out
+
+
+def attention_from_images(q, images, B, heads, Nq, Nk, d, scale=None, out=None, ldq=None, ldo=None, return_lse=False):
+    """softmax(q k^T * scale) v with k, v given as attention_kv_images()."""
+    C = heads * d
+    if out is None:
+        out = torch.empty(B * Nq, C, dtype=torch.float32, device=q.device)
+    lse = torch.empty(B * heads * Nq, dtype=torch.float32, device=q.device) if return_lse else None
+    sc = float(scale if scale is not None else d ** -0.5)
+    _check(load().ddpo_attention_fwd_bf16x3_images(_p(q), int(ldq or C), _p(images), images.numel(), _p(out), int(ldo or C), _p(lse), B, heads,
+                                                   Nq, Nk, d, sc, _stream()), "ddpo_attention_fwd_bf16x3_images")
     return (out, lse) if return_lse else out
 
 

@@ -13,6 +13,8 @@ from collections import OrderedDict
 from dataclasses import dataclass
 from typing import Tuple
 
+import os
+
 import torch
 
 from .. import lib as L
@@ -286,7 +288,9 @@ class UNet2DCondition:
         q = L.linear(x, P[name + ".to_q.kernel"])
         cached = self._ctx_kv.get((name, ctx.shape[0])) if (ctx is not None and rec is None and self._ctx_kv_active) else None
         if cached is not None:                     # text-context K / V were projected once for this sampling call
-            k, v = cached
+            k, v = cached[0], cached[1]
+            if len(cached) > 2 and cached[2] is not None:      # ... and packed once into the attention kernels' K / V^T images
+                return L.attention_from_images(q, cached[2], B, heads, N, ctx_len, C // heads)
         else:
             kv_src = x if ctx is None else ctx
             k = L.linear(kv_src, P[name + ".to_k.kernel"])
@@ -524,16 +528,33 @@ class UNet2DCondition:
         for name in self.cross_attention_names():
             wk, wv = self.params[name + ".to_k.kernel"], self.params[name + ".to_v.kernel"]
             ent = self._ctx_kv.get((name, B * Lc))
+            heads = self._heads_of(name)
             if ent is None:
-                ent = (torch.empty(B * Lc, wk.shape[1], dtype=torch.float32, device=self.device),
-                       torch.empty(B * Lc, wv.shape[1], dtype=torch.float32, device=self.device))
+                kbuf = torch.empty(B * Lc, wk.shape[1], dtype=torch.float32, device=self.device)
+                vbuf = torch.empty(B * Lc, wv.shape[1], dtype=torch.float32, device=self.device)
+                nb = 0
+                if L.DATAPATH != "fp32" and (wk.shape[1] // heads) in (8, 16, 40, 64, 80) and os.environ.get("DDPO_CTX_IMAGES", "1") != "0":
+                    nb = int(L.load().ddpo_attention_kv_images_bytes(B, heads, Lc, wk.shape[1] // heads))
+                ent = (kbuf, vbuf, torch.empty(nb, dtype=torch.uint8, device=self.device) if nb else None)
                 self._ctx_kv[(name, B * Lc)] = ent
             L.linear(ctx, wk, out=ent[0])
             L.linear(ctx, wv, out=ent[1])
+            if ent[2] is not None:                 # the cross-attention of all T steps streams these images: no per-step split / transpose of K, V
+                L.attention_kv_images(ent[0], ent[1], B, heads, Lc, wk.shape[1] // heads, out=ent[2])
         self._ctx_kv_active = True
 
     def release_context(self):
         self._ctx_kv_active = False
+
+    def _heads_of(self, attn_name):
+        """Number of heads of the attention layer `attn_name` (…down_blocks_i / up_blocks_i / mid_block…): cfg.num_heads per level."""
+        cfg = self.cfg
+        nlev = len(cfg.block_out_channels)
+        if attn_name.startswith("down_blocks_"):
+            return cfg.num_heads[int(attn_name.split("_")[2].split(".")[0])]
+        if attn_name.startswith("up_blocks_"):
+            return cfg.num_heads[nlev - 1 - int(attn_name.split("_")[2].split(".")[0])]
+        return cfg.num_heads[-1]
 
     # -------------------------------------------------------------------------------- time-projection table (sampling)
     def time_proj_names(self):

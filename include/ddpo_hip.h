@@ -221,6 +221,15 @@ int ddpo_attention_fwd(const float* q, int ldq, const float* k, int ldk, const f
  * transposed once per (batch, head) into per-tile LDS images that the attention kernel streams; without it (or for
  * short key sequences, where the size query returns 0) every query tile stages K / V itself.  Results are identical. */
 size_t ddpo_attention_fwd_bf16x3_ws_bytes(int B, int heads, int Nk, int d);
+/* For keys / values that stay constant over many attention calls (the text context of the cross-attention layers over the DDIM
+ * steps of a sampling call, /root/reference/ddpo/diffusers_patch/pipeline_flax_stable_diffusion.py:219-224 re-projects and
+ * re-reads it every step): pack K / V ONCE into the per-tile images (any Nk, `images` 16-byte aligned, >=
+ * ddpo_attention_kv_images_bytes) and run every attention from them.  Same kernels as above: identical results. */
+size_t ddpo_attention_kv_images_bytes(int B, int heads, int Nk, int d);
+int ddpo_attention_pack_kv_bf16x3(const float* k, int ldk, const float* v, int ldv, void* images, size_t images_bytes,
+                                  int B, int heads, int Nk, int d, void* stream);
+int ddpo_attention_fwd_bf16x3_images(const float* q, int ldq, const void* images, size_t images_bytes, float* o, int ldo,
+                                     float* lse, int B, int heads, int Nq, int Nk, int d, float scale, void* stream);
 int ddpo_attention_fwd_bf16x3(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
                               float* o, int ldo, float* lse, int B, int heads, int Nq, int Nk, int d, float scale,
                               void* ws, size_t ws_bytes, void* stream);

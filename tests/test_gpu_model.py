@@ -5,6 +5,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+from ddpo_amd import lib as L
 from ddpo_amd.models.unet import UNet2DCondition, UNetConfig
 from ddpo_amd.models.vae import VAEDecoder, VAEConfig
 from ddpo_amd.diffusers_patch.scheduling_ddim import DDIMScheduler
@@ -120,6 +121,37 @@ def test_time_projection_table_is_bit_identical_to_per_step_time_path(tiny, monk
     unet.precompute_timesteps([981, 21, 501])
     unet.release_timesteps()
     assert torch.equal(unet(x, t, c), y0)
+
+
+def test_context_kv_images_are_bit_identical_to_per_step_staging(monkeypatch):
+    """precompute_context also packs the text K / V once into the attention kernels' per-tile images; every cross-attention of the
+    sampling call then runs from them (ddpo_attention_fwd_bf16x3_images) instead of splitting / transposing K and V in every query tile
+    of every step.  Same kernels' arithmetic: the U-Net output must not change by a bit (bf16x3 datapath; fp32 keeps k, v).
+    Own model instance (head dim 16 at every level): the module fixture's captured graphs must keep their context buffers."""
+    monkeypatch.setattr(L, "DATAPATH", "bf16x3")
+    unet = UNet2DCondition(UNetConfig.named("tiny21"), DEV)
+    unet.params.init_synthetic(3)
+    unet.params.pack_bf16()
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(4, 4, 8, 8, generator=g).to(DEV)
+    t = torch.tensor([481, 481, 481, 481], dtype=torch.int32, device=DEV)
+    c = torch.randn(4, 77, 96, generator=g).to(DEV)
+    y0 = unet(x, t, c).clone()
+    unet.precompute_context(c)
+    try:
+        assert unet._ctx_kv and all(ent[2] is not None for ent in unet._ctx_kv.values())
+        y1 = unet(x, t, c).clone()
+    finally:
+        unet.release_context()
+    monkeypatch.setenv("DDPO_CTX_IMAGES", "0")
+    unet._ctx_kv.clear()
+    unet.precompute_context(c)
+    try:
+        assert all(ent[2] is None for ent in unet._ctx_kv.values())
+        y2 = unet(x, t, c).clone()
+    finally:
+        unet.release_context()
+    assert torch.equal(y0, y1) and torch.equal(y0, y2)
 
 
 def test_graph_replay_survives_a_change_of_sampling_geometry(tiny):
