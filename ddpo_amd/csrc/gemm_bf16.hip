@@ -320,6 +320,7 @@ __global__ void __launch_bounds__(BF_THREADS) gemm_conv_bf16_kernel(const ddpo_g
 // 1 branch per MFMA on those; here the only VALU work left in the k-loop is the fp32 -> bf16 hi/lo split).
 // ------------------------------------------------------------------------------------------------
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #define BUF_OOB 0x80000000u
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
@@ -1384,7 +1385,14 @@ __device__ __forceinline__ bf16x8 lds_frag(const uint32_t* base, int row, int dw
 // looked like its bound (measured in round 2: +0.5 % on the train step, so it is not).  Same values reach the MFMAs as in the fp32-fed form.
 // Also measured and rejected in round 2: unconditional loads + a second register stage (two k-tiles of prefetch): 256 VGPRs with
 // 12-24 spilled at two waves per SIMD, train step 9 % SLOWER (profiles/r02_ab_wgrad_deep.log).
-template <bool APLN, bool BPLN>
+// ROWL ("row loader", round 2): the SQ counters of the loader below showed ~10 VALU + 4 SALU per MFMA at 31 % MFMA-pipe busy: 16 bytes per
+// fetch, ~25 VALU per fetch of 64-bit address arithmetic, per-pixel (batch, y, x) bookkeeping with loops and divergent branches around every
+// load.  For the regular layers (dense, or stride-1 "same" convolutions whose rows tile into the 32-pixel k-tiles: OW % 32 == 0 or
+// 32 % OW == 0; M % 32 == 0; operand tensors < 2 GiB) all of that collapses: a k-tile is 32 consecutive pixels starting at an image-row
+// boundary that is the SAME for the whole workgroup, so (oy, ox) of the tile live in scalars, every thread's four byte offsets relative
+// to the tile are CONSTANTS, the per-tile advance is one scalar soffset, and a masked element is an out-of-range buffer offset that reads
+// zeros (raw buffer loads) — ~6 VALU per activation fetch, none per dY fetch, no branches.
+template <bool APLN, bool BPLN, bool ROWL = false>
 __global__ void __launch_bounds__(BF_THREADS) gemm_wgrad_bf16_kernel(const ddpo_gemm_desc d, int tiles_n, int m_per_split,
                                                                    const uint16_t* __restrict__ a_hi, const uint16_t* __restrict__ a_lo,
                                                                    const uint16_t* __restrict__ b_hi, const uint16_t* __restrict__ b_lo) {
@@ -1436,7 +1444,73 @@ __global__ void __launch_bounds__(BF_THREADS) gemm_wgrad_bf16_kernel(const ddpo_
   auto as_f4 = [](const uint2 h, const uint2 l) {
     return make_float4(__uint_as_float(h.x), __uint_as_float(h.y), __uint_as_float(l.x), __uint_as_float(l.y));
   };
-  auto load_tile = [&](int kt) {
+  // ---- ROWL state (see the note above the kernel)
+  constexpr uint32_t ESA = APLN ? 2u : 4u, ESB = BPLN ? 2u : 4u;     // bytes per element of the operands as stored
+  uint32_t rl_va[2][2], rl_vb[2][2];   // byte offsets of this thread's elements for k-tile 0 (BUF_OOB: never valid)
+  int rl_cy[2][2], rl_cx[2][2];        // iy = oy_t + cy, ix = ox_t + cx of the element's tap
+  int rl_oy = 0, rl_ox = 0;            // image row / column of the CURRENT k-tile's first pixel (uniform)
+  // a tap above / left of the tile has a NEGATIVE offset relative to its pixel: the activation descriptors start `rl_guard` bytes in front of
+  // the tensor so that every offset is non-negative (such elements are only ever fetched when their tap is inside the image, i.e. in range)
+  const int64_t rl_guard = conv ? (int64_t)(d.W + 1) * d.ld_src * (int64_t)ESA : 0;
+  __amdgpu_buffer_rsrc_t rl_ra0 = make_rsrc(reinterpret_cast<const char*>(APLN ? (const void*)a_hi : (const void*)d.src) - rl_guard),
+                         rl_ra1 = make_rsrc(reinterpret_cast<const char*>(APLN ? (const void*)a_lo : (const void*)d.src) - rl_guard);
+  __amdgpu_buffer_rsrc_t rl_rb0 = make_rsrc(BPLN ? (const void*)b_hi : (const void*)d.w), rl_rb1 = make_rsrc(BPLN ? (const void*)b_lo : (const void*)d.w);
+  if constexpr (ROWL) {
+    const int rem = conv ? m_begin % (d.OH * d.OW) : 0;
+    rl_oy = conv ? rem / d.OW : 0;
+    rl_ox = conv ? rem - rl_oy * d.OW : 0;
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int eoff = 16 * p + 2 * pp + e;
+        const int dy_e = (conv && d.OW < BK) ? eoff / d.OW : 0;
+        const int x_e = (conv && d.OW < BK) ? eoff - dy_e * d.OW : eoff;
+        rl_cy[p][e] = dy_e + dky;
+        rl_cx[p][e] = x_e + dkx;
+        const int64_t ao = ((int64_t)(m_begin + eoff) * d.ld_src + tap_off) * (int64_t)ESA + rl_guard;
+        const int64_t bo = ((int64_t)(m_begin + eoff) * d.ld_w + ng) * (int64_t)ESB;
+        rl_va[p][e] = (kvalid && ao >= 0 && ao < 0x7FFFFFF0ll) ? (uint32_t)ao : BUF_OOB;
+        rl_vb[p][e] = (nvalid && bo >= 0 && bo < 0x7FFFFFF0ll) ? (uint32_t)bo : BUF_OOB;
+      }
+  }
+  auto load_tile_rows = [&](int kt) {
+    const uint32_t so_a = (uint32_t)kt * (uint32_t)(BK * d.ld_src) * ESA, so_b = (uint32_t)kt * (uint32_t)(BK * d.ld_w) * ESB;
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        uint32_t voa = rl_va[p][e];
+        if (conv) {
+          const bool ok = (unsigned)(rl_oy + rl_cy[p][e]) < (unsigned)d.H && (unsigned)(rl_ox + rl_cx[p][e]) < (unsigned)d.W;
+          voa = ok ? voa : BUF_OOB;
+        }
+        if (APLN) {
+          const u32x2 h2 = __builtin_amdgcn_raw_buffer_load_b64(rl_ra0, voa, so_a, 0), l2 = __builtin_amdgcn_raw_buffer_load_b64(rl_ra1, voa, so_a, 0);
+          ra[p][e] = make_float4(__uint_as_float(h2.x), __uint_as_float(h2.y), __uint_as_float(l2.x), __uint_as_float(l2.y));
+        } else {
+          const u32x4 v4 = __builtin_amdgcn_raw_buffer_load_b128(rl_ra0, voa, so_a, 0);
+          ra[p][e] = make_float4(__uint_as_float(v4.x), __uint_as_float(v4.y), __uint_as_float(v4.z), __uint_as_float(v4.w));
+        }
+        if (BPLN) {
+          const u32x2 h2 = __builtin_amdgcn_raw_buffer_load_b64(rl_rb0, rl_vb[p][e], so_b, 0), l2 = __builtin_amdgcn_raw_buffer_load_b64(rl_rb1, rl_vb[p][e], so_b, 0);
+          rb[p][e] = make_float4(__uint_as_float(h2.x), __uint_as_float(h2.y), __uint_as_float(l2.x), __uint_as_float(l2.y));
+        } else {
+          const u32x4 v4 = __builtin_amdgcn_raw_buffer_load_b128(rl_rb0, rl_vb[p][e], so_b, 0);
+          rb[p][e] = make_float4(__uint_as_float(v4.x), __uint_as_float(v4.y), __uint_as_float(v4.z), __uint_as_float(v4.w));
+        }
+      }
+    if (conv) {                           // next k-tile: 32 pixels on (uniform)
+      if (d.OW >= BK) {
+        rl_ox += BK;
+        if (rl_ox >= d.OW) { rl_ox = 0; rl_oy = rl_oy + 1 >= d.OH ? 0 : rl_oy + 1; }
+      } else {
+        rl_oy += BK / d.OW;
+        if (rl_oy >= d.OH) rl_oy -= d.OH;
+      }
+    }
+  };
+  auto load_tile_px = [&](int kt) {
 #pragma unroll
     for (int p = 0; p < 2; ++p)
 #pragma unroll
@@ -1472,6 +1546,9 @@ __global__ void __launch_bounds__(BF_THREADS) gemm_wgrad_bf16_kernel(const ddpo_
           while (poy[p][e] >= d.OH) { poy[p][e] -= d.OH; ++pb[p][e]; }
         }
       }
+  };
+  auto load_tile = [&](int kt) {
+    if constexpr (ROWL) load_tile_rows(kt); else load_tile_px(kt);
   };
   auto store_tile = [&](int buf) {
     uint32_t* st = smem[buf];
@@ -1596,10 +1673,24 @@ static int wgrad_bf16x3(const ddpo_gemm_desc* dp, const uint16_t* a_hi, const ui
   splits = (d.M + mps - 1) / mps;
   hipStream_t st = as_stream(stream);
   const dim3 grid(tiles, splits), blk(BF_THREADS);
-  if (a_hi && b_hi) hipLaunchKernelGGL((gemm_wgrad_bf16_kernel<true, true>), grid, blk, 0, st, d, tiles_n, mps, a_hi, a_lo, b_hi, b_lo);
-  else if (a_hi) hipLaunchKernelGGL((gemm_wgrad_bf16_kernel<true, false>), grid, blk, 0, st, d, tiles_n, mps, a_hi, a_lo, b_hi, b_lo);
-  else if (b_hi) hipLaunchKernelGGL((gemm_wgrad_bf16_kernel<false, true>), grid, blk, 0, st, d, tiles_n, mps, a_hi, a_lo, b_hi, b_lo);
-  else hipLaunchKernelGGL((gemm_wgrad_bf16_kernel<false, false>), grid, blk, 0, st, d, tiles_n, mps, a_hi, a_lo, b_hi, b_lo);
+  // row loader for the regular layers (default; DDPO_WGRAD_ROWS=0 = always the per-pixel loader): conv 320->320 @ 64^2, U-Net batch 64:
+  // 2.54 -> 2.05 ms (190 -> 236 TF), profiles/r02_ab_wgrad_rows.log
+  static const int rows_mode = [] { const char* e = getenv("DDPO_WGRAD_ROWS"); return e ? atoi(e) : 1; }();
+  const bool conv_ = d.ksize > 0;
+  const bool simple_ = !conv_ || (d.stride == 1 && d.upsample == 0 && d.OH == d.H && d.OW == d.W);
+  const int64_t a_bytes = (int64_t)d.M * d.ld_src * (a_hi ? 2 : 4), b_bytes = (int64_t)d.M * d.ld_w * (b_hi ? 2 : 4);
+  const bool rows_ok = rows_mode && simple_ && (d.M % 32) == 0 && a_bytes + (conv_ ? (int64_t)(d.W + 1) * d.ld_src * 4 : 0) < 0x7FFFFFF0ll && b_bytes < 0x7FFFFFF0ll &&
+                       (!conv_ || (((d.OW % 32) == 0 || (32 % d.OW) == 0) && ((d.OH * d.OW) % 32) == 0));
+#define WG_LAUNCH(A, B)                                                                                                                        \
+  do {                                                                                                                                         \
+    if (rows_ok) hipLaunchKernelGGL((gemm_wgrad_bf16_kernel<A, B, true>), grid, blk, 0, st, d, tiles_n, mps, a_hi, a_lo, b_hi, b_lo);          \
+    else hipLaunchKernelGGL((gemm_wgrad_bf16_kernel<A, B, false>), grid, blk, 0, st, d, tiles_n, mps, a_hi, a_lo, b_hi, b_lo);                 \
+  } while (0)
+  if (a_hi && b_hi) WG_LAUNCH(true, true);
+  else if (a_hi) WG_LAUNCH(true, false);
+  else if (b_hi) WG_LAUNCH(false, true);
+  else WG_LAUNCH(false, false);
+#undef WG_LAUNCH
   DDPO_LAUNCH_CHECK();
   return DDPO_OK;
 }
