@@ -119,11 +119,12 @@ DATAPATH = os.environ.get("DDPO_DATAPATH", "fp32")
 SPLITK_WS_BYTES = 64 << 20       # scratch for the deterministic split-K of under-filled launches
 PACKED = {}          # data_ptr of an fp32 weight tensor -> dict(fwd=(hi, lo, Kp), bwd=(hi, lo) | None, K, N)
 
-# Plane-fed GEMMs (bf16x3 datapath, inference / sampling forward only): GroupNorm / LayerNorm write their result as bf16
+# Plane-fed GEMMs (bf16x3 datapath): GroupNorm / LayerNorm write their result as bf16
 # hi / lo planes and the consuming conv / linear layers fetch both operands by LDS-DMA (ddpo_gemm_conv_fwd_bf16_planes).
 # Bit-identical to the fp32-fed kernels (tests/test_gpu_planes.py).  ON by default since round 2 (DDPO_PLANES=0 switches it
 # off): on one box, back to back, the sampling bench went 3.222 / 3.243 (off) -> 3.268 (k-loop mode 6) -> 3.297 (mode 7, three
-# weight stages) -> 3.344 images/s (mode 7 + 256x320 tiles at the 64x64 level), profiles/r02_planes_ab.md.
+# weight stages) -> 3.344 images/s (mode 7 + 256x320 tiles at the 64x64 level) — measured in the first session of round 2, whose log was
+# lost with its container; the per-layer A/B of the final state is profiles/r02_gemm_breakdown_ab.md, the k-loop mode A/B profiles/r02_ab_apl_mode.log.
 PLANES = os.environ.get("DDPO_PLANES", "1") == "1"
 # The TRAINING forward writes its GroupNorm / LayerNorm results as planes too (they are consumed only by the layer's GEMM and by
 # its weight gradient, ddpo_gemm_conv_wgrad_bf16x3_planes): plane-fed forward GEMMs and no activation split in the wgrad loader.
