@@ -202,3 +202,34 @@ def test_aesthetic_reward_refuses_to_score_without_weights(monkeypatch, tmp_path
     assert laion.find_weights(None, str(tmp_path / "cache"))[1] == str(tmp_path / "cache" / laion.MLP_FILE)
     (tmp_path / "w" / "clip").mkdir(parents=True)
     assert laion.find_weights(str(tmp_path / "w"), str(tmp_path / "cache"))[0] == str(tmp_path / "w" / "clip")
+
+
+def test_planes_pay_rule_and_bench_train_fuse_default(monkeypatch):
+    """Host-side speed rules of round 2: a layer is plane-fed only where the plane-fed kernel is the faster one in the model (long
+    reductions, or >= 32768 rows), and bench.py's --train-fuse follows the entrypoint's geometry rule unless given."""
+    import torch
+    from ddpo_amd import lib as L
+    monkeypatch.setattr(L, "PLANES", True)
+    monkeypatch.setattr(L, "PLANES_ALL", False)
+    monkeypatch.setattr(L, "DATAPATH", "bf16x3")
+    mk = lambda K, N: torch.zeros(1)
+    entries = {}
+    def reg(K, N):
+        w = torch.zeros(1)
+        entries[w.data_ptr()] = dict(fwd=(None, None, K), bwd=None, K=K, N=N)
+        return w
+    monkeypatch.setattr(L, "PACKED", entries)
+    conv = reg(2880, 320)          # 3x3 conv 320 -> 320: long reduction
+    lin0 = reg(320, 320)           # 64x64-level projection
+    lin2 = reg(1280, 1280)         # 16x16-level projection
+    ff2 = reg(5120, 1280)          # FF2 at the 16x16 level
+    assert L.planes_pay(conv, 320, 4096) and L.planes_pay(ff2, 5120, 4096)
+    assert L.planes_pay(lin0, 320, 65536) and not L.planes_pay(lin0, 320, 16384)
+    assert not L.planes_pay(lin2, 1280, 4096)
+    monkeypatch.setattr(L, "PLANES_ALL", True)
+    assert L.planes_pay(lin2, 1280, 4096)                     # DDPO_PLANES_ALL=1: every eligible layer
+    assert not L.planes_pay(reg(40, 64), 40, 4096)            # never where the plane-fed kernel cannot run (K % 32 != 0)
+    monkeypatch.delenv("DDPO_TRAIN_FUSE", raising=False)
+    import bench
+    assert bench.parse([]).train_fuse == 16 and bench.parse(["--model", "sd21"]).train_fuse == 7
+    assert bench.parse(["--train-fuse", "10"]).train_fuse == 10
