@@ -176,3 +176,19 @@ def test_mode_validation(monkeypatch):
     assert d.seed_process_index == 0 and d.n_key_devices == 8
     d = dp.DataParallel(mode="multi_host", rank=3, world=8)
     assert d.seed_process_index == 3 and d.n_key_devices == 1
+
+
+@pytest.mark.parametrize("world,nb,sbs", [(4, 3, 2), (8, 1, 8), (2, 2, 4), (8, 2, 1)])
+def test_global_order_turns_rank_major_gather_into_the_one_process_order(world, nb, sbs):
+    """all_gather concatenates [rank][batch][sample]; the one-process run holds [batch][device][sample] (each sample batch is unsharded,
+    then the batches are concatenated).  Pure index check for larger worlds than the gloo test spawns."""
+    from ddpo_amd.training.dp import DataParallel
+    gid = lambda b, d, i: (b * world + d) * sbs + i                       # id of sample i of device d in sample batch b, one-process order
+    gathered = np.array([gid(b, d, i) for d in range(world) for b in range(nb) for i in range(sbs)])      # what all_gather returns
+    order = DataParallel(mode="single_host", rank=0, world=world)._global_order(nb, sbs)
+    assert np.array_equal(gathered[order], np.arange(world * nb * sbs))
+    # and every device's training rows partition the shuffled global batch
+    tb = 1
+    total = world * nb * sbs
+    rows = [np.arange(total).reshape(-1, world, tb)[:, d].reshape(-1) for d in range(world)]
+    assert np.array_equal(np.sort(np.concatenate(rows)), np.arange(total))
