@@ -336,6 +336,103 @@ def measure_train(args, comm, L, unet, sched, state, emb, neg, steps, warmup):
                                                  "note": "end-to-end: 6 x U-Net-forward algorithmic FLOPs per sample-timestep (2 fwd + 2 bwd) / wall time, per GPU"}}
 
 
+HBM_PEAK_GBPS = 8000.0                                 # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (about 6.3 TB/s achievable)
+
+
+def measure_hbm_kernels(args, comm, L, ucfg, sched, state, unet):
+    """Event-timed launches of the HBM-bound kernels of SURVEY.md §8(d) at the bench geometry, with §8(d)'s ALGORITHMIC bytes per unit:
+    DDIM step 4 x 4*C*h*w B per sample-step (256 KiB at 64x64), PPO fwd+bwd 10 x 4*C*h*w (640 KiB), gradient norm 4 B/param,
+    AdamW(bf16 mu) 24 B/param.  achieved = algorithmic bytes / average launch duration (HIP events on the launch stream)."""
+    dev = comm.dev
+    hw = args.resolution // 8
+    chw = 4 * hw * hw
+    st = sched.set_timesteps(state, args.n_inference_steps)
+    consts = sched.kernel_consts(st, 1.0)
+    out = {}
+
+    def timed(fn, reps, warm=2):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / reps
+
+    def row(name, unit_bytes, units, dt, note):
+        gbps = unit_bytes * units / dt / 1e9
+        out[name] = {"bound": "hbm", "algorithmic_bytes_per_unit": unit_bytes, "units_per_launch": units, "avg_launch_us": dt * 1e6,
+                     "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS, "note": note}
+
+    g = torch.Generator().manual_seed(9)
+    B = args.sample_batch_size
+    mk = lambda n: torch.randn(n, 4, hw, hw, generator=g).to(dev)
+    eu, ec, x, z = mk(B), mk(B), mk(B), mk(B)
+    ts = torch.full((B,), 481, dtype=torch.int32, device=dev)
+    xn, lp = torch.empty_like(x), torch.empty(B, device=dev)
+    dt = timed(lambda: L.ddim_step_fwd(eu, ec, x, z, ts, 5.0, consts, x_next=xn, logp=lp), 200)
+    row("ddim_step", 4 * 4 * chw, B, dt, f"{B} samples per launch = {B * 16 * chw / 2**20:.1f} MiB: launch-latency-bound by construction (one workgroup per "
+        f"sample); the kernel also reads the pre-drawn Threefry noise (5 passes of {4 * chw // 1024} KiB in all)")
+    Bt = args.train_batch_size * max(1, args.train_fuse)
+    eu, ec, x, x2 = mk(Bt), mk(Bt), mk(Bt), mk(Bt)
+    ts = torch.full((Bt,), 481, dtype=torch.int32, device=dev)
+    old_lp, adv = torch.full((Bt,), -1.0, device=dev), torch.randn(Bt, generator=g).to(dev)
+    dt = timed(lambda: L.ddim_logprob_ppo_fwd_bwd(ec, eu, x, x2, ts, old_lp, adv, 5.0, 1e-4, True, consts, group=args.train_batch_size), 100)
+    row("ppo_fwd_bwd_grouped", 10 * 4 * chw, Bt, dt, f"{Bt} sample-timesteps per launch ({max(1, args.train_fuse)} fused micro-batches of {args.train_batch_size}); "
+        "the timed call includes the wrapper's two output allocations")
+    n = unet.params.flat.numel()
+    gbuf = torch.randn(n, generator=torch.Generator(device=dev).manual_seed(1), device=dev) * 1e-3
+    sq = torch.zeros(1, dtype=torch.float64, device=dev)
+
+    def norm():
+        sq.zero_()
+        L.grad_sqnorm(gbuf, sq)
+    dt = timed(norm, 10)
+    row("grad_sqnorm", 4, n, dt, "clip_by_global_norm's reduction over the flat gradient (units = parameters)")
+    pbuf = unet.params.flat.clone()
+    mu = torch.zeros(n, dtype=torch.bfloat16, device=dev)
+    nu = torch.zeros(n, dtype=torch.float32, device=dev)
+    step = [0]
+
+    def adam():
+        step[0] += 1
+        L.adamw_bf16mu_step(pbuf, gbuf, mu, nu, sq, 1.0, 1e-5, 0.9, 0.999, 1e-8, 1e-4, 1.0, step[0], zero_grad=False)
+    dt = timed(adam, 10)
+    row("adamw_bf16mu", 24, n, dt, "clip + AdamW(bf16 mu) + weight decay over the flat buffers on a private copy of the parameters (units = parameters; "
+        "zero_grad off so that the gradient stays defined over the repeats: the shipped call also writes the 4 B/param of zeros)")
+    return out
+
+
+def roofline_traffic(dom):
+    """PMC-measured HBM bytes per launch of the dominant kernel family from profiles/roofline_traffic.json — rocprofv3 cannot run
+    inside this process, so the figure is collected by tools/pmc_unet_traffic.sh over exactly the launches the roofline pass
+    event-times and STAMPED with the git commit / date of that run.  It is refused (null + reason) when the stamp is missing or any
+    kernel source is newer than the collection (the k-loop may have changed since)."""
+    tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+    if not os.path.exists(tpath):
+        return None, "profiles/roofline_traffic.json not found"
+    tall = json.load(open(tpath))
+    tj = tall.get(dom + "_unet") or tall.get(dom + "_r02_unet") or tall.get(dom)
+    if not tj:
+        return None, f"no entry for datapath {dom}"
+    stamp = tj.get("collected_unix")
+    if stamp is None:
+        return None, "entry carries no collection stamp (collected before round 3): re-run tools/pmc_unet_traffic.sh"
+    srcs = [os.path.join(ROOT, "ddpo_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "ddpo_amd", "csrc")) if f.endswith((".hip", ".h"))]
+    hashes = tj.get("csrc_sha256")
+    if hashes:
+        import hashlib
+        cur = {os.path.basename(f): hashlib.sha256(open(f, "rb").read()).hexdigest()[:16] for f in srcs}
+        changed = sorted(k for k in ("gemm_bf16.hip", "common.h") if cur.get(k) != hashes.get(k))
+        if changed:
+            return None, f"kernel sources changed since the PMC run of {tj.get('collected_date')} (commit {tj.get('git_commit')}): {', '.join(changed)}"
+    note = tj.get("note", "") + f" [collected {tj.get('collected_date')}, commit {tj.get('git_commit')}, {tj.get('launches')} launches]"
+    return tj["traffic_bytes_per_launch"], note
+
+
 def bench_train(args, comm):
     L, ucfg, unet, vae, sched, state, pipe, emb, neg = build_engine(args, comm)
     res = measure_train(args, comm, L, unet, sched, state, emb, neg, args.steps, args.warmup)
@@ -471,16 +568,7 @@ def main(argv=None):
         peak = FP32_MFMA_PEAK_TFLOPS if dom == "fp32" else BF16_MFMA_PEAK_TFLOPS
         kname = "gemm_conv_kernel (v_mfma_f32_32x32x2_f32)" if dom == "fp32" else \
             f"gemm_conv_bf16_buf_kernel<128x320 | 128x128 | 128x64, NPASS={passes}> (v_mfma_f32_32x32x16_bf16)"
-        traffic, traffic_note = None, None
-        tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
-        if os.path.exists(tpath):
-            tall = json.load(open(tpath))
-            tj = tall.get(dom + "_r02_unet") or tall.get(dom)        # r02: counters over exactly the launches of this event-timed pass
-            if tj:
-                traffic = tj["traffic_bytes_per_launch"]
-                traffic_note = tj.get("note", f"PMC (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes) per launch over {tj.get('launches')} "
-                                              "launches of this kernel family = the same eager U-Net forwards this pass event-times (tools/pmc_unet_traffic.sh), "
-                                              "from profiles/roofline_traffic.json; not collectable inside this process")
+        traffic, traffic_note = roofline_traffic(dom)
         roofline = {"bound": "mfma", "kernel": kname, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                     "frac": achieved / peak, "traffic": traffic, "traffic_note": traffic_note,
                     "algorithmic_bytes_per_launch": sum(r[4] for r in recs) / max(len(recs), 1),
@@ -492,9 +580,14 @@ def main(argv=None):
     if not args.no_train_extra and args.model in ("sd15", "sd21"):
         # the PPO half of an epoch (the wall-clock bottleneck of "reward vs wall-clock"), reported next to the headline number
         try:
-            extra["train"] = measure_train(args, comm, L, unet, sched, state, emb, neg, steps=4, warmup=2)
+            extra["train"] = measure_train(args, comm, L, unet, sched, state, emb, neg, steps=12, warmup=2)
         except Exception as exc:          # the headline line must survive a failure of the secondary measurement
             extra["train"] = {"error": f"{type(exc).__name__}: {exc}"}
+    if not args.no_roofline:
+        try:
+            extra["hbm_kernels"] = measure_hbm_kernels(args, comm, L, ucfg, sched, state, unet)
+        except Exception as exc:
+            extra["hbm_kernels"] = {"error": f"{type(exc).__name__}: {exc}"}
     if rank != 0:
         comm.close()
         return

@@ -23,7 +23,8 @@ _PG_DEFAULTS = (
     # engine-specific addition (not a reference flag): how optax.adamw(mu_dtype=bfloat16) forms `b1 * mu` — True: in bf16, what JAX's
     # weak-type promotion does (scalar x bf16 array stays bf16: b1 -> 0.8984375, product rounded before the f32 term is added);
     # False: decay in f32, one rounding when mu is stored.  optax is not installable here, so the reading is a derivation, not a measurement.
-    ("mu_decay_in_bf16", True),
+    # None = not given on the command line: the entrypoint then takes DDPO_MU_DECAY_IN_BF16 (default 1 = True).
+    ("mu_decay_in_bf16", None),
 )
 
 base = {"pg": dict(_PG_DEFAULTS)}

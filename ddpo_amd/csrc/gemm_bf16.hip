@@ -389,32 +389,35 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int khalf = lane >> 5;
-  int a_ld[BK / 16][TM], b_ld[BK / 16][TN];
-#pragma unroll
-  for (int ks = 0; ks < BK / 16; ++ks) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i) a_ld[ks][i] = swz_off(wm * WTM + i * 32 + (lane & 31), ks * 2 + khalf);
-#pragma unroll
-    for (int j = 0; j < TN; ++j) b_ld[ks][j] = swz_off(wn * WTN + j * 32 + (lane & 31), ks * 2 + khalf);
-  }
+  // Fragment read offsets.  A 32-row block further down adds 32 * 64 B and leaves the swizzle term ((row >> 2) & 3) unchanged, and
+  // the ks = 1 chunk index (2 + khalf) differs from the ks = 0 one (khalf) in bit 1 only, i.e. the byte offset in bit 5: all offsets
+  // of a wave derive from TWO registers (a_ld0, b_ld0) by compile-time additions that fold into the ds_read offset field and one
+  // XOR for ks = 1 — 4 address VGPRs instead of 2 * (TM + TN) (14 on the 256x320 tile, which has none to spare).
+  static_assert((WTM % 32) == 0 && (WTN % 32) == 0, "wave sub-tiles are whole 32-row blocks");
+  const int a_ld0 = swz_off(wm * WTM + (lane & 31), khalf), b_ld0 = swz_off(wn * WTN + (lane & 31), khalf);
+  const int a_ld1 = a_ld0 ^ 32, b_ld1 = b_ld0 ^ 32;
 
   // Fragment loads are software-pipelined by hand across the barrier: the ks=0 fragments of the NEXT k-tile are requested
   // right after the barrier that publishes it and the second half of the current tile's ks=1 MFMAs is issued behind them,
   // so the LDS latency is covered by matrix work instead of stalling the wave at the top of every k-tile.
   struct Frag { bf16x8 ah[TM], al[TM], bh[TN], bl[TN]; };
-  auto ldfrag = [&](int cur, int ks, Frag& f) {
-    const char* sa = smem + cur * STAGE;
-    const char* sb = sa + NPL * A_BYTES;
+  auto ldfrag_at = [&](const char* sa, const char* sb, int ks, Frag& f) {
+    const char* pa = sa + (ks ? a_ld1 : a_ld0);
+    const char* pb = sb + (ks ? b_ld1 : b_ld0);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      f.ah[i] = *reinterpret_cast<const bf16x8*>(sa + a_ld[ks][i]);
-      if (NPASS == 3) f.al[i] = *reinterpret_cast<const bf16x8*>(sa + A_BYTES + a_ld[ks][i]);
+      f.ah[i] = *reinterpret_cast<const bf16x8*>(pa + i * 2048);
+      if (NPASS == 3) f.al[i] = *reinterpret_cast<const bf16x8*>(pa + A_BYTES + i * 2048);
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      f.bh[j] = *reinterpret_cast<const bf16x8*>(sb + b_ld[ks][j]);
-      if (NPASS == 3) f.bl[j] = *reinterpret_cast<const bf16x8*>(sb + B_BYTES + b_ld[ks][j]);
+      f.bh[j] = *reinterpret_cast<const bf16x8*>(pb + j * 2048);
+      if (NPASS == 3) f.bl[j] = *reinterpret_cast<const bf16x8*>(pb + B_BYTES + j * 2048);
     }
+  };
+  auto ldfrag = [&](int cur, int ks, Frag& f) {
+    const char* sa = smem + cur * STAGE;
+    ldfrag_at(sa, sa + NPL * A_BYTES, ks, f);
   };
   auto mma = [&](const Frag& f, int tbeg, int tend) {       // 32x32 blocks [tbeg, tend) of the wave tile, row-major
 #pragma unroll
@@ -513,7 +516,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
         if (conv && tap < ntaps) set_tap(tap);
       }
     };
-    if constexpr (APL == 4) {
+    if constexpr (APL == 4 || APL == 5) {
       // Plain schedule for the TALL 256x320 tile (64 x 160 per wave: 160 accumulator registers leave room for ONE fragment set;
       // the second wave of the SIMD covers the LDS latency).  28 fragment reads and 9 LDS-DMA pieces feed 60 MFMAs per wave and
       // k-tile, against 24 + 7 for 30 MFMAs on the 128x320 tile: 36 % fewer L2 and 42 % fewer LDS bytes per MFMA.
@@ -530,6 +533,48 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
         ldfrag(cur, 1, g);
         mma(g, 0, TM * TN);
       };
+      if constexpr (APL == 5) {
+        // ROTATED schedule (round 3).  The plain loop above makes both waves of a SIMD do the same thing at the same time: after the
+        // barrier both request fragments (nobody computes), then both compute.  Here the upper half of the waves runs the SAME
+        // per-k-tile work shifted by half a phase: it carries the ks = 1 fragments of tile kt - 1 ACROSS the barrier and multiplies them
+        // while the lower half issues its LDS-DMA pieces and reads the ks = 0 fragments of tile kt; from then on one wave of every SIMD
+        // reads while the other multiplies.  The barrier contract is unchanged — every wave has (a) waited for its own pieces of tile kt
+        // and (b) received all of its fragment READS of tile kt - 1 (lgkmcnt(0)) before it arrives; only the register-only MFMAs of
+        // those fragments are issued after it.  Per-element accumulation order is the plain loop's: bit-identical results.
+        const bool rot = wv >= NW / 2;
+        fill(0);
+        Frag g;
+        if (!rot) {
+          int kt = 0;
+#pragma unroll 1
+          for (; kt + 1 < nk; kt += 2) {
+            step4(kt, std::integral_constant<int, 0>{});
+            step4(kt + 1, std::integral_constant<int, 1>{});
+          }
+          if (kt < nk) step4(kt, std::integral_constant<int, 0>{});
+        } else {
+          auto step5 = [&](int kt, auto cur_c) {
+            constexpr int cur = decltype(cur_c)::value;
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt > 0) mma(g, 0, TM * TN);              // ks = 1 of tile kt - 1 (fragments read before the barrier)
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + 1 < nk) fill(cur ^ 1);
+            ldfrag(cur, 0, g);
+            mma(g, 0, TM * TN);
+            ldfrag(cur, 1, g);
+          };
+          int kt = 0;
+#pragma unroll 1
+          for (; kt + 1 < nk; kt += 2) {
+            step5(kt, std::integral_constant<int, 0>{});
+            step5(kt + 1, std::integral_constant<int, 1>{});
+          }
+          if (kt < nk) step5(kt, std::integral_constant<int, 0>{});
+          mma(g, 0, TM * TN);                            // ks = 1 of the last tile
+        }
+      } else {
       fill(0);
       int kt = 0;
 #pragma unroll 1
@@ -538,6 +583,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
         step4(kt + 1, std::integral_constant<int, 1>{});
       }
       if (kt < nk) step4(kt, std::integral_constant<int, 0>{});
+      }
     } else if constexpr (APL == 3) {
       // Mode 2's shape with the WEIGHT operand three LDS stages deep: [A s0 | A s1 | W s0 | W s1 | W s2] (128x320: 2 x 16 KB +
       // 3 x 40 KB = 152 KB).  At the barrier of k-tile s the activation pieces of tile s + 2 and the weight pieces of tile s + 3
@@ -571,18 +617,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
       // stage offsets are RUNTIME scalars (one v_add per fragment read): with compile-time stages the 152 KB image exceeds the
       // 64 KB reach of the ds_read offset field, the compiler keeps one address register per (stage, fragment) and spills
       auto ldfrag3 = [&](uint32_t a_off, uint32_t w_off, int ks, Frag& f) {
-        const char* sa = smem + a_off;
-        const char* sb = smem + 2 * A_STAGE + w_off;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          f.ah[i] = *reinterpret_cast<const bf16x8*>(sa + a_ld[ks][i]);
-          f.al[i] = *reinterpret_cast<const bf16x8*>(sa + A_BYTES + a_ld[ks][i]);
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          f.bh[j] = *reinterpret_cast<const bf16x8*>(sb + b_ld[ks][j]);
-          f.bl[j] = *reinterpret_cast<const bf16x8*>(sb + B_BYTES + b_ld[ks][j]);
-        }
+        ldfrag_at(smem + a_off, smem + 2 * A_STAGE + w_off, ks, f);
       };
       const bool late = d.splits != 0 && wv >= NW / 2;
       Frag g0, g1;
@@ -1141,6 +1176,7 @@ static int launch_bf16_wide(const ddpo_gemm_desc& d, const uint16_t* w_hi, const
 
 // Tall 256x320 tiles (plane-fed path only, 8 waves of 64x160, one workgroup per CU, plain k-loop APL = 4): for layers whose tile
 // grid still covers the chip — the 64x64-latent level of the U-Net (M = 65536: 256 tiles per 320 columns).  No split-K.
+template <int APL>
 static int launch_bf16_tall(const ddpo_gemm_desc& d, const uint16_t* w_hi, const uint16_t* w_lo, int ldw, hipStream_t st) {
   constexpr int BM = 256, BN = 320, WM = 4, WN = 2;
   const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;
@@ -1149,11 +1185,11 @@ static int launch_bf16_tall(const ddpo_gemm_desc& d, const uint16_t* w_hi, const
   const size_t lds = 8 * 32 * 160 * 4;                     // epilogue slices (160 KB) > 2 stages of operand tiles (144 KB)
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_bf16_buf_kernel<BM, BN, 3, 0, WM, WN, true, 4>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_bf16_buf_kernel<BM, BN, 3, 0, WM, WN, true, APL>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_conv_bf16_buf_kernel<BM, BN, 3, 0, WM, WN, true, 4>), dim3(nblk, 1), dim3(64 * WM * WN), lds, st, d, w_hi, w_lo, ldw,
+  hipLaunchKernelGGL((gemm_conv_bf16_buf_kernel<BM, BN, 3, 0, WM, WN, true, APL>), dim3(nblk, 1), dim3(64 * WM * WN), lds, st, d, w_hi, w_lo, ldw,
                      tiles_m, tiles_n, nblk, nk_total, (float*)nullptr);
   DDPO_LAUNCH_CHECK();
   return DDPO_OK;
@@ -1213,7 +1249,11 @@ static int dispatch_bf16(const ddpo_gemm_desc& d, const uint16_t* w_hi, const ui
     const long ntall = (long)((d.M + 255) / 256) * (d.N / 320), nwide = (long)((d.M + 127) / 128) * (d.N / 320);
     const double eff_tall = (double)ntall / (double)(((ntall + 255) / 256) * 256), eff_wide = (double)nwide / (double)(((nwide + 255) / 256) * 256);
     if (tall_mode && d.N % 320 == 0 && d.epilogue == 0 && ntall >= 200 && (tall_mode == 2 || eff_tall * 1.08 >= eff_wide))     // DDPO_APL_TALL=2: without the round rule (A/B)
-      return launch_bf16_tall(d, w_hi, w_lo, ldw, st);
+    {
+      // DDPO_TALL_ROT (default 1): rotated schedule, the two waves of a SIMD alternate between fragment reads / DMA issue and MFMAs
+      static const int tall_rot = [] { const char* e = getenv("DDPO_TALL_ROT"); return e ? atoi(e) : 1; }();
+      return tall_rot ? launch_bf16_tall<5>(d, w_hi, w_lo, ldw, st) : launch_bf16_tall<4>(d, w_hi, w_lo, ldw, st);
+    }
   }
   const int wsplits = wide_splits(d, wsf != nullptr, ws_bytes);
   if (wide_mode && d.N % 320 == 0 && d.M >= 512 && buf_path_ok(d, ldw) && !(d.K / BF_BK < 16 && d.N > 1280) &&

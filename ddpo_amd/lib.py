@@ -6,6 +6,7 @@ There is NO fallback path: if the shared library is missing or a call fails, an 
 """
 import ctypes
 import os
+import threading
 from ctypes import c_void_p, c_int, c_int32, c_int64, c_uint32, c_float, c_double, c_size_t, POINTER, byref
 
 import torch
@@ -116,6 +117,43 @@ _lib = None
 # 3 passes, ~1e-5 relative) or "bf16" (single pass = XLA's TPU default precision).  The bf16 paths are used for
 # weights that have been registered with `pack_weights` (ParamStore.pack_bf16); everything else stays on fp32.
 DATAPATH = os.environ.get("DDPO_DATAPATH", "fp32")
+
+
+_TLS = threading.local()
+
+
+def current_datapath():
+    """The datapath in force for the calling thread: a `with datapath(...)` override, else the process default `DATAPATH`."""
+    return getattr(_TLS, "datapath", None) or DATAPATH
+
+
+class datapath:
+    """`with lib.datapath("bf16x3"):` — datapath override for the CALLING THREAD only (the reward models run on their own thread
+    and stream next to the sampler), restored on exit."""
+
+    def __init__(self, name):
+        if name not in ("fp32", "bf16x3", "bf16"):
+            raise ValueError(f"unknown datapath {name!r}")
+        self.name = name
+
+    def __enter__(self):
+        self.prev = getattr(_TLS, "datapath", None)
+        _TLS.datapath = self.name
+        return self
+
+    def __exit__(self, *exc):
+        _TLS.datapath = self.prev
+        return False
+
+
+def fp32_class_datapath():
+    """Datapath for models whose PARAMETERS the reference keeps in fp32 whatever `dtype` the SD trees are cast to (the reward models:
+    /root/reference/ddpo/utils/serialization.py:343-350 casts text_encoder / vae / unet only): the current one, except that the
+    single-pass `bf16` selected by `load_unet(dtype=bfloat16)` is replaced by `bf16x3`."""
+    cur = current_datapath()
+    return datapath("bf16x3" if cur == "bf16" else cur)
+
+
 SPLITK_WS_BYTES = 64 << 20       # scratch for the deterministic split-K of under-filled launches
 PACKED = {}          # data_ptr of an fp32 weight tensor -> dict(fwd=(hi, lo, Kp), bwd=(hi, lo) | None, K, N)
 
@@ -164,7 +202,7 @@ def planes_ok(w, cin, rows):
     of a convolution's input, M of a dense layer) can take a plane-fed activation: bf16x3 datapath, weight planes registered
     (pack_weights), 32-channel k-tiles that never straddle a tap, and 31-bit byte offsets (the conditions of the
     buffer-addressed kernel, buf_path_ok() in csrc/gemm_bf16.hip — the VAE's 512x512 levels at batch 8 exceed them)."""
-    if not (PLANES and DATAPATH == "bf16x3" and cin % 32 == 0):
+    if not (PLANES and current_datapath() == "bf16x3" and cin % 32 == 0):
         return False
     ent = PACKED.get(w.data_ptr())
     if ent is None:
@@ -189,7 +227,7 @@ def planes_out_ok(w, cin, rows, N):
     """True when the GEMM / conv with weight `w` (reduction channels per tap `cin`, `rows` source rows, N output columns) runs on a
     buffer-addressed bf16x3 kernel, i.e. can emit its result as planes (ddpo_gemm_desc.out_hi): the conditions of planes_ok()
     except that the ACTIVATION may be fp32 (then only K % 32 and the 31-bit offsets matter), plus N % 4 == 0."""
-    if not (PLANES and PLANES_OUT and DATAPATH == "bf16x3" and cin % 32 == 0 and N % 4 == 0):
+    if not (PLANES and PLANES_OUT and current_datapath() == "bf16x3" and cin % 32 == 0 and N % 4 == 0):
         return False
     ent = PACKED.get(w.data_ptr())
     if ent is None:
@@ -438,7 +476,7 @@ def pack_weights_geglu(w, bias):
     the shape does not qualify (the caller then keeps the unfused linear + geglu pair)."""
     K, N = w.shape
     F = N // 2
-    if DATAPATH == "fp32" or (N % 128) or (K % 32):
+    if current_datapath() == "fp32" or (N % 128) or (K % 32):
         return False
     ent = PACKED.get(w.data_ptr())
     if ent is None:
@@ -461,7 +499,7 @@ def linear_geglu(x, w, out=None, planes_out=False):
     Returns None when it was not (caller falls back to linear + geglu).  planes_out: the result comes back as `Planes` only
     (for a plane-fed second feed-forward GEMM)."""
     ent = PACKED.get(w.data_ptr())
-    if DATAPATH == "fp32" or ent is None or "geglu" not in ent or ent["geglu"]["stale"]:
+    if current_datapath() == "fp32" or ent is None or "geglu" not in ent or ent["geglu"]["stale"]:
         return None
     g = ent["geglu"]
     M, K = x.shape
@@ -469,12 +507,12 @@ def linear_geglu(x, w, out=None, planes_out=False):
     if (M * K * 4) >= (1 << 31):
         return None
     pl = x if isinstance(x, Planes) else None
-    if pl is not None and (DATAPATH != "bf16x3" or K % 32):
+    if pl is not None and (current_datapath() != "bf16x3" or K % 32):
         raise DdpoHipError("plane-fed linear_geglu needs the bf16x3 datapath and K % 32 == 0 (check planes_ok before asking for planes)")
     d = GemmDesc()
     opl = None
     if planes_out:
-        if DATAPATH != "bf16x3":
+        if current_datapath() != "bf16x3":
             raise DdpoHipError("plane-emitting linear_geglu needs the bf16x3 datapath")
         opl = Planes(M, N // 2, x.device)
         d.out_hi, d.out_lo, d.ld_planes = opl.hi.data_ptr(), opl.lo.data_ptr(), N // 2
@@ -487,7 +525,7 @@ def linear_geglu(x, w, out=None, planes_out=False):
     d.alpha = 1.0
     d.M, d.N, d.K = int(M), int(N), int(K)
     d.epilogue = 1
-    npass = 3 if DATAPATH == "bf16x3" else 1
+    npass = 3 if current_datapath() == "bf16x3" else 1
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -498,13 +536,13 @@ def linear_geglu(x, w, out=None, planes_out=False):
         _check(load().ddpo_gemm_conv_fwd_bf16(byref(d), _p(g["hi"]), _p(g["lo"]), K, npass, None, 0, _stream()), "ddpo_gemm_conv_fwd_bf16")
     if PROFILE is not None:
         e1.record()
-        PROFILE.append((e0, e1, 2.0 * M * N * K, DATAPATH, 4.0 * (M * K + K * N + M * N // 2)))
+        PROFILE.append((e0, e1, 2.0 * M * N * K, current_datapath(), 4.0 * (M * K + K * N + M * N // 2)))
     return opl if planes_out else out
 
 
 def _bf16_route(w, K, N, conv, dgrad):
     """Return (hi, lo, ldw, npass) if this contraction should run on the bf16 MFMA path, else None."""
-    if DATAPATH == "fp32":
+    if current_datapath() == "fp32":
         return None
     ent = PACKED.get(w.data_ptr())
     if ent is None:
@@ -512,7 +550,7 @@ def _bf16_route(w, K, N, conv, dgrad):
     cin = conv["Cin"] if conv else K
     if cin % 8:
         return None
-    npass = 3 if DATAPATH == "bf16x3" else 1
+    npass = 3 if current_datapath() == "bf16x3" else 1
     if dgrad:
         if ent["bwd"] is None or not conv:
             return None
@@ -575,9 +613,9 @@ def gemm_conv(src, w, *, M, N, K, bias=None, rowbias=None, rows_per_batch=0, res
     if PROFILE is not None:
         e1.record()
         a_bytes = 4.0 * (conv["B"] * conv["H"] * conv["W"] * conv["Cin"] if conv else M * K)       # unique operand bytes
-        w_bytes = (4.0 if route is None else (4.0 if DATAPATH == "bf16x3" else 2.0)) * K * N
+        w_bytes = (4.0 if route is None else (4.0 if current_datapath() == "bf16x3" else 2.0)) * K * N
         io_bytes = a_bytes + w_bytes + 4.0 * M * N * (2 if residual is not None else 1)
-        PROFILE.append((e0, e1, 2.0 * M * N * K, "fp32" if route is None else DATAPATH, io_bytes))
+        PROFILE.append((e0, e1, 2.0 * M * N * K, "fp32" if route is None else current_datapath(), io_bytes))
     if planes_out == "only":
         return opl
     return (out, opl) if planes_out == "both" else out
@@ -608,7 +646,7 @@ def attention(q, k, v, B, heads, Nq, Nk, d, scale=None, out=None, ldq=None, ldk=
         out = torch.empty(B * Nq, C, dtype=torch.float32, device=q.device)
     lse = torch.empty(B * heads * Nq, dtype=torch.float32, device=q.device) if return_lse else None
     sc = float(scale if scale is not None else d ** -0.5)
-    if DATAPATH != "fp32" and d in (8, 16, 40, 64, 80):
+    if current_datapath() != "fp32" and d in (8, 16, 40, 64, 80):
         nb = int(load().ddpo_attention_fwd_bf16x3_ws_bytes(B, heads, Nk, d))      # 0 for short key sequences
         ws = _scratch(nb, q.device, "attn_kv") if nb else None
         _check(load().ddpo_attention_fwd_bf16x3(_p(q), int(ldq or C), _p(k), int(ldk or C), _p(v), int(ldv or C), _p(out), int(ldo or C),
@@ -623,7 +661,7 @@ def attention_kv_images(k, v, B, heads, Nk, d, out=None, ldk=None, ldv=None):
     """Pack K / V (B*Nk, heads*d) once into the per-tile images of the bf16x3 attention kernels (uint8 tensor), for keys / values that
     stay constant over many attention calls (the text context over the DDIM steps).  Returns None where the datapath / head dim has no
     image kernel (the caller keeps k, v)."""
-    if DATAPATH == "fp32" or d not in (8, 16, 40, 64, 80):
+    if current_datapath() == "fp32" or d not in (8, 16, 40, 64, 80):
         return None
     C = heads * d
     nb = int(load().ddpo_attention_kv_images_bytes(B, heads, Nk, d))
@@ -654,7 +692,7 @@ def attention_bwd(q, k, v, o, d_o, lse, B, heads, Nq, Nk, d, scale=None):
     dv = torch.empty(B * Nk, C, dtype=torch.float32, device=q.device)
     dvec = torch.empty(B * heads * Nq, dtype=torch.float32, device=q.device)
     fn, name = load().ddpo_attention_bwd, "ddpo_attention_bwd"
-    if DATAPATH != "fp32" and d in (8, 16, 40, 64, 80):
+    if current_datapath() != "fp32" and d in (8, 16, 40, 64, 80):
         fn, name = load().ddpo_attention_bwd_bf16x3, "ddpo_attention_bwd_bf16x3"
     _check(fn(_p(q), C, _p(k), C, _p(v), C, _p(o), _p(d_o), _p(lse), _p(dvec), _p(dq), _p(dk), _p(dv),
               B, heads, Nq, Nk, d, float(scale if scale is not None else d ** -0.5), _stream()), name)
@@ -708,7 +746,7 @@ def linear_dgrad(dy, w, residual=None):
     """dx = dy @ w^T for the forward y = x @ w, w: (K, N) Flax layout."""
     M, N = dy.shape
     K = w.shape[0]
-    ent = PACKED.get(w.data_ptr()) if DATAPATH != "fp32" else None
+    ent = PACKED.get(w.data_ptr()) if current_datapath() != "fp32" else None
     if ent is not None and ent["bwd"] is not None and N % 8 == 0:
         # the original (K, N) order is exactly "output column k, reduction index n contiguous": forward-style planes with ldw = N
         d = GemmDesc()
@@ -720,7 +758,7 @@ def linear_dgrad(dy, w, residual=None):
         d.alpha = 1.0
         d.M, d.N, d.K = int(M), int(K), int(N)
         ws = _scratch(SPLITK_WS_BYTES, dy.device, "splitk")
-        _check(load().ddpo_gemm_conv_fwd_bf16(byref(d), _p(ent["bwd"][0]), _p(ent["bwd"][1]), int(N), 3 if DATAPATH == "bf16x3" else 1,
+        _check(load().ddpo_gemm_conv_fwd_bf16(byref(d), _p(ent["bwd"][0]), _p(ent["bwd"][1]), int(N), 3 if current_datapath() == "bf16x3" else 1,
                                               _p(ws), SPLITK_WS_BYTES, _stream()), "ddpo_gemm_conv_fwd_bf16(dgrad)")
         return out
     return gemm_conv(dy, w, M=M, N=K, K=N, w_trans=True, residual=residual)
@@ -736,11 +774,11 @@ def linear_wgrad(x, dy, dw):
 def gemm_wgrad(src, dy, dw, *, M, N, K, conv=None, ld_src=None, ld_dy=None, accumulate=True, splits=0, alpha=1.0):
     """dw += A^T dY.  `src` / `dy` may be `Planes` (the forward input as a plane-emitting norm wrote it, dY from a plane-emitting
     output stage): the bf16x3 kernel then skips the fp32 -> bf16 split of that operand."""
-    fast = DATAPATH != "fp32" and accumulate and (conv is None or (conv["stride"] in (1, 2) and conv["upsample"] in (0, 1) and
+    fast = current_datapath() != "fp32" and accumulate and (conv is None or (conv["stride"] in (1, 2) and conv["upsample"] in (0, 1) and
                                                                       conv["pad"] == conv["ksize"] // 2)) and K >= 64 and N >= 32
     spl = src if isinstance(src, Planes) else None
     dpl = dy if isinstance(dy, Planes) else None
-    if not fast or DATAPATH != "bf16x3":           # exact-fp32 / single-pass kernels take fp32 operands (small layers: conv_out, tests)
+    if not fast or current_datapath() != "bf16x3":           # exact-fp32 / single-pass kernels take fp32 operands (small layers: conv_out, tests)
         if spl is not None:
             src, spl = spl.float(), None
         if dpl is not None:

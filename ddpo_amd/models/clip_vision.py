@@ -136,7 +136,7 @@ class ClipVisionTower:
         tree["visual_projection.kernel"] = g("visual_projection.weight").t().contiguous()
         P.load_dict(tree)
         self._pos_cache.clear()
-        if L.DATAPATH != "fp32":
+        if L.current_datapath() != "fp32":
             self.pack()
 
     def pack(self):
@@ -156,7 +156,12 @@ class ClipVisionTower:
         return ent
 
     def forward(self, pixel_values):
-        """(N,3,S,S) fp32 on the device -> image_embeds (N, proj)."""
+        """(N,3,S,S) fp32 on the device -> image_embeds (N, proj).  The reward model keeps fp32 parameters in the reference whatever
+        dtype the SD trees are cast to, so it never runs on the single-pass bf16 datapath (lib.fp32_class_datapath)."""
+        with L.fp32_class_datapath():
+            return self._forward(pixel_values)
+
+    def _forward(self, pixel_values):
         cfg, P = self.cfg, self.params
         N = pixel_values.shape[0]
         if tuple(pixel_values.shape[1:]) != (3, cfg.image, cfg.image):

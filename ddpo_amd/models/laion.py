@@ -131,7 +131,7 @@ class AestheticScorer:
     def __call__(self, images):
         """images: float32 (N,H,W,3) in [0,1] (host) -> (N,) float32 scores (host)."""
         px = preprocess(images, self.cfg.image)                               # host, PIL: byte-identical resize
-        with torch.cuda.stream(self.stream):
+        with torch.cuda.stream(self.stream), L.fp32_class_datapath():
             x = torch.from_numpy(px).to(self.device)
             f = L.l2_normalize_rows(self.tower(x))
             for wp, bp, n in self.mlp:

@@ -533,7 +533,7 @@ class UNet2DCondition:
                 kbuf = torch.empty(B * Lc, wk.shape[1], dtype=torch.float32, device=self.device)
                 vbuf = torch.empty(B * Lc, wv.shape[1], dtype=torch.float32, device=self.device)
                 nb = 0
-                if L.DATAPATH != "fp32" and (wk.shape[1] // heads) in (8, 16, 40, 64, 80) and os.environ.get("DDPO_CTX_IMAGES", "1") != "0":
+                if L.current_datapath() != "fp32" and (wk.shape[1] // heads) in (8, 16, 40, 64, 80) and os.environ.get("DDPO_CTX_IMAGES", "1") != "0":
                     nb = int(L.load().ddpo_attention_kv_images_bytes(B, heads, Lc, wk.shape[1] // heads))
                 ent = (kbuf, vbuf, torch.empty(nb, dtype=torch.uint8, device=self.device) if nb else None)
                 self._ctx_kv[(name, B * Lc)] = ent
@@ -571,8 +571,6 @@ class UNet2DCondition:
         P = self.params
         ts = torch.as_tensor(timesteps, dtype=torch.int32, device=self.device).reshape(-1).contiguous()
         T = ts.numel()
-        if T > 128:
-            raise ValueError("precompute_timesteps: more than 128 steps would change the GEMM tiling of the time path")
         names = self.time_proj_names()
         widths = [P[n + ".time_emb_proj.bias"].numel() for n in names]
         total = sum(widths)
@@ -585,14 +583,17 @@ class UNet2DCondition:
                 off += w
             ent = dict(table=torch.empty(T, total, dtype=torch.float32, device=self.device), row=row, views=views, names=names, widths=widths)
             self._temb = ent
-        emb = L.timestep_embedding(ts, self.cfg.block_out_channels[0])
-        t1 = L.linear(emb, P["time_embedding.linear_1.kernel"], P["time_embedding.linear_1.bias"])
-        temb = L.linear(L.silu(t1), P["time_embedding.linear_2.kernel"], P["time_embedding.linear_2.bias"])
-        act = L.silu(temb)
-        off = 0
-        for n, w in zip(names, widths):
-            L.linear(act, P[n + ".time_emb_proj.kernel"], P[n + ".time_emb_proj.bias"], out=ent["table"][:, off:off + w], ld_out=total)
-            off += w
+        # at most 128 rows per GEMM: one row tile, i.e. the tiling (and so every row's bits) of the per-step time path, for any step count
+        for r0 in range(0, T, 128):
+            r1 = min(T, r0 + 128)
+            emb = L.timestep_embedding(ts[r0:r1].contiguous(), self.cfg.block_out_channels[0])
+            t1 = L.linear(emb, P["time_embedding.linear_1.kernel"], P["time_embedding.linear_1.bias"])
+            temb = L.linear(L.silu(t1), P["time_embedding.linear_2.kernel"], P["time_embedding.linear_2.bias"])
+            act = L.silu(temb)
+            off = 0
+            for n, w in zip(names, widths):
+                L.linear(act, P[n + ".time_emb_proj.kernel"], P[n + ".time_emb_proj.bias"], out=ent["table"][r0:r1, off:off + w], ld_out=total)
+                off += w
         self._temb_active = True
 
     def select_timestep(self, i):
@@ -607,7 +608,7 @@ class UNet2DCondition:
         input geometry) and replayed: the launch-bound host loop disappears from the sampling hot loop.  Inputs are copied
         into the graph's static buffers; the returned tensor is the graph's static output (valid until the next replay).
         Weights are read in place, so optimizer updates / re-packing are seen by later replays."""
-        key = (tuple(sample.shape), tuple(context.shape), L.DATAPATH, self._ctx_kv_active, bool(cfg_dup), self._temb_active)
+        key = (tuple(sample.shape), tuple(context.shape), L.current_datapath(), self._ctx_kv_active, bool(cfg_dup), self._temb_active)
         if not hasattr(self, "_graphs"):
             self._graphs = {}
         ent = self._graphs.get(key)

@@ -98,7 +98,7 @@ class AccumulatingTrainState:
                             tx.learning_rate, tx.b1, tx.b2, tx.eps, tx.weight_decay, tx.max_grad_norm, t,
                             mu_decay_in_bf16=tx.mu_decay_in_bf16, zero_grad=True)
         self.last_grad_norm = torch.sqrt(self._sqnorm.clone()) * inv       # device scalar, no host sync
-        if L.DATAPATH != "fp32":
+        if L.current_datapath() != "fp32":
             self.params.pack_bf16()                                        # refresh the bf16 hi/lo weight planes
         self.opt_state["count"] = t
         self.step += 1
@@ -139,7 +139,7 @@ def _graphed_fwd_bwd(state, batch, sched_state, sched, train_cfg, guidance_scale
     """Replay of _fwd_bwd as a captured HIP graph (one per batch geometry / hyper-parameter set): ~3000 kernel launches per
     micro-step become one graph launch.  Gradients still accumulate into the same flat buffer."""
     key = (tuple(batch["latents"].shape), tuple(batch["prompt_embeds"].shape), bool(train_cfg), float(guidance_scale), float(eta),
-           float(clip_range), sched_state.num_inference_steps, L.DATAPATH, group)
+           float(clip_range), sched_state.num_inference_steps, L.current_datapath(), group)
     cache = state.__dict__.setdefault("_graphs", {})
     ent = cache.get(key)
     if ent == "eager":

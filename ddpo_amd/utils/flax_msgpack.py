@@ -44,7 +44,12 @@ def _ext_unpack(code, data):
     if code in (_EXT_NDARRAY, _EXT_NPSCALAR):
         shape, dtype_name, buf = msgpack.unpackb(data, raw=True)
         dtype_name = dtype_name.decode() if isinstance(dtype_name, bytes) else dtype_name
-        arr = np.frombuffer(buf, dtype=np.dtype(dtype_name)).reshape(shape).copy()      # own, writable memory
+        if dtype_name == "bfloat16":
+            # numpy has no bfloat16 (flax relies on ml_dtypes): a bf16 value is the upper half of the fp32 with the same bits, so the
+            # leaf is widened exactly to float32 (what every consumer here wants: parameters live in fp32 buffers)
+            arr = (np.frombuffer(buf, dtype=np.uint16).astype(np.uint32) << 16).view(np.float32).reshape(shape)
+        else:
+            arr = np.frombuffer(buf, dtype=np.dtype(dtype_name)).reshape(shape).copy()      # own, writable memory
         return arr[()] if code == _EXT_NPSCALAR else arr
     if code == _EXT_COMPLEX:
         re, im = msgpack.unpackb(data)

@@ -65,9 +65,25 @@ def resolve_pretrained(pretrained_model, cache="cache"):
     roots = [r for r in (cache, os.path.join(os.environ["HF_HOME"], "hub") if os.environ.get("HF_HOME") else None,
                          os.environ.get("HUGGINGFACE_HUB_CACHE"), os.path.expanduser("~/.cache/huggingface/hub")) if r]
     for root in roots:
-        snaps = sorted(glob.glob(os.path.join(root, "models--" + pm.replace("/", "--"), "snapshots", "*")))
+        repo = os.path.join(root, "models--" + pm.replace("/", "--"))
+        snaps = [d for d in glob.glob(os.path.join(repo, "snapshots", "*")) if os.path.isdir(d)]
         if snaps:
-            return snaps[-1]
+            # the revision `from_pretrained(revision=None)` resolves: refs/main; DDPO_PRETRAINED_REVISION names another ref or a
+            # commit hash; without a usable ref the most recently written snapshot (never "the lexicographically largest hash")
+            ref = os.environ.get("DDPO_PRETRAINED_REVISION", "main")
+            want = None
+            ref_file = os.path.join(repo, "refs", ref)
+            if os.path.isfile(ref_file):
+                with open(ref_file) as f:
+                    want = f.read().strip()
+            elif ref != "main":
+                want = ref
+            for d in snaps:
+                if want and os.path.basename(d) == want:
+                    return d
+            if want and ref != "main":
+                raise FileNotFoundError(f"revision '{ref}' of '{pm}' is not in the cache '{repo}'")
+            return max(snaps, key=os.path.getmtime)
         for cand in (os.path.join(root, pm), os.path.join(root, pm.split("/")[-1])):
             if os.path.isdir(cand):
                 return cand
@@ -174,6 +190,8 @@ def load_unet(loadpath=None, epoch="latest", pretrained_model="duongna/stable-di
         L.DATAPATH = "bf16"           # single-pass bf16 MFMA, fp32 accumulate: XLA's arithmetic with bf16 parameters
     elif dname in ("float32", "fp32", "f32"):
         bf16_params = False
+        if L.DATAPATH == "bf16":      # an earlier load_unet(dtype=bfloat16) in this process: back to the fp32-class default
+            L.DATAPATH = os.environ.get("DDPO_DATAPATH", "bf16x3")
     else:
         raise ValueError(f"dtype must be float32 or bfloat16 (reference config/base.py:71), got {dtype!r}")
     family = model_family(pretrained_model)

@@ -229,6 +229,30 @@ def _resnet_f(p, name, x, temb, groups, eps):
     return h + x
 
 
+# Score matrices above this many elements (SD-2.1 at 96x96 latents: 5 heads x 9216^2 = 425 M per layer, ten such layers alive
+# under autograd) are formed one block of query rows at a time, each block under torch.utils.checkpoint when gradients are
+# recorded: softmax is row-wise, so every output row is computed by exactly the same operations as in the one-shot form; only
+# the probabilities are recomputed in the backward pass instead of being kept (bounds the host memory of the full-size tests).
+_ATTN_CHUNK_ELEMS = 1 << 28
+_ATTN_CHUNK_ROWS = 1024
+
+
+def _attention_rows(q, k, v, scale):
+    return torch.softmax((q @ k.transpose(-1, -2)) * scale, dim=-1) @ v
+
+
+def _attention_rows_chunked(q, k, v, scale):
+    from torch.utils.checkpoint import checkpoint
+    outs = []
+    for r0 in range(0, q.shape[2], _ATTN_CHUNK_ROWS):
+        qc = q[:, :, r0:r0 + _ATTN_CHUNK_ROWS]
+        if torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad):
+            outs.append(checkpoint(_attention_rows, qc, k, v, scale, use_reentrant=False))
+        else:
+            outs.append(_attention_rows(qc, k, v, scale))
+    return torch.cat(outs, dim=2)
+
+
 def _attention_f(p, name, x, ctx, heads):
     B, N, C = x.shape
     ctx = x if ctx is None else ctx
@@ -238,8 +262,11 @@ def _attention_f(p, name, x, ctx, heads):
     d = C // heads
     sp = lambda t: t.reshape(B, -1, heads, d).permute(0, 2, 1, 3)
     q, k, v = sp(q), sp(k), sp(v)
-    s = (q @ k.transpose(-1, -2)) * (d ** -0.5)
-    o = torch.softmax(s, dim=-1) @ v
+    if B * heads * q.shape[2] * k.shape[2] > _ATTN_CHUNK_ELEMS:
+        o = _attention_rows_chunked(q, k, v, d ** -0.5)
+    else:
+        s = (q @ k.transpose(-1, -2)) * (d ** -0.5)
+        o = torch.softmax(s, dim=-1) @ v
     o = o.permute(0, 2, 1, 3).reshape(B, N, C)
     return _dense_f(p, name + ".to_out_0", o)
 

@@ -233,3 +233,38 @@ def test_attention_bwd_bf16x3(datapath, B, heads, Nq, Nk, d):
     o, lse = L.attention(q.to(DEV), k.to(DEV), v.to(DEV), B, heads, Nq, Nk, d, return_lse=True)
     dq, dk, dv = L.attention_bwd(q.to(DEV), k.to(DEV), v.to(DEV), o, do.to(DEV), lse, B, heads, Nq, Nk, d)
     assert _rel(dq, qd.grad) < 2e-4 and _rel(dk, kd.grad) < 2e-4 and _rel(dv, vd.grad) < 2e-4
+
+
+@pytest.mark.parametrize("family,ocfg,ctx", [("tiny", "TINY", 64), ("tiny21", "TINY21", 96)])
+def test_bfloat16_dtype_path_is_held_to_the_reference_bf16_arithmetic(datapath, family, ocfg, ctx, monkeypatch):
+    """BASELINE configs[4] names `dtype=bfloat16`.  In the reference that casts the parameter trees to bf16 and makes every Flax
+    module compute in bf16 (/root/reference/ddpo/utils/serialization.py:322-350: `from_pretrained(dtype=...)` + `to_dtype`): bf16
+    parameters AND bf16 activations between layers, fp32 accumulation inside a contraction.  Here `load_unet(dtype="bfloat16")`
+    rounds the parameters once and selects the single-pass bf16 MFMA datapath, activations between layers stay fp32.  Tolerance
+    the path is held to: it must be at least as close to the float64 oracle as the reference's own bf16 arithmetic is (the oracle
+    run in torch bfloat16 end to end: measured 1.6e-2 .. 2.5e-2 on these models), and inside 3e-2."""
+    from ddpo_amd.utils.serialization import load_unet
+    from oracle import unet as OU
+    monkeypatch.setenv("DDPO_ALLOW_SYNTHETIC", "1")
+    monkeypatch.setenv("DDPO_MODEL_CONFIG", family)
+    cfg = getattr(OU, ocfg)
+    pipeline, params = load_unet(None, pretrained_model="none", dtype="bfloat16", device=DEV, seed=7)
+    assert L.DATAPATH == "bf16" and pipeline.param_dtype == "bfloat16"
+    unet = pipeline.unet
+    op = {k: v.detach().cpu().clone() for k, v in unet.params.views.items()}
+    assert all(torch.equal(v, v.bfloat16().float()) for v in op.values())           # parameters are bf16 values
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(2, 4, 16, 16, generator=g)
+    t = torch.tensor([481, 21], dtype=torch.int32)
+    c = torch.randn(2, 77, ctx, generator=g)
+    with torch.no_grad():
+        ref = OU.unet_forward({k: v.double() for k, v in op.items()}, cfg, x.double(), t, c.double())
+        emu = OU.unet_forward({k: v.bfloat16() for k, v in op.items()}, cfg, x.bfloat16(), t, c.bfloat16()).float()
+    out = unet(x.to(DEV), t.to(DEV), c.to(DEV))
+    e_prod, e_ref = _rel(out, ref), _rel(emu, ref)
+    print(f"\n[bfloat16 dtype] {family}: engine (bf16 operands, fp32 between layers) {e_prod:.2e}  vs reference-style all-bf16 arithmetic {e_ref:.2e}")
+    assert e_prod < 3e-2 and e_prod <= e_ref
+    # ... and a later float32 load in the same process is back on the fp32-class datapath (ADVICE r02)
+    monkeypatch.delenv("DDPO_DATAPATH", raising=False)
+    load_unet(None, pretrained_model="none", dtype="float32", device=DEV, seed=7)
+    assert L.DATAPATH == "bf16x3"

@@ -224,6 +224,47 @@ def test_unet_sd21_single_sample_96x96_bf16x3():
         L.PACKED.clear()
 
 
+@pytest.mark.timeout(900)
+def test_sampler_sd21_full_size_96x96_graph_path():
+    """BASELINE configs[4] (C5) sampler at size: the full SD-2.1 U-Net, 96x96 latents, classifier-free guidance, v-prediction DDIM
+    with eta = 1, THREE denoising steps through the captured-HIP-graph path (`jit=True`, the reference's only live path:
+    /root/reference/ddpo/diffusers_patch/pipeline_flax_stable_diffusion.py:355-365), time-projection table and cached text K/V
+    included, against the fp32 oracle's sampling loop: timesteps equal, trajectories / final latents / log-probs within the
+    north-star tolerance.  The eager path must agree with the graph replay bit for bit."""
+    from ddpo_amd import lib as L
+    op = OU.init_params(OU.unet_param_shapes(OU.SD21), seed=0)
+    old = L.DATAPATH
+    L.DATAPATH = "bf16x3"
+    try:
+        unet = UNet2DCondition(UNetConfig.named("sd21"), DEV)
+        unet.params.load_dict(op)
+        unet.params.pack_bf16(bwd=False)
+        sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", set_alpha_to_one=False,
+                              steps_offset=1, prediction_type="v_prediction")
+        pipe = StableDiffusionPipeline(unet, None, sched)
+        state = sched.create_state(device=DEV)
+        g = torch.Generator().manual_seed(31)
+        emb = torch.randn(1, 77, 1024, generator=g)
+        neg = torch.randn(1, 77, 1024, generator=g)
+        key = OP.PRNGKey(11)
+        T = 3
+        args = (emb.to(DEV), neg.to(DEV), {"unet": unet.params, "scheduler": state}, key, T)
+        final, lat, nxt, lps, ts = pipe(*args, height=768, width=768, guidance_scale=5.0, eta=1.0, jit=True)
+        final_e, lat_e, nxt_e, lps_e, ts_e = pipe(*args, height=768, width=768, guidance_scale=5.0, eta=1.0, jit=False)
+        assert torch.equal(final, final_e) and torch.equal(nxt, nxt_e) and torch.equal(lps, lps_e)
+        dd = DDIMOracle(prediction_type="v_prediction")
+        with torch.no_grad():
+            ofinal, olat, onxt, olps, ots = oracle_sample(op, OU.SD21, dd, dd.create_state(), emb, neg, key, T, 768, 768, 5.0, 1.0)
+        assert final.shape == (1, 4, 96, 96) and np.array_equal(ts.cpu().numpy(), ots)
+        e_f, e_n = _rel(final.cpu().numpy(), ofinal), _rel(nxt.cpu().numpy(), onxt)
+        e_lp = float(np.abs(lps.cpu().numpy() - olps).max() / np.abs(olps).max())
+        print(f"\n[sd21 96x96 sampler, {T} steps, graph path] final latents {e_f:.2e}  trajectory {e_n:.2e}  log-probs rel {e_lp:.2e}")
+        assert e_f < 1e-3 and e_n < 1e-3 and e_lp < 1e-3
+    finally:
+        L.DATAPATH = old
+        L.PACKED.clear()
+
+
 @pytest.mark.parametrize("datapath", ["fp32", "bf16x3"])
 def test_sd21_shaped_config_sampler_and_train_step(datapath):
     """BASELINE configs[4] shape class on the toy scale: SD-2.1 architecture switches (linear proj_in/out, per-level head

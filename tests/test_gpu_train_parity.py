@@ -126,6 +126,18 @@ def test_train_step_sd15_full_size_bf16x3():
     _check("sd15", OU.SD15, "epsilon", hw=64, b=1, ts=[481], ctx_dim=768, T=50, datapath="bf16x3", dtype=dtype, seed=0)
 
 
+@pytest.mark.timeout(1500)
+def test_train_step_sd21_full_size_bf16x3():
+    """BASELINE configs[4] (C5) at size: ONE SD-2.1 train_step at 96x96 latents (768^2 px), b = 1, train_cfg, v-prediction
+    (/root/reference/ddpo/diffusers_patch/scheduling_ddim_flax.py:309-316), linear proj_in / proj_out, 1024-wide text context,
+    self-attention over 9216 keys at d = 64 forward AND backward, 96x96 tile quantisation of every GEMM — same gates as the
+    SD-1.5 test above (loss, per-block gradient norms < 1e-3, gradient vector < 2e-3).  The oracle runs in fp32 by default
+    (1e-6 of noise against a 1e-3 gate; the 9216^2 score matrices are formed in checkpointed row blocks, oracle/unet.py);
+    DDPO_PARITY_F64=1 runs it in float64 (about three times the host time)."""
+    dtype = torch.float64 if os.environ.get("DDPO_PARITY_F64") == "1" else torch.float32
+    _check("sd21", OU.SD21, "v_prediction", hw=96, b=1, ts=[481], ctx_dim=1024, T=50, datapath="bf16x3", dtype=dtype, seed=0)
+
+
 @pytest.mark.timeout(900)
 def test_vae_sd_decode_512_matches_oracle_and_jpeg_sizes():
     """Full-size VAE decode (4x64x64 latents -> 512x512x3; generic >= 2 GiB loader, materialised 4096^2 softmax) on the bench's

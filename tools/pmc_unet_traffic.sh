@@ -32,6 +32,13 @@ if "FETCH_SIZE" in res and "WRITE_SIZE" in res:
     res["write_bytes_per_launch"] = 1024.0 * res["WRITE_SIZE"]["sum_kb"] / res["WRITE_SIZE"]["launches"]
     res["traffic_bytes_per_launch"] = res["fetch_bytes_per_launch"] + res["write_bytes_per_launch"]
     res["traffic_over_algorithmic"] = res["traffic_bytes_per_launch"] / alg["algorithmic_bytes_per_launch"]
+# stamp: what bench.py checks before it quotes this figure (content hashes of the kernel sources the counters were taken on)
+import hashlib, os, time
+root = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+cs = os.path.join(root, "ddpo_amd", "csrc")
+res["csrc_sha256"] = {f: hashlib.sha256(open(os.path.join(cs, f), "rb").read()).hexdigest()[:16] for f in sorted(os.listdir(cs)) if f.endswith((".hip", ".h"))}
+res["collected_unix"] = int(time.time())
+res["collected_date"] = time.strftime("%Y-%m-%d %H:%M UTC", time.gmtime())
 json.dump(res, open("traffic_unet.json", "w"), indent=1)
 print(json.dumps(res, indent=1))
 PY
