@@ -13,6 +13,26 @@
 #include <cstdlib>
 #include <type_traits>
 
+// Phase timing of the k-loop kernels (tools/native/kernel_probe_timing only: the macro is never defined for libddpo_hip.so).
+// Thread 0 of every workgroup stamps s_memtime (shader clock) and s_memrealtime (100 MHz) at: entry, first barrier of the k-loop,
+// end of the k-loop, end of the output stage.
+#ifdef DDPO_KLOOP_TIMING
+__device__ unsigned long long ddpo_dbg_t[16384 * 8];
+#define DBG_T(i)                                                                                      \
+  do {                                                                                                \
+    if (threadIdx.x == 0) {                                                                           \
+      const int w_ = (blockIdx.x + gridDim.x * blockIdx.y) & 16383;                                   \
+      ddpo_dbg_t[w_ * 8 + (i)] = __builtin_amdgcn_s_memtime();                                        \
+      ddpo_dbg_t[w_ * 8 + 4 + (i)] = __builtin_amdgcn_s_memrealtime();                                \
+    }                                                                                                 \
+  } while (0)
+extern "C" int ddpo_debug_kloop_times(unsigned long long* host, int n_wg) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(ddpo_dbg_t), (size_t)n_wg * 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#else
+#define DBG_T(i) do { } while (0)
+#endif
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -359,6 +379,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
   constexpr int STAGE = NPL * (A_BYTES + B_BYTES);
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
   const int wm = wid / WN, wn = wid % WN;
+  DBG_T(0);
 
   int bid = blockIdx.x;
   {
@@ -525,6 +546,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
         constexpr int cur = decltype(cur_c)::value;
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        if (kt == 0) DBG_T(1);
         if (kt + 1 < nk && !late) fill(cur ^ 1);
         Frag g;
         ldfrag(cur, 0, g);
@@ -584,7 +606,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
       }
       if (kt < nk) step4(kt, std::integral_constant<int, 0>{});
       }
-    } else if constexpr (APL == 3) {
+    } else if constexpr (APL == 3 || APL == 6) {
       // Mode 2's shape with the WEIGHT operand three LDS stages deep: [A s0 | A s1 | W s0 | W s1 | W s2] (128x320: 2 x 16 KB +
       // 3 x 40 KB = 152 KB).  At the barrier of k-tile s the activation pieces of tile s + 2 and the weight pieces of tile s + 3
       // are requested, in that order; the wait in front of the next barrier is a COUNTED vmcnt(NB): everything but the newest NB
@@ -614,6 +636,12 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
                        :: "s"(lw + i * (PAIRS * 1024)), "v"(bvoff[i]), "s"(rs_w), "s"(so_w) : "memory");
         ++kw_next;
       };
+      auto fill_w_piece = [&](int stage, int i) {            // one piece of the weight tile kw_next (the caller advances kw_next after the last); i constant after inlining
+        const uint32_t so_w = __builtin_amdgcn_readfirstlane((uint32_t)kw_next * (BK * 2));
+        const uint32_t lw = __builtin_amdgcn_readfirstlane(lds_w3 + stage * W_STAGE + i * (PAIRS * 1024));
+        asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                     :: "s"(lw), "v"(bvoff[i]), "s"(rs_w), "s"(so_w) : "memory");
+      };
       // stage offsets are RUNTIME scalars (one v_add per fragment read): with compile-time stages the 152 KB image exceeds the
       // 64 KB reach of the ds_read offset field, the compiler keeps one address register per (stage, fragment) and spills
       auto ldfrag3 = [&](uint32_t a_off, uint32_t w_off, int ks, Frag& f) {
@@ -626,6 +654,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
       if (nk > 2) fill_w(2);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
+      DBG_T(1);
       ldfrag3(0, 0, 0, g0);
       uint32_t as = 0, ws = 0;                             // stage INDICES of the current k-tile (kt & 1, kt % 3)
 #pragma unroll 1
@@ -641,6 +670,27 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
         if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(NB) : "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        if constexpr (APL == 6) {
+          // SPREAD (round 3): the pieces are not issued as one burst behind the barrier (eight waves x seven pieces queue on the CU's one
+          // address path while nobody multiplies) but interleaved with the ks = 1 MFMAs, one weight piece behind each 32x32 block: the
+          // activation pieces (needed one k-tile earlier than the weights) first, then [block, piece] pairs.  Same request ORDER per wave
+          // (activations, then weights), so the counted vmcnt(NB) in front of the next barrier means what it meant.
+          static_assert(NB <= TM * TN, "one weight piece per accumulator block");
+          if (kt + 2 < nk) fill_a(as);
+          if (kt + 1 < nk) ldfrag3(as_n * A_STAGE, ws_n * W_STAGE, 0, g0);
+          __builtin_amdgcn_sched_barrier(0);
+          const bool wreq = kt + 3 < nk;
+#pragma unroll
+          for (int j = 0; j < TM * TN; ++j) {
+            mma(g1, j, j + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (j < NB && wreq) fill_w_piece(ws, j);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if (wreq) ++kw_next;
+          as = as_n; ws = ws_n;
+          continue;
+        }
         if (!late) {                                       // activation tile kt + 2, then weight tile kt + 3, into the stages just freed
           if (kt + 2 < nk) fill_a(as);
           if (kt + 3 < nk) fill_w(ws);
@@ -668,6 +718,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
       if (nk > 1) fill(1);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
+      DBG_T(1);
       ldfrag(0, 0, g0);
       auto step2 = [&](int kt, auto cur_c) {
         constexpr int cur = decltype(cur_c)::value;
@@ -824,6 +875,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
       if (DEEP) load_tile(1, s0);
     }
     __syncthreads();
+    DBG_T(1);
     ldfrag(0, 0, f0);
     if (ABL & 8) ldfrag(0, 1, f1);
     if (ABL & 1) s1 = s0;
@@ -863,6 +915,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
 
   }
 
+  DBG_T(2);
   // ---- epilogue.  The C fragment gives a lane one column and 16 scattered rows (dword stores, 2 x 128 B per wave
   // instruction); instead each wave transposes its 64 x (BN/2) sub-tile through its own slice of the (now idle) LDS and
   // writes whole rows with 16-byte stores: 4x fewer store / residual-load instructions, 512 B..1 KiB contiguous each.
@@ -914,6 +967,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
           if (d.out_hi) store_planes4(d, row, col, v);
         }
       }
+      DBG_T(3);
       return;
     }
   }
@@ -949,6 +1003,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
         if (d.out) *reinterpret_cast<float4*>(d.out + (int64_t)row * d.ld_out + q * 32 + gc) = o;
         if (d.out_hi) store_planes4(d, row, q * 32 + gc, o);
       }
+      DBG_T(3);
       return;
     }
     {
@@ -980,6 +1035,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
         if (d.out_hi) store_planes4(d, row, col, v);
       }
     }
+    DBG_T(3);
     return;
   }
   if (part) {
@@ -996,6 +1052,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
           if (row < d.M) pp[(int64_t)row * d.N + col] = acc[i][j][r];
         }
       }
+    DBG_T(3);
     return;
   }
 #pragma unroll
@@ -1017,6 +1074,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
       }
     }
   }
+  DBG_T(3);
 }
 
 // fixed-order reduction of the split-K partials + the fused epilogue (bit-reproducible: no atomics)
@@ -1094,7 +1152,7 @@ static int launch_bf16(const ddpo_gemm_desc& d, const uint16_t* w_hi, const uint
   splits = (nk_total + ktps - 1) / ktps;
   float* part = splits > 1 ? ws : nullptr;
   constexpr int NPL = (NPASS == 3) ? 2 : 1;
-  size_t lds = (APL == 3) ? NPL * (size_t)(2 * BM + 3 * BN) * 64 : 2 * NPL * (size_t)(BM + BN) * 64;     // APL 3: three weight stages
+  size_t lds = (APL == 3 || APL == 6) ? NPL * (size_t)(2 * BM + 3 * BN) * 64 : 2 * NPL * (size_t)(BM + BN) * 64;     // APL 3: three weight stages
   if (lds < (size_t)BM * BN * 4) lds = (size_t)BM * BN * 4;     // the epilogue transposes the C tile through LDS
   static bool attr_set = false;
   if (!attr_set) {
@@ -1327,6 +1385,7 @@ extern "C" int ddpo_gemm_conv_fwd_bf16_planes(const ddpo_gemm_desc* dp, const ui
   // 128x320 tile (slower), a 128x160 tile with two workgroups per CU for short reductions (no gain, profiles/r02_probe_n160.log).
   static const int apl_mode = [] { const char* e = getenv("DDPO_APL_MODE"); return e ? atoi(e) : 7; }();
   d.splits = (apl_mode & 4) ? 1 : 0;                 // `splits` is a wgrad-only field: the forward kernel reads it as the stagger flag
+  if ((apl_mode & 3) == 3 && (apl_mode & 8)) return dispatch_bf16<6>(d, w_hi, w_lo, ldw, 3, ws, ws_bytes, as_stream(stream));      // 11 / 15: three weight stages, requests spread over the MFMA blocks
   if ((apl_mode & 3) == 3) return dispatch_bf16<3>(d, w_hi, w_lo, ldw, 3, ws, ws_bytes, as_stream(stream));      // three weight stages (7 = + stagger)
   return dispatch_bf16<2>(d, w_hi, w_lo, ldw, 3, ws, ws_bytes, as_stream(stream));
 }

@@ -298,6 +298,82 @@ static int probe_gemm2(int B, int iters) {
   return g_fail;
 }
 
+// ------------------------------------------------------------------------------------------------ phase timing (kernel_probe_timing)
+#ifdef PROBE_TIMING
+extern "C" int ddpo_debug_kloop_times(unsigned long long* host, int n_wg);
+// One launch of one layer on the instrumented library; per workgroup: entry -> first k-loop barrier (prologue), k-loop, output stage,
+// in microseconds (s_memrealtime, 100 MHz) and the shader clock seen over the whole workgroup (s_memtime ticks / us).
+static void run_ktime(int B, int H, int Cin, int Cout, int ks, int planes, void* ws, size_t ws_bytes) {
+  const bool conv = ks > 0;
+  const int pad = ks / 2, OH = conv ? H : 0;
+  const int64_t M = conv ? (int64_t)B * OH * OH : (int64_t)B * H;
+  const int K = conv ? ks * ks * Cin : Cin, N = Cout, Kp = (K + 7) / 8 * 8;
+  const int64_t arows = conv ? (int64_t)B * H * H : M;
+  const int acols = conv ? Cin : K;
+  Dev src(arows * acols, 11, 1.0f), w((int64_t)K * N, 12, 1.0f / sqrtf((float)K)), bias(N, 13, 0.5f);
+  float* out = (float*)dalloc((size_t)M * N * 4);
+  uint16_t *hi = (uint16_t*)dalloc((size_t)N * Kp * 2), *lo = (uint16_t*)dalloc((size_t)N * Kp * 2);
+  uint16_t *ah = (uint16_t*)dalloc((size_t)arows * acols * 2), *al = (uint16_t*)dalloc((size_t)arows * acols * 2);
+  ABI_OK(ddpo_pack_weights_bf16(w.p, K, N, Kp, hi, lo, nullptr, nullptr, nullptr));
+  ABI_OK(ddpo_split_planes_bf16(src.p, acols, ah, al, acols, arows, acols, nullptr));
+  ddpo_gemm_desc d;
+  memset(&d, 0, sizeof(d));
+  d.src = src.p; d.ld_src = acols; d.bias = bias.p; d.out = out; d.ld_out = N; d.alpha = 1.f;
+  d.M = (int)M; d.N = N; d.K = K;
+  if (conv) { d.ksize = ks; d.stride = 1; d.pad = pad; d.B = B; d.H = H; d.W = H; d.Cin = Cin; d.OH = OH; d.OW = OH; }
+  auto launch = [&] {
+    if (planes) ABI_OK(ddpo_gemm_conv_fwd_bf16_planes(&d, ah, al, acols, hi, lo, Kp, ws, ws_bytes, nullptr));
+    else ABI_OK(ddpo_gemm_conv_fwd_bf16(&d, hi, lo, Kp, 3, ws, ws_bytes, nullptr));
+  };
+  const std::vector<WarmBuf> warm = planes ? std::vector<WarmBuf>{{ah, (size_t)arows * acols * 2}, {al, (size_t)arows * acols * 2}}
+                                           : std::vector<WarmBuf>{{src.p, (size_t)arows * acols * 4}};
+  const float ms = probe_cold() ? time_cold_ms(3, launch, warm) : time_ms(3, launch);
+  HIP_OK(hipDeviceSynchronize());
+  const int NW = 16384;
+  std::vector<unsigned long long> t((size_t)NW * 8, 0ull);
+  // poison, run once, read
+  {
+    std::vector<unsigned long long> z((size_t)NW * 8, 0ull);
+    (void)z;
+  }
+  launch();
+  HIP_OK(hipDeviceSynchronize());
+  if (ddpo_debug_kloop_times(t.data(), NW) != 0) { printf("ktime: no timing symbol\n"); return; }
+  // workgroups of the LAST launch: those whose entry stamp is within the last launch window (max entry - 1 ms)
+  unsigned long long tmax = 0;
+  for (int i = 0; i < NW; ++i) tmax = std::max(tmax, t[i * 8 + 4 + 3]);
+  double sp = 0, sk = 0, se = 0, mp = 0, mk = 0, me = 0, clk = 0;
+  unsigned long long first = ~0ull, last = 0;
+  int n = 0;
+  for (int i = 0; i < NW; ++i) {
+    const unsigned long long* r = &t[i * 8 + 4];
+    if (r[3] == 0 || tmax - r[3] > 100000ull) continue;     // older than 1 ms before the end: not this launch
+    const double p = (r[1] - r[0]) * 0.01, k = (r[2] - r[1]) * 0.01, e = (r[3] - r[2]) * 0.01;
+    sp += p; sk += k; se += e; mp = std::max(mp, p); mk = std::max(mk, k); me = std::max(me, e);
+    if (r[3] > r[0]) clk += (double)(t[i * 8 + 3] - t[i * 8 + 0]) / ((r[3] - r[0]) * 0.01);
+    first = std::min(first, r[0]); last = std::max(last, r[3]);
+    ++n;
+  }
+  if (conv) printf("ktime conv %dx%d %5d->%5d @%3d^2 B%-3d %s:", ks, ks, Cin, Cout, H, B, planes ? "planes" : "fp32  ");
+  else printf("ktime gemm M=%7lld K=%5d N=%5d %s:", (long long)M, K, N, planes ? "planes" : "fp32  ");
+  printf(" event %7.1f us | %5d WGs, span %7.1f us | prologue avg %6.1f max %6.1f | k-loop avg %7.1f max %7.1f (%d k-tiles: %.2f us each) | output avg %6.1f max %6.1f | clock %.0f MHz\n",
+         ms * 1e3, n, (last - first) * 0.01, sp / n, mp, sk / n, mk, K / 32, sk / n / (K / 32), se / n, me, clk / n);
+  fflush(stdout);
+  src.release(); w.release(); bias.release();
+  HIP_OK(hipFree(out)); HIP_OK(hipFree(hi)); HIP_OK(hipFree(lo)); HIP_OK(hipFree(ah)); HIP_OK(hipFree(al));
+}
+static int probe_ktime(int B) {
+  const size_t ws_bytes = 64u << 20;
+  void* ws = dalloc(ws_bytes);
+  const ConvCase convs[] = {{64, 320, 320, 3, 1, 0}, {32, 640, 640, 3, 1, 0}, {16, 1280, 1280, 3, 1, 0}, {64, 960, 320, 3, 1, 0}};
+  for (const ConvCase& c : convs) for (int pl = 0; pl < 2; ++pl) run_ktime(B, c.H, c.Cin, c.Cout, c.ks, pl, ws, ws_bytes);
+  const int dense[][3] = {{4096, 320, 320}, {4096, 1280, 320}, {1024, 640, 640}, {256, 1280, 1280}, {1024, 2560, 640}, {4096, 320, 960}};
+  for (auto& g : dense) for (int pl = 0; pl < 2; ++pl) run_ktime(B, g[0], g[1], g[2], 0, pl, ws, ws_bytes);
+  HIP_OK(hipFree(ws));
+  return 0;
+}
+#endif
+
 // ------------------------------------------------------------------------------------------------ attention
 static void run_attn(int B, int heads, int Nq, int Nk, int d, int iters) {
   const int C = heads * d;
@@ -465,6 +541,9 @@ int main(int argc, char** argv) {
   else if (mode == "gemm2") rc = probe_gemm2(B, iters);
   else if (mode == "attn") rc = probe_attn(B, iters);
   else if (mode == "ppo") rc = probe_ppo();
+#ifdef PROBE_TIMING
+  else if (mode == "ktime") rc = probe_ktime(B);
+#endif
   else { fprintf(stderr, "usage: kernel_probe gemm|gemm2|attn|ppo [batch] [iters]\n"); return 64; }
   HIP_OK(hipDeviceSynchronize());
   printf("# %s: %s\n", mode.c_str(), rc ? "FAILURES" : "all spot checks passed");
