@@ -17,7 +17,7 @@
 // Thread 0 of every workgroup stamps s_memtime (shader clock) and s_memrealtime (100 MHz) at: entry, first barrier of the k-loop,
 // end of the k-loop, end of the output stage.
 #ifdef DDPO_KLOOP_TIMING
-__device__ unsigned long long ddpo_dbg_t[16384 * 8];
+__device__ unsigned long long ddpo_dbg_t[2 * 16384 * 8];
 #define DBG_T(i)                                                                                      \
   do {                                                                                                \
     if (threadIdx.x == 0) {                                                                           \
@@ -26,11 +26,33 @@ __device__ unsigned long long ddpo_dbg_t[16384 * 8];
       ddpo_dbg_t[w_ * 8 + 4 + (i)] = __builtin_amdgcn_s_memrealtime();                                \
     }                                                                                                 \
   } while (0)
+// exposed wait of wave 0 at the k-tile boundaries: DBG_W0 before the s_waitcnt in front of the barrier, DBG_W1 behind the barrier,
+// DBG_WSTORE once after the loop (slot 3 of the realtime half is overwritten: the probe reads slot 7 as "wait cycles")
+#define DBG_ABL(bit) ((d.splits >> 4) & (bit))      /* timing build only: 1 = no LDS-DMA inside the loop, 2 = no MFMAs */
+#define DBG_WDECL unsigned long long dbg_w0_ = 0, dbg_wacc_ = 0, dbg_bacc_ = 0
+#define DBG_W0() do { dbg_w0_ = __builtin_amdgcn_s_memtime(); } while (0)
+#define DBG_WMID() do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); dbg_wacc_ += n_ - dbg_w0_; dbg_w0_ = n_; } while (0)
+#define DBG_W1() do { dbg_bacc_ += __builtin_amdgcn_s_memtime() - dbg_w0_; } while (0)
+#define DBG_WSTORE()                                                                 \
+  do {                                                                               \
+    if (threadIdx.x == 0) {                                                          \
+      const int w_ = (blockIdx.x + gridDim.x * blockIdx.y) & 16383;                  \
+      ddpo_dbg_t[(16384 + w_) * 8 + 0] = dbg_wacc_;                                  \
+      ddpo_dbg_t[(16384 + w_) * 8 + 1] = dbg_bacc_;                                  \
+    }                                                                                \
+  } while (0)
 extern "C" int ddpo_debug_kloop_times(unsigned long long* host, int n_wg) {
-  return hipMemcpyFromSymbol(host, HIP_SYMBOL(ddpo_dbg_t), (size_t)n_wg * 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+  (void)n_wg;
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(ddpo_dbg_t), (size_t)2 * 16384 * 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
 }
 #else
 #define DBG_T(i) do { } while (0)
+#define DBG_ABL(bit) 0
+#define DBG_WDECL do { } while (0)
+#define DBG_W0() do { } while (0)
+#define DBG_WMID() do { } while (0)
+#define DBG_W1() do { } while (0)
+#define DBG_WSTORE() do { } while (0)
 #endif
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -191,6 +213,7 @@ __global__ void __launch_bounds__(BF_THREADS) gemm_conv_bf16_kernel(const ddpo_g
       if (n < d.N && bval) {
         int64_t off;
         if (d.w_dgrad) off = ((int64_t)(ntaps - 1 - b_tap) * d.N + n) * d.Cin + b_co;   // forward [tap][ci=n][co] order, flipped tap
+        else if (d.w_layout == 1) off = ((int64_t)(kb >> 5) * d.N + n) * 32 + (kb & 31);   // k-blocked (Kb, N, 32)
         else off = (int64_t)n * ldw + kb;
         h = *reinterpret_cast<const uint4*>(w_hi + off);
         if (NPASS == 3) l = *reinterpret_cast<const uint4*>(w_lo + off);
@@ -380,6 +403,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
   const int wm = wid / WN, wn = wid % WN;
   DBG_T(0);
+  DBG_WDECL;
 
   int bid = blockIdx.x;
   {
@@ -506,10 +530,14 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
         avoff[i] = ok ? off : BUF_OOB;
       }
     };
+    // weight planes: row-major (N, ldw) -> row stride ldw * 2 B, k-tile advance 64 B; k-blocked (Kb, N, 32) -> row stride 64 B,
+    // k-tile advance N * 64 B (a piece = 16 consecutive columns = 1 KiB of consecutive memory)
+    const uint32_t w_row_b = d.w_layout == 1 ? 64u : (uint32_t)ldw * 2u;
+    const uint32_t w_kt_b = d.w_layout == 1 ? (uint32_t)d.N * 64u : (uint32_t)(BK * 2);
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int n = n0 + 16 * (pr + PAIRS * i) + lr;
-      bvoff[i] = n < d.N ? (uint32_t)n * (uint32_t)ldw * 2u + lc16 : BUF_OOB;
+      bvoff[i] = n < d.N ? (uint32_t)n * w_row_b + lc16 : BUF_OOB;
     }
     const int nk_total = d.K / BK;
     const int kt0 = blockIdx.y * kt_per_split;
@@ -520,7 +548,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
 
     // one k-tile = NA + NB LDS-DMA pieces per wave (issued back to back; nothing of it touches a VGPR besides the offsets)
     auto fill = [&](int stage) {
-      const uint32_t so_a = (uint32_t)cib * 2u, so_w = (uint32_t)kt_next * (BK * 2);
+      const uint32_t so_a = (uint32_t)cib * 2u, so_w = (uint32_t)kt_next * w_kt_b;
       const uint32_t la = lds_a + stage * STAGE, lw = lds_w + stage * STAGE;
 #pragma unroll
       for (int i = 0; i < NA; ++i)
@@ -541,19 +569,23 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
       // Plain schedule for the TALL 256x320 tile (64 x 160 per wave: 160 accumulator registers leave room for ONE fragment set;
       // the second wave of the SIMD covers the LDS latency).  28 fragment reads and 9 LDS-DMA pieces feed 60 MFMAs per wave and
       // k-tile, against 24 + 7 for 30 MFMAs on the 128x320 tile: 36 % fewer L2 and 42 % fewer LDS bytes per MFMA.
-      const bool late = d.splits != 0 && wv >= NW / 2;
+      const bool late = (d.splits & 1) != 0 && wv >= NW / 2;
       auto step4 = [&](int kt, auto cur_c) {
         constexpr int cur = decltype(cur_c)::value;
+        DBG_W0();
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        DBG_WMID();
         __builtin_amdgcn_s_barrier();
+        DBG_W1();
         if (kt == 0) DBG_T(1);
-        if (kt + 1 < nk && !late) fill(cur ^ 1);
+        if (kt + 1 < nk && !late && !DBG_ABL(1)) fill(cur ^ 1);
         Frag g;
         ldfrag(cur, 0, g);
-        mma(g, 0, TM * TN);
-        if (kt + 1 < nk && late) fill(cur ^ 1);
+        if (!DBG_ABL(2)) mma(g, 0, TM * TN);
+        if (kt + 1 < nk && late && !DBG_ABL(1)) fill(cur ^ 1);
         ldfrag(cur, 1, g);
-        mma(g, 0, TM * TN);
+        if (!DBG_ABL(2)) mma(g, 0, TM * TN);
+        if (DBG_ABL(2)) asm volatile("" :: "v"(g.ah[0]), "v"(g.bl[TN - 1]), "v"(g.al[TM - 1]), "v"(g.bh[0]));
       };
       if constexpr (APL == 5) {
         // ROTATED schedule (round 3).  The plain loop above makes both waves of a SIMD do the same thing at the same time: after the
@@ -629,7 +661,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
         }
       };
       auto fill_w = [&](int stage) {
-        const uint32_t so_w = (uint32_t)kw_next * (BK * 2), lw = lds_w3 + stage * W_STAGE;
+        const uint32_t so_w = (uint32_t)kw_next * w_kt_b, lw = lds_w3 + stage * W_STAGE;
 #pragma unroll
         for (int i = 0; i < NB; ++i)
           asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
@@ -637,7 +669,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
         ++kw_next;
       };
       auto fill_w_piece = [&](int stage, int i) {            // one piece of the weight tile kw_next (the caller advances kw_next after the last); i constant after inlining
-        const uint32_t so_w = __builtin_amdgcn_readfirstlane((uint32_t)kw_next * (BK * 2));
+        const uint32_t so_w = __builtin_amdgcn_readfirstlane((uint32_t)kw_next * w_kt_b);
         const uint32_t lw = __builtin_amdgcn_readfirstlane(lds_w3 + stage * W_STAGE + i * (PAIRS * 1024));
         asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                      :: "s"(lw), "v"(bvoff[i]), "s"(rs_w), "s"(so_w) : "memory");
@@ -647,7 +679,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
       auto ldfrag3 = [&](uint32_t a_off, uint32_t w_off, int ks, Frag& f) {
         ldfrag_at(smem + a_off, smem + 2 * A_STAGE + w_off, ks, f);
       };
-      const bool late = d.splits != 0 && wv >= NW / 2;
+      const bool late = (d.splits & 1) != 0 && wv >= NW / 2;
       Frag g0, g1;
       fill_a(0); fill_w(0);
       if (nk > 1) { fill_a(1); fill_w(1); }
@@ -663,13 +695,17 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
         const uint32_t as_n = as ^ 1, ws_n = ws == 2 ? 0 : ws + 1;
         ldfrag3(a_off, w_off, 1, g1);
         __builtin_amdgcn_sched_barrier(0);
-        mma(g0, 0, TM * TN);
+        if (!DBG_ABL(2)) mma(g0, 0, TM * TN);
+        else asm volatile("" :: "v"(g0.ah[0]), "v"(g0.bl[TN - 1]), "v"(g0.al[TM - 1]), "v"(g0.bh[0]));
         __builtin_amdgcn_sched_barrier(0);
         // tile kt + 1 (A requested one barrier ago, W two barriers ago) must have landed; the weight tile kt + 2 requested one
         // barrier ago — the newest NB pieces of this wave — may stay in flight.  lgkmcnt(0): my reads of tile kt's stages returned.
+        DBG_W0();
         if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(NB) : "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        DBG_WMID();
         __builtin_amdgcn_s_barrier();
+        DBG_W1();
         if constexpr (APL == 6) {
           // SPREAD (round 3): the pieces are not issued as one burst behind the barrier (eight waves x seven pieces queue on the CU's one
           // address path while nobody multiplies) but interleaved with the ks = 1 MFMAs, one weight piece behind each 32x32 block: the
@@ -691,19 +727,20 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
           as = as_n; ws = ws_n;
           continue;
         }
-        if (!late) {                                       // activation tile kt + 2, then weight tile kt + 3, into the stages just freed
+        if (!late && !DBG_ABL(1)) {                        // activation tile kt + 2, then weight tile kt + 3, into the stages just freed
           if (kt + 2 < nk) fill_a(as);
           if (kt + 3 < nk) fill_w(ws);
         }
         if (kt + 1 < nk) ldfrag3(as_n * A_STAGE, ws_n * W_STAGE, 0, g0);
         __builtin_amdgcn_sched_barrier(0);
-        mma(g1, 0, (TM * TN) / 2);
+        if (!DBG_ABL(2)) mma(g1, 0, (TM * TN) / 2);
+        else asm volatile("" :: "v"(g1.ah[0]), "v"(g1.bl[TN - 1]), "v"(g1.al[TM - 1]), "v"(g1.bh[0]));
         __builtin_amdgcn_sched_barrier(0);
-        if (late) {
+        if (late && !DBG_ABL(1)) {
           if (kt + 2 < nk) fill_a(as);
           if (kt + 3 < nk) fill_w(ws);
         }
-        mma(g1, (TM * TN) / 2, TM * TN);
+        if (!DBG_ABL(2)) mma(g1, (TM * TN) / 2, TM * TN);
         __builtin_amdgcn_sched_barrier(0);
         as = as_n; ws = ws_n;
       }
@@ -712,7 +749,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
       // registers; its ks = 1 fragments are requested and the ks = 0 MFMAs run under them; then everybody waits for tile kt + 1
       // to have landed and for its own reads of tile kt's stage to have returned, the barrier publishes both facts, tile kt + 2 is
       // requested into the stage just freed, the ks = 0 fragments of tile kt + 1 are requested and the ks = 1 MFMAs run under them.
-      const bool late = d.splits != 0 && wv >= NW / 2;          // staggered request (see DDPO_APL_MODE)
+      const bool late = (d.splits & 1) != 0 && wv >= NW / 2;          // staggered request (see DDPO_APL_MODE)
       Frag g0, g1;
       fill(0);
       if (nk > 1) fill(1);
@@ -792,7 +829,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
     for (int i = 0; i < BCH; ++i) {
       const int br = (t >> 2) + BR * i;
       const int n = n0 + br;
-      const uint32_t row_bytes = d.w_dgrad ? (uint32_t)d.Cin * 2u : (uint32_t)ldw * 2u;
+      const uint32_t row_bytes = d.w_dgrad ? (uint32_t)d.Cin * 2u : (d.w_layout == 1 ? 64u : (uint32_t)ldw * 2u);
       bvoff[i] = (n < d.N && (BFULL || br < BN)) ? (uint32_t)n * row_bytes + bc * 16u : BUF_OOB;
     }
 
@@ -810,7 +847,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
     // collapse the prefetch distance): requests past this split's last k-tile re-fetch the last tile and are never consumed.
     auto load_tile = [&](int ktr, Stage& sg) {
       const int so_a = cib * 4;
-      const int so_w = d.w_dgrad ? ((ntaps - 1 - tap) * d.N * d.Cin + cib) * 2 : (kt0 + min(ktr, nk - 1)) * (BK * 2);
+      const int so_w = d.w_dgrad ? ((ntaps - 1 - tap) * d.N * d.Cin + cib) * 2 : (kt0 + min(ktr, nk - 1)) * (d.w_layout == 1 ? d.N * 64 : BK * 2);
 #pragma unroll
       for (int i = 0; i < AROWS; ++i) {
         const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_a, avoff[i], so_a, 0);
@@ -916,6 +953,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
   }
 
   DBG_T(2);
+  DBG_WSTORE();
   // ---- epilogue.  The C fragment gives a lane one column and 16 scattered rows (dword stores, 2 x 128 B per wave
   // instruction); instead each wave transposes its 64 x (BN/2) sub-tile through its own slice of the (now idle) LDS and
   // writes whole rows with 16-byte stores: 4x fewer store / residual-load instructions, 512 B..1 KiB contiguous each.
@@ -1120,6 +1158,7 @@ static bool g_force_generic = false;
 static bool buf_path_ok(const ddpo_gemm_desc& d, int ldw) {
   if (g_force_generic) return false;
   const int64_t lim = 0x7FFFFFFF;
+  if (d.w_layout == 1) ldw = (d.K + 31) / 32 * 32;          // k-blocked planes: Kb * N * 32 elements
   if (d.ksize > 0) {
     if (d.Cin % BF_BK) return false;
     if ((int64_t)d.B * d.H * d.W * d.ld_src * 4 >= lim) return false;
@@ -1348,9 +1387,10 @@ extern "C" int ddpo_gemm_conv_fwd_bf16(const ddpo_gemm_desc* dp, const uint16_t*
   } else if (d.K & 7) {
     return DDPO_EINVAL;
   }
+  if (d.w_layout != 0 && (d.w_layout != 1 || d.w_dgrad)) return DDPO_EINVAL;
   if (d.w_dgrad) {
     if (d.ksize <= 0 || (d.Cin & 7)) return DDPO_EINVAL;       // W planes in forward [K][N] order; co chunks of 8 stay inside a tap
-  } else if (ldw < d.K || (ldw & 7)) {
+  } else if (d.w_layout == 0 && (ldw < d.K || (ldw & 7))) {
     return DDPO_EINVAL;
   }
   return dispatch_bf16<0>(d, w_hi, w_lo, ldw, npass, ws, ws_bytes, as_stream(stream));
@@ -1363,8 +1403,10 @@ extern "C" int ddpo_gemm_conv_fwd_bf16_planes(const ddpo_gemm_desc* dp, const ui
   if (!dp || !a_hi || !a_lo || !w_hi || !w_lo) return DDPO_EINVAL;
   ddpo_gemm_desc d = *dp;
   if (d.M <= 0 || d.N <= 0 || d.K <= 0 || lda <= 0 || (lda & 7) || d.w_dgrad || !planes_out_ok(d)) return DDPO_EINVAL;
-  if (((reinterpret_cast<uintptr_t>(a_hi) | reinterpret_cast<uintptr_t>(a_lo) | reinterpret_cast<uintptr_t>(w_hi) |
-        reinterpret_cast<uintptr_t>(w_lo)) & 15) || ldw < d.K || (ldw & 7)) return DDPO_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(a_hi) | reinterpret_cast<uintptr_t>(a_lo) | reinterpret_cast<uintptr_t>(w_hi) |
+       reinterpret_cast<uintptr_t>(w_lo)) & 15) return DDPO_EINVAL;
+  if (d.w_layout != 0 && d.w_layout != 1) return DDPO_EINVAL;
+  if (d.w_layout == 0 && (ldw < d.K || (ldw & 7))) return DDPO_EINVAL;
   if (d.ksize > 0) {
     if (d.ksize != 1 && d.ksize != 3) return DDPO_EINVAL;
     if (d.K != d.ksize * d.ksize * d.Cin || d.M != d.B * d.OH * d.OW || d.upsample < 0 || d.upsample > 2 || lda < d.Cin) return DDPO_EINVAL;
@@ -1385,6 +1427,9 @@ extern "C" int ddpo_gemm_conv_fwd_bf16_planes(const ddpo_gemm_desc* dp, const ui
   // 128x320 tile (slower), a 128x160 tile with two workgroups per CU for short reductions (no gain, profiles/r02_probe_n160.log).
   static const int apl_mode = [] { const char* e = getenv("DDPO_APL_MODE"); return e ? atoi(e) : 7; }();
   d.splits = (apl_mode & 4) ? 1 : 0;                 // `splits` is a wgrad-only field: the forward kernel reads it as the stagger flag
+#ifdef DDPO_KLOOP_TIMING
+  { const char* e = getenv("DDPO_DBG_ABL"); if (e) d.splits |= atoi(e) << 4; }
+#endif
   if ((apl_mode & 3) == 3 && (apl_mode & 8)) return dispatch_bf16<6>(d, w_hi, w_lo, ldw, 3, ws, ws_bytes, as_stream(stream));      // 11 / 15: three weight stages, requests spread over the MFMA blocks
   if ((apl_mode & 3) == 3) return dispatch_bf16<3>(d, w_hi, w_lo, ldw, 3, ws, ws_bytes, as_stream(stream));      // three weight stages (7 = + stagger)
   return dispatch_bf16<2>(d, w_hi, w_lo, ldw, 3, ws, ws_bytes, as_stream(stream));
@@ -1422,6 +1467,43 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(const float* __restri
       fwd_lo[(int64_t)n * Kp + k] = (uint16_t)(p >> 16);
     }
   }
+}
+
+// k-blocked forward planes (Kb = ceil(K / 32), N, 32): same 32x32 tile transpose, the tile of k-block kb lands at [kb][n0 .. n0+31][0..31]
+__global__ void __launch_bounds__(256) pack_weights_kblocked_kernel(const float* __restrict__ w, int K, int N, uint16_t* __restrict__ fwd_hi,
+                                                                    uint16_t* __restrict__ fwd_lo) {
+  __shared__ uint32_t tile[32][33];
+  const int kb = blockIdx.y, k0 = kb * 32, n0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    const int k = k0 + r, n = n0 + tx;
+    uint32_t packed = 0;
+    if (k < K && n < N) {
+      const float x = w[(int64_t)k * N + n];
+      const uint32_t h = cvt_pk_bf16(x, 0.f) & 0xFFFFu;
+      const float rem = x - __uint_as_float(h << 16);
+      packed = h | ((cvt_pk_bf16(rem, 0.f) & 0xFFFFu) << 16);
+    }
+    tile[r][tx] = packed;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int n = n0 + r;
+    if (n < N) {
+      const uint32_t p = tile[tx][r];
+      const int64_t o = ((int64_t)kb * N + n) * 32 + tx;
+      fwd_hi[o] = (uint16_t)(p & 0xFFFFu);
+      fwd_lo[o] = (uint16_t)(p >> 16);
+    }
+  }
+}
+
+extern "C" int ddpo_pack_weights_bf16_kblocked(const float* w, int K, int N, uint16_t* fwd_hi, uint16_t* fwd_lo, void* stream) {
+  if (!w || !fwd_hi || !fwd_lo || K <= 0 || N <= 0) return DDPO_EINVAL;
+  dim3 grid((N + 31) / 32, (K + 31) / 32);
+  hipLaunchKernelGGL(pack_weights_kblocked_kernel, grid, dim3(256), 0, as_stream(stream), w, K, N, fwd_hi, fwd_lo);
+  DDPO_LAUNCH_CHECK();
+  return DDPO_OK;
 }
 
 extern "C" int ddpo_pack_weights_bf16(const float* w, int K, int N, int Kp, uint16_t* fwd_hi, uint16_t* fwd_lo, uint16_t* bwd_hi,

@@ -35,10 +35,10 @@ class GemmDesc(ctypes.Structure):
                 ("B", c_int), ("H", c_int), ("W", c_int), ("Cin", c_int),
                 ("OH", c_int), ("OW", c_int),
                 ("w_dgrad", c_int), ("ld_w", c_int), ("splits", c_int), ("accumulate", c_int), ("epilogue", c_int),
-                ("out_hi", c_void_p), ("out_lo", c_void_p), ("ld_planes", c_int)]
+                ("out_hi", c_void_p), ("out_lo", c_void_p), ("ld_planes", c_int), ("w_layout", c_int)]
 
 
-ABI_VERSION = 5          # must equal ddpo_abi_version() of the loaded library (include/ddpo_hip.h)
+ABI_VERSION = 6          # must equal ddpo_abi_version() of the loaded library (include/ddpo_hip.h)
 
 _SIGS = {
     "ddpo_abi_version": (c_int, []),
@@ -73,6 +73,7 @@ _SIGS = {
                                           c_float, c_int, c_void_p, c_void_p, c_void_p]),
     "ddpo_layernorm_fwd_planes": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "ddpo_pack_weights_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ddpo_pack_weights_bf16_kblocked": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "ddpo_attention_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int,
                                    c_int, c_int, c_int, c_float, c_void_p]),
     "ddpo_attention_kv_images_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
@@ -170,6 +171,9 @@ TRAIN_PLANES = os.environ.get("DDPO_TRAIN_PLANES", "1") == "1"
 # GEMM output stages that emit planes for a following GEMM (GEGLU -> FF2, block output -> down / up-sampler convolution)
 PLANES_OUT = os.environ.get("DDPO_PLANES_OUT", "1") == "1"
 PLANES_ALL = os.environ.get("DDPO_PLANES_ALL", "0") == "1"      # plane-feed every eligible layer, also where it is measured slower
+# Forward weight planes in the k-blocked layout (ceil(K / 32), N, 32) instead of row-major (N, Kp): every LDS-DMA piece / 16-column
+# group of a k-tile is 1 KiB of consecutive memory (ddpo_gemm_desc.w_layout = 1; same values, same arithmetic: bit-identical results)
+W_KBLOCKED = os.environ.get("DDPO_W_KBLOCKED", "1") == "1"
 
 
 class Planes:
@@ -457,8 +461,11 @@ def pack_weights(w, bwd=True):
     Kp = (K + 7) // 8 * 8
     ent = PACKED.get(w.data_ptr())
     mk = lambda *s: torch.zeros(*s, dtype=torch.int16, device=w.device)
-    if ent is None or ent["K"] != K or ent["N"] != N:
-        ent = dict(K=K, N=N, fwd=(mk(N, Kp), mk(N, Kp), Kp), bwd=None)
+    lay = 1 if (W_KBLOCKED and N % 4 == 0) else 0
+    if lay:
+        Kp = (K + 31) // 32 * 32             # k-blocked planes: whole 32-wide k blocks (zero padded)
+    if ent is None or ent["K"] != K or ent["N"] != N or ent.get("w_layout", 0) != lay:
+        ent = dict(K=K, N=N, fwd=(mk(N, Kp), mk(N, Kp), Kp), bwd=None, w_layout=lay)
         PACKED[w.data_ptr()] = ent
     if bwd and ent["bwd"] is None:
         ent["bwd"] = (mk(K, N), mk(K, N))
@@ -466,7 +473,12 @@ def pack_weights(w, bwd=True):
         ent["geglu"]["stale"] = True          # re-ordered GEGLU planes (pack_weights_geglu) no longer match w
     fh, fl, _ = ent["fwd"]
     bh, bl = ent["bwd"] if ent["bwd"] is not None else (None, None)
-    _check(load().ddpo_pack_weights_bf16(_p(w), K, N, Kp, _p(fh), _p(fl), _p(bh), _p(bl), _stream()), "ddpo_pack_weights_bf16")
+    if ent["w_layout"] == 1:
+        _check(load().ddpo_pack_weights_bf16_kblocked(_p(w), K, N, _p(fh), _p(fl), _stream()), "ddpo_pack_weights_bf16_kblocked")
+        if bh is not None:               # data-gradient planes keep the original (K, N) order: the plain split of w, no transpose
+            _check(load().ddpo_split_planes_bf16(_p(w), N, _p(bh), _p(bl), N, K, N, _stream()), "ddpo_split_planes_bf16")
+    else:
+        _check(load().ddpo_pack_weights_bf16(_p(w), K, N, Kp, _p(fh), _p(fl), _p(bh), _p(bl), _stream()), "ddpo_pack_weights_bf16")
     return ent
 
 
@@ -485,11 +497,14 @@ def pack_weights_geglu(w, bias):
         idx = torch.arange(F, device=w.device).view(F // 32, 1, 32)
         perm = torch.cat([idx, idx + F], dim=1).reshape(-1)               # [a_0 | gate_0 | a_1 | gate_1 | ...]
         mk = lambda: torch.zeros(N, K, dtype=torch.int16, device=w.device)
-        ent["geglu"] = dict(perm=perm, hi=mk(), lo=mk(), bias=torch.empty(N, dtype=torch.float32, device=w.device))
+        ent["geglu"] = dict(perm=perm, hi=mk(), lo=mk(), bias=torch.empty(N, dtype=torch.float32, device=w.device), w_layout=1 if W_KBLOCKED else 0)
     g = ent["geglu"]
     wp = w.index_select(1, g["perm"]).contiguous()
     torch.index_select(bias, 0, g["perm"], out=g["bias"])
-    _check(load().ddpo_pack_weights_bf16(_p(wp), K, N, K, _p(g["hi"]), _p(g["lo"]), None, None, _stream()), "ddpo_pack_weights_bf16")
+    if g["w_layout"] == 1:               # K % 32 == 0 here: (K / 32, N, 32) has the element count of (N, K)
+        _check(load().ddpo_pack_weights_bf16_kblocked(_p(wp), K, N, _p(g["hi"]), _p(g["lo"]), _stream()), "ddpo_pack_weights_bf16_kblocked")
+    else:
+        _check(load().ddpo_pack_weights_bf16(_p(wp), K, N, K, _p(g["hi"]), _p(g["lo"]), None, None, _stream()), "ddpo_pack_weights_bf16")
     g["stale"] = False
     return True
 
@@ -525,6 +540,7 @@ def linear_geglu(x, w, out=None, planes_out=False):
     d.alpha = 1.0
     d.M, d.N, d.K = int(M), int(N), int(K)
     d.epilogue = 1
+    d.w_layout = g["w_layout"]
     npass = 3 if current_datapath() == "bf16x3" else 1
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -591,6 +607,8 @@ def gemm_conv(src, w, *, M, N, K, bias=None, rowbias=None, rows_per_batch=0, res
         for k in ("ksize", "stride", "pad", "upsample", "B", "H", "W", "Cin", "OH", "OW"):
             setattr(d, k, int(conv[k]))
     route = None if w_trans else _bf16_route(w, K, N, conv, False)
+    if route is not None:
+        d.w_layout = PACKED[w.data_ptr()].get("w_layout", 0)
     if opl is not None and (route is None or route[3] != 3):
         raise DdpoHipError("a plane-emitting GEMM needs the bf16x3 datapath and registered weight planes (check planes_out_ok)")
     if pl is not None and (route is None or route[3] != 3 or (conv["Cin"] if conv else K) % 32 or ld_src is not None):

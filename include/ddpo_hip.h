@@ -162,6 +162,13 @@ typedef struct {
    * NULL (planes only).  Needs the vector output stage (N, ld_out, ld_res, ld_rowbias % 4 == 0, 16-byte aligned
    * pointers); DDPO_EINVAL otherwise.  With epilogue == 1 the planes hold the N/2 GEGLU outputs. */
   uint16_t* out_hi; uint16_t* out_lo; int ld_planes;
+  /* layout of the forward weight planes handed to ddpo_gemm_conv_fwd_bf16 / _planes (ABI v6):
+   *   0: row-major (N, ldw) bf16, k contiguous per output column (ddpo_pack_weights_bf16);
+   *   1: k-blocked (ceil(Kp / 32), N, 32) bf16 (ddpo_pack_weights_bf16_kblocked): the 32 k of one k-tile of all N columns are ONE
+   *      contiguous block, so a 1 KiB LDS-DMA piece of the weight operand (16 columns x 64 B) is 1 KiB of consecutive memory =
+   *      8 full 128-byte cache lines instead of 16 half lines at the row stride — the weight stream of the k-loop measured
+   *      1.25-1.4x faster per CU (tools/native/dma_bench, profiles/r03_dma_bench.log).  `ldw` is ignored.  Not with w_dgrad. */
+  int w_layout;
 } ddpo_gemm_desc;
 int ddpo_gemm_conv_fwd(const ddpo_gemm_desc* d, void* stream);
 /* Data gradients reuse ddpo_gemm_conv_fwd: src = dY, w = forward kernel with w_trans=1, w_dgrad=1, and for the
@@ -189,6 +196,8 @@ int ddpo_gemm_conv_fwd_bf16(const ddpo_gemm_desc* d, const uint16_t* w_hi, const
 int ddpo_gemm_conv_fwd_bf16_planes(const ddpo_gemm_desc* d, const uint16_t* a_hi, const uint16_t* a_lo, int lda,
                                    const uint16_t* w_hi, const uint16_t* w_lo, int ldw, void* ws, size_t ws_bytes,
                                    void* stream);
+/* fp32 W (K, N) -> bf16 hi / lo planes in the k-blocked forward layout (ceil(K / 32), N, 32), zero padded in k (w_layout = 1). */
+int ddpo_pack_weights_bf16_kblocked(const float* w, int K, int N, uint16_t* fwd_hi, uint16_t* fwd_lo, void* stream);
 /* x:(rows, cols) fp32, row stride ldx -> hi / lo bf16 planes (rows, ld_out): hi = bf16(x), lo = bf16(x - hi). */
 int ddpo_split_planes_bf16(const float* x, int ldx, uint16_t* hi, uint16_t* lo, int ld_out, int64_t rows, int cols,
                            void* stream);

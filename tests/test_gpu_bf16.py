@@ -268,3 +268,47 @@ def test_bfloat16_dtype_path_is_held_to_the_reference_bf16_arithmetic(datapath, 
     monkeypatch.delenv("DDPO_DATAPATH", raising=False)
     load_unet(None, pretrained_model="none", dtype="float32", device=DEV, seed=7)
     assert L.DATAPATH == "bf16x3"
+
+
+@pytest.mark.parametrize("case", [("dense", 1000, 320, 320), ("dense", 4096, 1280, 640), ("dense", 300, 40, 64), ("dense", 16, 1280, 320),
+                                  ("conv", 2, 32, 320, 320, 3), ("conv", 2, 16, 64, 96, 3), ("conv", 3, 12, 8, 16, 3), ("conv", 1, 64, 320, 320, 1)])
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16"])
+def test_kblocked_weight_planes_are_bit_identical_to_row_major(datapath, monkeypatch, mode, case):
+    """ddpo_gemm_desc.w_layout = 1 (forward weight planes stored (ceil(K/32), N, 32), ABI v6) changes WHERE the loaders fetch the
+    weight operand from, not what they fetch: every kernel family (generic pointer-addressed loader for Cin % 32 != 0, buffer-addressed
+    fp32-fed, plane-fed LDS-DMA, split-K, GEGLU output stage) must give bit-identical results with both layouts."""
+    L.DATAPATH = mode
+    g = torch.Generator().manual_seed(11)
+    outs = []
+    for kb in (False, True):
+        monkeypatch.setattr(L, "W_KBLOCKED", kb)
+        L.PACKED.clear()
+        if case[0] == "dense":
+            _, M, K, N = case
+            x = torch.randn(M, K, generator=torch.Generator().manual_seed(5)).to(DEV)
+            w = (torch.randn(K, N, generator=torch.Generator().manual_seed(6)) / math.sqrt(K)).to(DEV)
+            b = torch.randn(N, generator=torch.Generator().manual_seed(7)).to(DEV)
+            ent = L.pack_weights(w)
+            assert ent["w_layout"] == (1 if kb else 0)
+            res = [L.linear(x, w, b)]
+            if mode == "bf16x3" and L.planes_ok(w, K, M):
+                res.append(L.linear(L.split_planes(x), w, b))
+            if N % 128 == 0 and K % 32 == 0 and L.pack_weights_geglu(w, b):
+                res.append(L.linear_geglu(x, w))
+            dy = torch.randn(M, N, generator=torch.Generator().manual_seed(8)).to(DEV)
+            res.append(L.linear_dgrad(dy, w))                      # data gradient: the (K, N)-ordered planes are layout independent
+        else:
+            _, B, H, Cin, Cout, ks = case
+            x = torch.randn(B * H * H, Cin, generator=torch.Generator().manual_seed(5)).to(DEV)
+            w = (torch.randn(ks, ks, Cin, Cout, generator=torch.Generator().manual_seed(6)) / math.sqrt(ks * ks * Cin)).to(DEV)
+            b = torch.randn(Cout, generator=torch.Generator().manual_seed(7)).to(DEV)
+            L.pack_weights(w)
+            res = [L.conv2d(x, w, b, B, H, H, Cin, Cout, ks)[0]]
+            if mode == "bf16x3" and L.planes_ok(w, Cin, B * H * H):
+                res.append(L.conv2d(L.split_planes(x), w, b, B, H, H, Cin, Cout, ks)[0])
+            dy = torch.randn(B * H * H, Cout, generator=torch.Generator().manual_seed(8)).to(DEV)
+            res.append(L.conv2d_dgrad(dy, w, B, H, H, Cin, Cout, ks))
+        outs.append(res)
+    assert len(outs[0]) == len(outs[1]) >= 2
+    for a, bb in zip(*outs):
+        assert torch.equal(a, bb)

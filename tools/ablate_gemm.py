@@ -22,7 +22,7 @@ def run(M, K, N, conv=None):
         x = torch.randn(M, K, device=dev); w = torch.randn(K, N, device=dev) * 0.02
     L.pack_weights(w)
     ent = L.PACKED[w.data_ptr()]
-    hi, lo, ldw = ent["fwd"]
+    hi, lo, ldw = ent["fwd"]      # row-major planes: run with DDPO_W_KBLOCKED=0
     out = torch.empty(M, N, device=dev)
     d = L.GemmDesc()
     d.src = x.data_ptr(); d.ld_src = x.shape[1]; d.out = out.data_ptr(); d.ld_out = N; d.alpha = 1.0

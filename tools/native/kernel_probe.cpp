@@ -120,6 +120,16 @@ static float time_cold_ms(int iters, const std::function<void()>& fn, const std:
   HIP_OK(hipEventDestroy(e0)); HIP_OK(hipEventDestroy(e1));
   return (float)(total / iters);
 }
+static bool probe_wkblk() { const char* e = getenv("PROBE_WKBLK"); return e && atoi(e) != 0; }     // k-blocked weight planes (w_layout = 1)
+static void pack_w(const float* w, int K, int N, int Kp, uint16_t* hi, uint16_t* lo, ddpo_gemm_desc* d0, ddpo_gemm_desc* d1 = nullptr) {
+  if (probe_wkblk()) {
+    ABI_OK(ddpo_pack_weights_bf16_kblocked(w, K, N, hi, lo, nullptr));
+    d0->w_layout = 1;
+    if (d1) d1->w_layout = 1;
+  } else {
+    ABI_OK(ddpo_pack_weights_bf16(w, K, N, Kp, hi, lo, nullptr, nullptr, nullptr));
+  }
+}
 static bool probe_cold() { const char* e = getenv("PROBE_COLD"); return e && atoi(e) != 0; }
 
 // ------------------------------------------------------------------------------------------------ gemm / conv
@@ -135,11 +145,11 @@ static void run_gemm(int B, int H, int Cin, int Cout, int ks, int stride, int up
   const int K = conv ? ks * ks * Cin : Cin, N = Cout, Kp = (K + 7) / 8 * 8;
   Dev src(conv ? (int64_t)B * H * H * Cin : M * K, 11, 1.0f), w((int64_t)K * N, 12, 1.0f / sqrtf((float)K)), bias(N, 13, 0.5f);
   float* out = (float*)dalloc((size_t)M * N * 4);
-  uint16_t* hi = (uint16_t*)dalloc((size_t)N * Kp * 2);
-  uint16_t* lo = (uint16_t*)dalloc((size_t)N * Kp * 2);
-  ABI_OK(ddpo_pack_weights_bf16(w.p, K, N, Kp, hi, lo, nullptr, nullptr, nullptr));
+  uint16_t* hi = (uint16_t*)dalloc((size_t)N * ((Kp + 31) / 32 * 32) * 2);
+  uint16_t* lo = (uint16_t*)dalloc((size_t)N * ((Kp + 31) / 32 * 32) * 2);
   ddpo_gemm_desc d;
   memset(&d, 0, sizeof(d));
+  pack_w(w.p, K, N, Kp, hi, lo, &d);
   d.src = src.p; d.ld_src = conv ? Cin : K;
   d.bias = bias.p; d.out = out; d.ld_out = N; d.alpha = 1.f;
   d.M = (int)M; d.N = N; d.K = K;
@@ -230,12 +240,12 @@ static void run_gemm2(int B, int H, int Cin, int Cout, int ks, int stride, int u
   Dev src(arows * acols, 11, 1.0f), w((int64_t)K * N, 12, 1.0f / sqrtf((float)K)), bias(N, 13, 0.5f), res(M * N, 14, 1.0f);
   float* out1 = (float*)dalloc((size_t)M * N * 4);
   float* out2 = (float*)dalloc((size_t)M * N * 4);
-  uint16_t *hi = (uint16_t*)dalloc((size_t)N * Kp * 2), *lo = (uint16_t*)dalloc((size_t)N * Kp * 2);
+  uint16_t *hi = (uint16_t*)dalloc((size_t)N * ((Kp + 31) / 32 * 32) * 2), *lo = (uint16_t*)dalloc((size_t)N * ((Kp + 31) / 32 * 32) * 2);
   uint16_t *ah = (uint16_t*)dalloc((size_t)arows * acols * 2), *al = (uint16_t*)dalloc((size_t)arows * acols * 2);
-  ABI_OK(ddpo_pack_weights_bf16(w.p, K, N, Kp, hi, lo, nullptr, nullptr, nullptr));
   ABI_OK(ddpo_split_planes_bf16(src.p, acols, ah, al, acols, arows, acols, nullptr));
   ddpo_gemm_desc d;
   memset(&d, 0, sizeof(d));
+  pack_w(w.p, K, N, Kp, hi, lo, &d);
   d.src = src.p; d.ld_src = acols;
   d.bias = bias.p; d.residual = res.p; d.ld_res = N; d.ld_out = N; d.alpha = 1.f;
   d.M = (int)M; d.N = N; d.K = K;
@@ -312,12 +322,12 @@ static void run_ktime(int B, int H, int Cin, int Cout, int ks, int planes, void*
   const int acols = conv ? Cin : K;
   Dev src(arows * acols, 11, 1.0f), w((int64_t)K * N, 12, 1.0f / sqrtf((float)K)), bias(N, 13, 0.5f);
   float* out = (float*)dalloc((size_t)M * N * 4);
-  uint16_t *hi = (uint16_t*)dalloc((size_t)N * Kp * 2), *lo = (uint16_t*)dalloc((size_t)N * Kp * 2);
+  uint16_t *hi = (uint16_t*)dalloc((size_t)N * ((Kp + 31) / 32 * 32) * 2), *lo = (uint16_t*)dalloc((size_t)N * ((Kp + 31) / 32 * 32) * 2);
   uint16_t *ah = (uint16_t*)dalloc((size_t)arows * acols * 2), *al = (uint16_t*)dalloc((size_t)arows * acols * 2);
-  ABI_OK(ddpo_pack_weights_bf16(w.p, K, N, Kp, hi, lo, nullptr, nullptr, nullptr));
   ABI_OK(ddpo_split_planes_bf16(src.p, acols, ah, al, acols, arows, acols, nullptr));
   ddpo_gemm_desc d;
   memset(&d, 0, sizeof(d));
+  pack_w(w.p, K, N, Kp, hi, lo, &d);
   d.src = src.p; d.ld_src = acols; d.bias = bias.p; d.out = out; d.ld_out = N; d.alpha = 1.f;
   d.M = (int)M; d.N = N; d.K = K;
   if (conv) { d.ksize = ks; d.stride = 1; d.pad = pad; d.B = B; d.H = H; d.W = H; d.Cin = Cin; d.OH = OH; d.OW = OH; }
@@ -330,7 +340,7 @@ static void run_ktime(int B, int H, int Cin, int Cout, int ks, int planes, void*
   const float ms = probe_cold() ? time_cold_ms(3, launch, warm) : time_ms(3, launch);
   HIP_OK(hipDeviceSynchronize());
   const int NW = 16384;
-  std::vector<unsigned long long> t((size_t)NW * 8, 0ull);
+  std::vector<unsigned long long> t((size_t)2 * NW * 8, 0ull);
   // poison, run once, read
   {
     std::vector<unsigned long long> z((size_t)NW * 8, 0ull);
@@ -342,7 +352,7 @@ static void run_ktime(int B, int H, int Cin, int Cout, int ks, int planes, void*
   // workgroups of the LAST launch: those whose entry stamp is within the last launch window (max entry - 1 ms)
   unsigned long long tmax = 0;
   for (int i = 0; i < NW; ++i) tmax = std::max(tmax, t[i * 8 + 4 + 3]);
-  double sp = 0, sk = 0, se = 0, mp = 0, mk = 0, me = 0, clk = 0;
+  double sp = 0, sk = 0, se = 0, mp = 0, mk = 0, me = 0, clk = 0, wv = 0, wb = 0;
   unsigned long long first = ~0ull, last = 0;
   int n = 0;
   for (int i = 0; i < NW; ++i) {
@@ -351,13 +361,15 @@ static void run_ktime(int B, int H, int Cin, int Cout, int ks, int planes, void*
     const double p = (r[1] - r[0]) * 0.01, k = (r[2] - r[1]) * 0.01, e = (r[3] - r[2]) * 0.01;
     sp += p; sk += k; se += e; mp = std::max(mp, p); mk = std::max(mk, k); me = std::max(me, e);
     if (r[3] > r[0]) clk += (double)(t[i * 8 + 3] - t[i * 8 + 0]) / ((r[3] - r[0]) * 0.01);
+    wv += (double)t[(size_t)(NW + i) * 8 + 0]; wb += (double)t[(size_t)(NW + i) * 8 + 1];
     first = std::min(first, r[0]); last = std::max(last, r[3]);
     ++n;
   }
   if (conv) printf("ktime conv %dx%d %5d->%5d @%3d^2 B%-3d %s:", ks, ks, Cin, Cout, H, B, planes ? "planes" : "fp32  ");
   else printf("ktime gemm M=%7lld K=%5d N=%5d %s:", (long long)M, K, N, planes ? "planes" : "fp32  ");
-  printf(" event %7.1f us | %5d WGs, span %7.1f us | prologue avg %6.1f max %6.1f | k-loop avg %7.1f max %7.1f (%d k-tiles: %.2f us each) | output avg %6.1f max %6.1f | clock %.0f MHz\n",
-         ms * 1e3, n, (last - first) * 0.01, sp / n, mp, sk / n, mk, K / 32, sk / n / (K / 32), se / n, me, clk / n);
+  const double mhz = clk / n;
+  printf(" event %7.1f us | %5d WGs, span %7.1f us | prologue avg %6.1f max %6.1f | k-loop avg %7.1f max %7.1f (%d k-tiles: %.2f us each; wave 0 waits per k-tile: vmcnt/lgkm %.2f us + barrier %.2f us) | output avg %6.1f max %6.1f | clock %.0f MHz\n",
+         ms * 1e3, n, (last - first) * 0.01, sp / n, mp, sk / n, mk, K / 32, sk / n / (K / 32), wv / n / mhz / (K / 32), wb / n / mhz / (K / 32), se / n, me, mhz);
   fflush(stdout);
   src.release(); w.release(); bias.release();
   HIP_OK(hipFree(out)); HIP_OK(hipFree(hi)); HIP_OK(hipFree(lo)); HIP_OK(hipFree(ah)); HIP_OK(hipFree(al));
