@@ -63,4 +63,11 @@ __device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo) {
   lo.y = cvt_pk_bf16(r2, r3);
 }
 
+// Element offset of (row, channel c) in a bf16 ACTIVATION plane of `rows` rows.  ld > 0: row-major, row stride ld.  ld == 0 (ABI v6):
+// k-blocked, (C / 32, rows, 32) — the 32 channels of one k-tile of CONSECUTIVE rows are consecutive memory, so an LDS-DMA piece
+// of the plane-fed GEMM (16 consecutive rows x 64 B) is 1 KiB contiguous = 8 full cache lines instead of 16 half lines.
+__host__ __device__ __forceinline__ int64_t plane_off(int64_t row, int c, int ld, int64_t rows) {
+  return ld ? row * ld + c : ((int64_t)(c >> 5) * rows + row) * 32 + (c & 31);
+}
+
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }

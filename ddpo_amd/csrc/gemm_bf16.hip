@@ -73,8 +73,9 @@ __device__ __forceinline__ int swz_off(int row, int chunk) { return row * 64 + (
 __device__ __forceinline__ void store_planes4(const ddpo_gemm_desc& d, int64_t row, int col, const float4 v) {
   uint2 h, l;
   split4(v, h, l);
-  *reinterpret_cast<uint2*>(d.out_hi + row * d.ld_planes + col) = h;
-  *reinterpret_cast<uint2*>(d.out_lo + row * d.ld_planes + col) = l;
+  const int64_t o = plane_off(row, col, d.ld_planes, d.M);           // ld_planes == 0: k-blocked planes (ncols / 32, M, 32)
+  *reinterpret_cast<uint2*>(d.out_hi + o) = h;
+  *reinterpret_cast<uint2*>(d.out_lo + o) = l;
 }
 
 // AFFINE: no upsampling / zero-insert in the gather, so the source address of tap (ky,kx) is rowptr + (ky*W + kx)*ld + ci
@@ -498,6 +499,10 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
     const uint32_t lds_a = lds0 + plane * A_BYTES + pr * 1024;                       // + stage * STAGE + i * PAIRS * 1024
     const uint32_t lds_w = lds0 + NPL * A_BYTES + plane * B_BYTES + pr * 1024;
 
+    // activation planes: row-major (rows, ld_src) -> row stride ld_src * 2 B, k-tile advance 64 B; k-blocked (ld_src == 0: (C / 32, rows, 32))
+    // -> row stride 64 B, k-tile advance rows * 64 B (16 consecutive pixels of a piece = 1 KiB of consecutive memory)
+    const uint32_t a_row_b = d.ld_src == 0 ? 64u : (uint32_t)d.ld_src * 2u;
+    const uint32_t a_kt_b = d.ld_src == 0 ? (uint32_t)(conv ? d.B * d.H * d.W : d.M) * 64u : (uint32_t)(BK * 2);
     int aiy0[NA], aix0[NA], apix[NA];
     uint32_t avoff[NA], bvoff[NB];
 #pragma unroll
@@ -515,7 +520,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
         avoff[i] = BUF_OOB;
       } else {
         aiy0[i] = aix0[i] = apix[i] = 0;
-        avoff[i] = valid ? (uint32_t)m * (uint32_t)d.ld_src * 2u + lc16 : BUF_OOB;
+        avoff[i] = valid ? (uint32_t)m * a_row_b + lc16 : BUF_OOB;
       }
     }
     auto set_tap = [&](int tap) {
@@ -526,7 +531,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
         const int iy = aiy0[i] + ky, ix = aix0[i] + kx;
         const bool ok = (unsigned)iy < (unsigned)VH && (unsigned)ix < (unsigned)VW && !(zins && ((iy | ix) & 1));
         const int sy = d.upsample ? (iy >> 1) : iy, sx = d.upsample ? (ix >> 1) : ix;
-        const uint32_t off = (uint32_t)(apix[i] + sy * d.W + sx) * (uint32_t)d.ld_src * 2u + lc16;
+        const uint32_t off = (uint32_t)(apix[i] + sy * d.W + sx) * a_row_b + lc16;
         avoff[i] = ok ? off : BUF_OOB;
       }
     };
@@ -548,7 +553,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
 
     // one k-tile = NA + NB LDS-DMA pieces per wave (issued back to back; nothing of it touches a VGPR besides the offsets)
     auto fill = [&](int stage) {
-      const uint32_t so_a = (uint32_t)cib * 2u, so_w = (uint32_t)kt_next * w_kt_b;
+      const uint32_t so_a = (uint32_t)(cib >> 5) * a_kt_b, so_w = (uint32_t)kt_next * w_kt_b;
       const uint32_t la = lds_a + stage * STAGE, lw = lds_w + stage * STAGE;
 #pragma unroll
       for (int i = 0; i < NA; ++i)
@@ -649,7 +654,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
       const uint32_t lds_w3 = lds0 + 2 * A_STAGE + plane * B_BYTES + pr * 1024;
       int kw_next = kt0;                                   // tap / cib / set_tap follow the ACTIVATION tiles
       auto fill_a = [&](int stage) {
-        const uint32_t so_a = (uint32_t)cib * 2u, la = lds_a3 + stage * A_STAGE;
+        const uint32_t so_a = (uint32_t)(cib >> 5) * a_kt_b, la = lds_a3 + stage * A_STAGE;
 #pragma unroll
         for (int i = 0; i < NA; ++i)
           asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
@@ -1142,10 +1147,11 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const ddpo_gemm_desc
 // plane-emitting output stage: only the vector output stage of the buffer-addressed kernels (and the split-K reduce) writes planes
 static bool planes_out_ok(const ddpo_gemm_desc& d) {
   if (!d.out_hi) return d.out != nullptr && !d.out_lo;
-  if (!d.out_lo || d.ld_planes <= 0 || (d.ld_planes & 3)) return false;
+  if (!d.out_lo || d.ld_planes < 0 || (d.ld_planes & 3)) return false;
   if ((reinterpret_cast<uintptr_t>(d.out_hi) | reinterpret_cast<uintptr_t>(d.out_lo)) & 7) return false;
   const int ncols = d.epilogue == 1 ? d.N / 2 : d.N;
-  if (d.ld_planes < ncols || (d.N & 3)) return false;
+  if (d.ld_planes == 0 ? (ncols & 31) != 0 : d.ld_planes < ncols) return false;      // 0: k-blocked (ncols / 32, M, 32)
+  if (d.N & 3) return false;
   if (d.out && ((d.ld_out & 3) || (reinterpret_cast<uintptr_t>(d.out) & 15))) return false;
   if (d.residual && ((d.ld_res & 3) || (reinterpret_cast<uintptr_t>(d.residual) & 15))) return false;
   if (d.rowbias && ((d.ld_rowbias & 3) || (reinterpret_cast<uintptr_t>(d.rowbias) & 15))) return false;
@@ -1161,12 +1167,12 @@ static bool buf_path_ok(const ddpo_gemm_desc& d, int ldw) {
   if (d.w_layout == 1) ldw = (d.K + 31) / 32 * 32;          // k-blocked planes: Kb * N * 32 elements
   if (d.ksize > 0) {
     if (d.Cin % BF_BK) return false;
-    if ((int64_t)d.B * d.H * d.W * d.ld_src * 4 >= lim) return false;
+    if ((int64_t)d.B * d.H * d.W * (d.ld_src ? d.ld_src : d.Cin) * 4 >= lim) return false;       // ld_src == 0: k-blocked activation planes
     const int64_t wbytes = d.w_dgrad ? (int64_t)d.K * d.N * 2 : (int64_t)d.N * ldw * 2;
     if (wbytes >= lim) return false;
   } else {
     if (d.K % BF_BK) return false;
-    if ((int64_t)d.M * d.ld_src * 4 >= lim || (int64_t)d.N * ldw * 2 >= lim) return false;
+    if ((int64_t)d.M * (d.ld_src ? d.ld_src : d.K) * 4 >= lim || (int64_t)d.N * ldw * 2 >= lim) return false;
   }
   return true;
 }
@@ -1377,7 +1383,7 @@ extern "C" int ddpo_gemm_conv_fwd_bf16(const ddpo_gemm_desc* dp, const uint16_t*
   const ddpo_gemm_desc& d = *dp;
   if (npass != 1 && npass != 3) return DDPO_EINVAL;
   if (npass == 3 && !w_lo) return DDPO_EINVAL;
-  if (!d.src || d.M <= 0 || d.N <= 0 || d.K <= 0 || (d.ld_src & 3) || (reinterpret_cast<uintptr_t>(d.src) & 15)) return DDPO_EINVAL;
+  if (!d.src || d.M <= 0 || d.N <= 0 || d.K <= 0 || d.ld_src <= 0 || (d.ld_src & 3) || (reinterpret_cast<uintptr_t>(d.src) & 15)) return DDPO_EINVAL;
   if ((reinterpret_cast<uintptr_t>(w_hi) & 15) || (w_lo && (reinterpret_cast<uintptr_t>(w_lo) & 15))) return DDPO_EINVAL;
   if (!planes_out_ok(d) || (d.out_hi && !buf_path_ok(d, ldw))) return DDPO_EINVAL;
   if (d.ksize > 0) {
@@ -1402,15 +1408,15 @@ extern "C" int ddpo_gemm_conv_fwd_bf16_planes(const ddpo_gemm_desc* dp, const ui
                                               void* stream) {
   if (!dp || !a_hi || !a_lo || !w_hi || !w_lo) return DDPO_EINVAL;
   ddpo_gemm_desc d = *dp;
-  if (d.M <= 0 || d.N <= 0 || d.K <= 0 || lda <= 0 || (lda & 7) || d.w_dgrad || !planes_out_ok(d)) return DDPO_EINVAL;
+  if (d.M <= 0 || d.N <= 0 || d.K <= 0 || lda < 0 || (lda & 7) || d.w_dgrad || !planes_out_ok(d)) return DDPO_EINVAL;      // lda == 0: k-blocked planes
   if ((reinterpret_cast<uintptr_t>(a_hi) | reinterpret_cast<uintptr_t>(a_lo) | reinterpret_cast<uintptr_t>(w_hi) |
        reinterpret_cast<uintptr_t>(w_lo)) & 15) return DDPO_EINVAL;
   if (d.w_layout != 0 && d.w_layout != 1) return DDPO_EINVAL;
   if (d.w_layout == 0 && (ldw < d.K || (ldw & 7))) return DDPO_EINVAL;
   if (d.ksize > 0) {
     if (d.ksize != 1 && d.ksize != 3) return DDPO_EINVAL;
-    if (d.K != d.ksize * d.ksize * d.Cin || d.M != d.B * d.OH * d.OW || d.upsample < 0 || d.upsample > 2 || lda < d.Cin) return DDPO_EINVAL;
-  } else if (lda < d.K) {
+    if (d.K != d.ksize * d.ksize * d.Cin || d.M != d.B * d.OH * d.OW || d.upsample < 0 || d.upsample > 2 || (lda && lda < d.Cin)) return DDPO_EINVAL;
+  } else if (lda && lda < d.K) {
     return DDPO_EINVAL;
   }
   d.src = reinterpret_cast<const float*>(a_hi);      // the kernel reads d.src / d.w as the two planes and d.ld_src in elements
@@ -1528,13 +1534,15 @@ __global__ void __launch_bounds__(256) split_planes_kernel(const float* __restri
     const int c = (int)(i - r * cols4) << 2;
     uint2 h, l;
     split4(*reinterpret_cast<const float4*>(x + r * ldx + c), h, l);
-    *reinterpret_cast<uint2*>(hi + r * ld_out + c) = h;
-    *reinterpret_cast<uint2*>(lo + r * ld_out + c) = l;
+    const int64_t o = plane_off(r, c, ld_out, rows);
+    *reinterpret_cast<uint2*>(hi + o) = h;
+    *reinterpret_cast<uint2*>(lo + o) = l;
   }
 }
 
 extern "C" int ddpo_split_planes_bf16(const float* x, int ldx, uint16_t* hi, uint16_t* lo, int ld_out, int64_t rows, int cols, void* stream) {
-  if (!x || !hi || !lo || rows <= 0 || cols <= 0 || (cols & 3) || (ldx & 3) || (ld_out & 3) || ldx < cols || ld_out < cols) return DDPO_EINVAL;
+  if (!x || !hi || !lo || rows <= 0 || cols <= 0 || (cols & 3) || (ldx & 3) || (ld_out & 3) || ldx < cols) return DDPO_EINVAL;
+  if (ld_out == 0 ? (cols & 31) != 0 : ld_out < cols) return DDPO_EINVAL;          // ld_out == 0: k-blocked planes (cols / 32, rows, 32)
   if ((reinterpret_cast<uintptr_t>(x) & 15) || ((reinterpret_cast<uintptr_t>(hi) | reinterpret_cast<uintptr_t>(lo)) & 7)) return DDPO_EINVAL;
   int64_t blocks = (rows * (cols >> 2) + 255) / 256;
   if (blocks > 8192) blocks = 8192;
@@ -1619,7 +1627,14 @@ __global__ void __launch_bounds__(BF_THREADS) gemm_wgrad_bf16_kernel(const ddpo_
       poy[p][e] = conv ? (m / d.OW) % d.OH : 0;
       pb[p][e] = conv ? m / (d.OW * d.OH) : 0;
     }
-  const int64_t tap_off = conv ? ((int64_t)dky * d.W + dkx) * d.ld_src + ci : kg;
+  // element strides / channel terms of the two operands.  A k-blocked PLANE operand (ld == 0: (C / 32, rows, 32), ABI v6) has pixel
+  // stride 32 and the channel quad's block base + offset inside the block as its "channel term"; everything below is written on these.
+  const bool kbA = APLN && d.ld_src == 0, kbB = BPLN && d.ld_w == 0;
+  const int64_t rowsA = conv ? (int64_t)d.B * d.H * d.W : (int64_t)d.M;
+  const int lda_e = kbA ? 32 : d.ld_src, ldb_e = kbB ? 32 : d.ld_w;
+  const int64_t a_c0 = kbA ? (int64_t)(ci >> 5) * rowsA * 32 + (ci & 31) : (int64_t)ci;          // dense: ci == kg
+  const int64_t b_c0 = kbB ? (int64_t)(ng >> 5) * (int64_t)d.M * 32 + (ng & 31) : (int64_t)ng;
+  const int64_t tap_off = conv ? ((int64_t)dky * d.W + dkx) * lda_e + a_c0 : a_c0;
 
   float4 ra[2][2], rb[2][2];          // fp32 operands; a plane operand keeps (hi.x, hi.y, lo.x, lo.y) raw bits in the same registers
   auto as_f4 = [](const uint2 h, const uint2 l) {
@@ -1632,7 +1647,7 @@ __global__ void __launch_bounds__(BF_THREADS) gemm_wgrad_bf16_kernel(const ddpo_
   int rl_oy = 0, rl_ox = 0;            // image row / column of the CURRENT k-tile's first pixel (uniform)
   // a tap above / left of the tile has a NEGATIVE offset relative to its pixel: the activation descriptors start `rl_guard` bytes in front of
   // the tensor so that every offset is non-negative (such elements are only ever fetched when their tap is inside the image, i.e. in range)
-  const int64_t rl_guard = conv ? (int64_t)(d.W + 1) * d.ld_src * (int64_t)ESA : 0;
+  const int64_t rl_guard = conv ? (int64_t)(d.W + 1) * lda_e * (int64_t)ESA : 0;
   __amdgpu_buffer_rsrc_t rl_ra0 = make_rsrc(reinterpret_cast<const char*>(APLN ? (const void*)a_hi : (const void*)d.src) - rl_guard),
                          rl_ra1 = make_rsrc(reinterpret_cast<const char*>(APLN ? (const void*)a_lo : (const void*)d.src) - rl_guard);
   __amdgpu_buffer_rsrc_t rl_rb0 = make_rsrc(BPLN ? (const void*)b_hi : (const void*)d.w), rl_rb1 = make_rsrc(BPLN ? (const void*)b_lo : (const void*)d.w);
@@ -1649,14 +1664,14 @@ __global__ void __launch_bounds__(BF_THREADS) gemm_wgrad_bf16_kernel(const ddpo_
         const int x_e = (conv && d.OW < BK) ? eoff - dy_e * d.OW : eoff;
         rl_cy[p][e] = dy_e + dky;
         rl_cx[p][e] = x_e + dkx;
-        const int64_t ao = ((int64_t)(m_begin + eoff) * d.ld_src + tap_off) * (int64_t)ESA + rl_guard;
-        const int64_t bo = ((int64_t)(m_begin + eoff) * d.ld_w + ng) * (int64_t)ESB;
+        const int64_t ao = ((int64_t)(m_begin + eoff) * lda_e + tap_off) * (int64_t)ESA + rl_guard;
+        const int64_t bo = ((int64_t)(m_begin + eoff) * ldb_e + b_c0) * (int64_t)ESB;
         rl_va[p][e] = (kvalid && ao >= 0 && ao < 0x7FFFFFF0ll) ? (uint32_t)ao : BUF_OOB;
         rl_vb[p][e] = (nvalid && bo >= 0 && bo < 0x7FFFFFF0ll) ? (uint32_t)bo : BUF_OOB;
       }
   }
   auto load_tile_rows = [&](int kt) {
-    const uint32_t so_a = (uint32_t)kt * (uint32_t)(BK * d.ld_src) * ESA, so_b = (uint32_t)kt * (uint32_t)(BK * d.ld_w) * ESB;
+    const uint32_t so_a = (uint32_t)kt * (uint32_t)(BK * lda_e) * ESA, so_b = (uint32_t)kt * (uint32_t)(BK * ldb_e) * ESB;
 #pragma unroll
     for (int p = 0; p < 2; ++p)
 #pragma unroll
@@ -1700,13 +1715,13 @@ __global__ void __launch_bounds__(BF_THREADS) gemm_wgrad_bf16_kernel(const ddpo_
         float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
         if (m < m_end) {
           bool ok = kvalid;
-          int64_t aoff = (int64_t)m * d.ld_src + tap_off;
+          int64_t aoff = (int64_t)m * lda_e + tap_off;
           if (conv) {
             const int iy = poy[p][e] * d.stride + dky, ix = pox[p][e] * d.stride + dkx;       // virtual (upsampled) coordinates
             ok = ok && iy >= 0 && iy < VH && ix >= 0 && ix < VW;
             if (!simple) {
               const int sy = d.upsample ? (iy >> 1) : iy, sx = d.upsample ? (ix >> 1) : ix;
-              aoff = ((int64_t)(pb[p][e] * d.H + sy) * d.W + sx) * d.ld_src + ci;
+              aoff = ((int64_t)(pb[p][e] * d.H + sy) * d.W + sx) * lda_e + a_c0;
             }
           }
           if (ok) {
@@ -1714,7 +1729,7 @@ __global__ void __launch_bounds__(BF_THREADS) gemm_wgrad_bf16_kernel(const ddpo_
             else va = *reinterpret_cast<const float4*>(d.src + aoff);
           }
           if (nvalid) {
-            const int64_t boff = (int64_t)m * d.ld_w + ng;
+            const int64_t boff = (int64_t)m * ldb_e + b_c0;
             if (BPLN) vb = as_f4(*reinterpret_cast<const uint2*>(b_hi + boff), *reinterpret_cast<const uint2*>(b_lo + boff));
             else vb = *reinterpret_cast<const float4*>(d.w + boff);
           }
@@ -1824,6 +1839,10 @@ static int wgrad_bf16x3(const ddpo_gemm_desc* dp, const uint16_t* a_hi, const ui
   if (!b_hi && (reinterpret_cast<uintptr_t>(d.w) & 15)) return DDPO_EINVAL;
   if ((reinterpret_cast<uintptr_t>(a_hi) | reinterpret_cast<uintptr_t>(a_lo) | reinterpret_cast<uintptr_t>(b_hi) | reinterpret_cast<uintptr_t>(b_lo)) & 7)
     return DDPO_EINVAL;
+  // ld == 0 marks a k-blocked PLANE operand (channels / 32, rows, 32): planes only, whole 32-channel blocks
+  if (d.ld_src < 0 || d.ld_w < 0) return DDPO_EINVAL;
+  if (d.ld_src == 0 && (!a_hi || ((d.ksize > 0 ? d.Cin : d.K) & 31))) return DDPO_EINVAL;
+  if (d.ld_w == 0 && (!b_hi || (d.N & 31))) return DDPO_EINVAL;
   if (d.ksize > 0) {
     if (d.ksize != 1 && d.ksize != 3) return DDPO_EINVAL;
     if ((d.Cin & 3) || d.K != d.ksize * d.ksize * d.Cin || d.M != d.B * d.OH * d.OW) return DDPO_EINVAL;
@@ -1859,8 +1878,9 @@ static int wgrad_bf16x3(const ddpo_gemm_desc* dp, const uint16_t* a_hi, const ui
   static const int rows_mode = [] { const char* e = getenv("DDPO_WGRAD_ROWS"); return e ? atoi(e) : 1; }();
   const bool conv_ = d.ksize > 0;
   const bool simple_ = !conv_ || (d.stride == 1 && d.upsample == 0 && d.OH == d.H && d.OW == d.W);
-  const int64_t a_bytes = (int64_t)d.M * d.ld_src * (a_hi ? 2 : 4), b_bytes = (int64_t)d.M * d.ld_w * (b_hi ? 2 : 4);
-  const bool rows_ok = rows_mode && simple_ && (d.M % 32) == 0 && a_bytes + (conv_ ? (int64_t)(d.W + 1) * d.ld_src * 4 : 0) < 0x7FFFFFF0ll && b_bytes < 0x7FFFFFF0ll &&
+  const int64_t lda_b = d.ld_src ? d.ld_src : (conv_ ? d.Cin : d.K), ldb_b = d.ld_w ? d.ld_w : d.N;      // k-blocked planes: the same bytes in all
+  const int64_t a_bytes = (int64_t)d.M * lda_b * (a_hi ? 2 : 4), b_bytes = (int64_t)d.M * ldb_b * (b_hi ? 2 : 4);
+  const bool rows_ok = rows_mode && simple_ && (d.M % 32) == 0 && a_bytes + (conv_ ? (int64_t)(d.W + 1) * lda_b * 4 : 0) < 0x7FFFFFF0ll && b_bytes < 0x7FFFFFF0ll &&
                        (!conv_ || (((d.OW % 32) == 0 || (32 % d.OW) == 0) && ((d.OH * d.OW) % 32) == 0));
 #define WG_LAUNCH(A, B)                                                                                                                        \
   do {                                                                                                                                         \

@@ -137,11 +137,11 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__
         // both hi halves and writes 8 channels of the hi plane, the odd lane both lo halves and writes the lo plane
         const bool odd = threadIdx.x & 1;
         const uint32_t rx = __shfl_xor(odd ? h.x : l.x, 1, 64), ry = __shfl_xor(odd ? h.y : l.y, 1, 64);
-        if (!odd) *reinterpret_cast<uint4*>(y_hi + row * ldy + c) = make_uint4(h.x, h.y, rx, ry);
-        else *reinterpret_cast<uint4*>(y_lo + row * ldy + c - 4) = make_uint4(rx, ry, l.x, l.y);
+        if (!odd) *reinterpret_cast<uint4*>(y_hi + plane_off(row, c, ldy, (int64_t)B * HW)) = make_uint4(h.x, h.y, rx, ry);
+        else *reinterpret_cast<uint4*>(y_lo + plane_off(row, c - 4, ldy, (int64_t)B * HW)) = make_uint4(rx, ry, l.x, l.y);
       } else {
-        *reinterpret_cast<uint2*>(y_hi + row * ldy + c) = h;
-        *reinterpret_cast<uint2*>(y_lo + row * ldy + c) = l;
+        *reinterpret_cast<uint2*>(y_hi + plane_off(row, c, ldy, (int64_t)B * HW)) = h;
+        *reinterpret_cast<uint2*>(y_lo + plane_off(row, c, ldy, (int64_t)B * HW)) = l;
       }
     } else {
       *reinterpret_cast<float4*>(y + row * ldy + c) = o;
@@ -170,6 +170,7 @@ static int groupnorm_fwd_impl(const float* x, int ldx, float* y, uint16_t* y_hi,
   if (!x || !gamma || !beta || !ws || !stats || B <= 0 || HW <= 0 || C <= 0 || G <= 0 || G > GN_MAXG) return DDPO_EINVAL;
   if (planes ? (!y_hi || !y_lo) : false) return DDPO_EINVAL;
   if ((C & 3) || (C % G) || (ldx & 3) || (ldy & 3) || C > GN_MAXC || B > 65535) return DDPO_EINVAL;
+  if (ldy == 0 && (!planes || (C & 31))) return DDPO_EINVAL;          // ldy == 0: k-blocked planes (C / 32, B*HW, 32)
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(ws) | reinterpret_cast<uintptr_t>(stats)) & 15) return DDPO_EINVAL;
   if (planes ? ((reinterpret_cast<uintptr_t>(y_hi) | reinterpret_cast<uintptr_t>(y_lo)) & 7) != 0 : (reinterpret_cast<uintptr_t>(y) & 15) != 0)
     return DDPO_EINVAL;
@@ -225,7 +226,7 @@ template <bool PL>
 __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         int rows, int C, float eps, uint16_t* __restrict__ y_hi,
-                                                        uint16_t* __restrict__ y_lo, int pair) {
+                                                        uint16_t* __restrict__ y_lo, int pair, int ldy = -1) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -270,11 +271,11 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
         if (pair) {           // lane-paired 16-byte stores (see gn_apply_kernel); C % 8 == 0 keeps both lanes of a pair inside the row
           const bool odd = lane & 1;
           const uint32_t rx = __shfl_xor(odd ? h.x : l.x, 1, 64), ry = __shfl_xor(odd ? h.y : l.y, 1, 64);
-          if (!odd) *reinterpret_cast<uint4*>(y_hi + (int64_t)row * C + (c4 << 2)) = make_uint4(h.x, h.y, rx, ry);
-          else *reinterpret_cast<uint4*>(y_lo + (int64_t)row * C + (c4 << 2) - 4) = make_uint4(rx, ry, l.x, l.y);
+          if (!odd) *reinterpret_cast<uint4*>(y_hi + plane_off(row, c4 << 2, ldy, rows)) = make_uint4(h.x, h.y, rx, ry);
+          else *reinterpret_cast<uint4*>(y_lo + plane_off(row, (c4 << 2) - 4, ldy, rows)) = make_uint4(rx, ry, l.x, l.y);
         } else {
-          *reinterpret_cast<uint2*>(y_hi + (int64_t)row * C + (c4 << 2)) = h;
-          *reinterpret_cast<uint2*>(y_lo + (int64_t)row * C + (c4 << 2)) = l;
+          *reinterpret_cast<uint2*>(y_hi + plane_off(row, c4 << 2, ldy, rows)) = h;
+          *reinterpret_cast<uint2*>(y_lo + plane_off(row, c4 << 2, ldy, rows)) = l;
         }
       } else {
         *reinterpret_cast<float4*>(yr + (c4 << 2)) = o;
@@ -293,13 +294,14 @@ extern "C" int ddpo_layernorm_fwd(const float* x, float* y, const float* gamma, 
 }
 
 extern "C" int ddpo_layernorm_fwd_planes(const float* x, uint16_t* y_hi, uint16_t* y_lo, const float* gamma, const float* beta,
-                                         int rows, int C, float eps, void* stream) {
+                                         int rows, int C, float eps, int kblocked, void* stream) {
   if (!x || !y_hi || !y_lo || !gamma || !beta || rows <= 0 || C <= 0 || (C & 3) || C > 256 * LN_MAXV) return DDPO_EINVAL;
+  if (kblocked && (C & 31)) return DDPO_EINVAL;
   if ((reinterpret_cast<uintptr_t>(y_hi) | reinterpret_cast<uintptr_t>(y_lo)) & 7) return DDPO_EINVAL;
   float* const nof = nullptr;
   const int pair = ((C & 7) == 0 && ((reinterpret_cast<uintptr_t>(y_hi) | reinterpret_cast<uintptr_t>(y_lo)) & 15) == 0) ? 1 : 0;
   hipLaunchKernelGGL(layernorm_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, as_stream(stream), x, nof, gamma, beta, rows, C, eps, y_hi,
-                     y_lo, pair);
+                     y_lo, pair, kblocked ? 0 : C);
   DDPO_LAUNCH_CHECK();
   return DDPO_OK;
 }

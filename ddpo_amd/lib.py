@@ -54,6 +54,10 @@ _SIGS = {
     "ddpo_ddim_logprob_ppo_fwd_bwd_grouped": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                       c_float, c_float, c_int, POINTER(DdimConsts), c_void_p, c_void_p,
                                                       c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ddpo_rwr_noisy_latents": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_int, c_int, c_int,
+                                       c_void_p]),
+    "ddpo_rwr_mse_fwd_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                     c_void_p]),
     "ddpo_grad_sqnorm": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_void_p]),
     "ddpo_adamw_bf16mu_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_double, c_double,
                                        c_double, c_double, c_double, c_double, c_double, c_int, c_int, c_int, c_void_p]),
@@ -71,7 +75,7 @@ _SIGS = {
     "ddpo_split_planes_bf16": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p]),
     "ddpo_groupnorm_fwd_planes": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                           c_float, c_int, c_void_p, c_void_p, c_void_p]),
-    "ddpo_layernorm_fwd_planes": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
+    "ddpo_layernorm_fwd_planes": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p]),
     "ddpo_pack_weights_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ddpo_pack_weights_bf16_kblocked": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "ddpo_attention_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int,
@@ -174,15 +178,31 @@ PLANES_ALL = os.environ.get("DDPO_PLANES_ALL", "0") == "1"      # plane-feed eve
 # Forward weight planes in the k-blocked layout (ceil(K / 32), N, 32) instead of row-major (N, Kp): every LDS-DMA piece / 16-column
 # group of a k-tile is 1 KiB of consecutive memory (ddpo_gemm_desc.w_layout = 1; same values, same arithmetic: bit-identical results)
 W_KBLOCKED = os.environ.get("DDPO_W_KBLOCKED", "1") == "1"
+# The ACTIVATION planes can be stored the same way — (C / 32, rows, 32) when C % 32 == 0 (plane row stride 0 in the C ABI), written by
+# the plane-emitting producers (GroupNorm / LayerNorm / GEMM output stages / split_planes), read by the plane-fed GEMMs and wgrads;
+# bit-identical (tests/test_gpu_planes.py runs both storages) — but it is OFF: interleaved A/B on one box, sampling 3.522 / 3.543
+# (row-major) vs 3.555 / 3.532 (k-blocked) images/s, training 48.7 / 49.1 vs 48.9 / 48.7 (profiles/r03_ab_akblk_bench.log): the
+# activation operand was just written by the previous kernel and is served from L2 / Infinity Cache either way, while the producers'
+# stores get ten 64-byte segments per row instead of one 640-byte run.  The weight operand, streamed from HBM by every launch, is
+# where the layout pays (+3.0 %).
+A_KBLOCKED = os.environ.get("DDPO_A_KBLOCKED", "0") == "1"
 
 
 class Planes:
-    """An activation (rows, C) stored as bf16 hi / lo planes (two int16 tensors): x ~= hi + lo."""
-    __slots__ = ("hi", "lo")
+    """An activation (rows, C) stored as bf16 hi / lo planes (two int16 buffers): x ~= hi + lo.  Storage is row-major (rows, C), or —
+    when A_KBLOCKED and C % 32 == 0 — k-blocked (C / 32, rows, 32); `ld` is the plane row stride handed to the C ABI (0 = k-blocked)."""
+    __slots__ = ("hi", "lo", "rows", "C", "kblocked")
 
     def __init__(self, rows, C, device):
-        self.hi = torch.empty(rows, C, dtype=torch.int16, device=device)
-        self.lo = torch.empty(rows, C, dtype=torch.int16, device=device)
+        self.rows, self.C = int(rows), int(C)
+        self.kblocked = bool(A_KBLOCKED and C % 32 == 0)
+        shp = (C // 32, rows, 32) if self.kblocked else (rows, C)
+        self.hi = torch.empty(shp, dtype=torch.int16, device=device)
+        self.lo = torch.empty(shp, dtype=torch.int16, device=device)
+
+    @property
+    def ld(self):
+        return 0 if self.kblocked else self.C
 
     @property
     def device(self):
@@ -190,15 +210,20 @@ class Planes:
 
     @property
     def shape(self):
-        return self.hi.shape
+        return torch.Size((self.rows, self.C))
 
     def data_ptr(self):
         return self.hi.data_ptr()
 
+    def plane(self, which):
+        """The hi / lo plane as a logical (rows, C) int16 tensor (tests / debugging: un-blocks the k-blocked storage)."""
+        t = self.hi if which == "hi" else self.lo
+        return t.permute(1, 0, 2).reshape(self.rows, self.C) if self.kblocked else t
+
     def float(self):
-        """hi + lo as fp32 (tests / debugging)."""
+        """hi + lo as fp32 (rows, C) (tests / debugging)."""
         f = lambda t: (t.to(torch.int32) << 16).view(torch.float32)
-        return f(self.hi) + f(self.lo)
+        return f(self.plane("hi")) + f(self.plane("lo"))
 
 
 def planes_ok(w, cin, rows):
@@ -244,7 +269,7 @@ def split_planes(x):
     """fp32 (rows, C) -> Planes (what a plane-emitting producer writes; used by tests and tools)."""
     rows, C = x.shape
     pl = Planes(rows, C, x.device)
-    _check(load().ddpo_split_planes_bf16(_p(x), C, _p(pl.hi), _p(pl.lo), C, rows, C, _stream()), "ddpo_split_planes_bf16")
+    _check(load().ddpo_split_planes_bf16(_p(x), C, _p(pl.hi), _p(pl.lo), pl.ld, rows, C, _stream()), "ddpo_split_planes_bf16")
     return pl
 
 
@@ -382,6 +407,31 @@ def ddim_logprob_ppo_fwd_bwd(eps_c, eps_u, x, x_next, ts, old_logp, advantages, 
     return d_c, d_u, per_sample, info
 
 
+# ------------------------------------------------------------------------------------------------ RWR
+def rwr_noisy_latents(moments, e1, noise, ts, alphas_cumprod_dev, scale=0.18215):
+    """moments (B,h,w,2C) NHWC, e1 (B,h,w,C) NHWC, noise (B,C,h,w) -> (latents, noisy_latents), both (B,C,h,w)."""
+    B, h, w, C2 = moments.shape
+    C = C2 // 2
+    lat = torch.empty(B, C, h, w, dtype=torch.float32, device=moments.device)
+    noisy = torch.empty_like(lat)
+    _check(load().ddpo_rwr_noisy_latents(_p(moments), _p(e1), _p(noise), _p(ts), _p(alphas_cumprod_dev), alphas_cumprod_dev.numel(),
+                                         float(scale), _p(lat), _p(noisy), B, C, h * w, _stream()), "ddpo_rwr_noisy_latents")
+    return lat, noisy
+
+
+def rwr_mse_fwd_bwd(eps_c, eps_u, noise, weights, guidance_scale, train_cfg):
+    """Weighted denoising MSE + its closed-form gradient.  Returns (d_eps_c, d_eps_u | None, per_sample (B,2), loss (1,))."""
+    B = eps_c.shape[0]
+    chw = eps_c.numel() // B
+    d_c = torch.empty_like(eps_c)
+    d_u = torch.empty_like(eps_c) if train_cfg else None
+    per_sample = torch.empty(B, 2, dtype=torch.float32, device=eps_c.device)
+    loss = torch.empty(1, dtype=torch.float32, device=eps_c.device)
+    _check(load().ddpo_rwr_mse_fwd_bwd(_p(eps_c), _p(eps_u), _p(noise), _p(weights), float(guidance_scale), int(bool(train_cfg)),
+                                       _p(d_c), _p(d_u), _p(per_sample), _p(loss), B, chw, _stream()), "ddpo_rwr_mse_fwd_bwd")
+    return d_c, d_u, per_sample, loss
+
+
 # ------------------------------------------------------------------------------------------------ optimizer
 def grad_sqnorm(g, out_sq=None):
     if out_sq is None:
@@ -419,7 +469,7 @@ def groupnorm(x, B, HW, gamma, beta, groups, eps, silu, out=None, ld_x=None, ld_
         pl = Planes(B * HW, C, x.device)
         ws = _scratch(load().ddpo_groupnorm_ws_bytes(B, HW, C, groups), x.device, "gn")
         stats = torch.empty(load().ddpo_groupnorm_stats_floats(B, C, groups), dtype=torch.float32, device=x.device)
-        _check(load().ddpo_groupnorm_fwd_planes(_p(x), int(ld_x or C), _p(pl.hi), _p(pl.lo), C, _p(gamma), _p(beta), B, HW, C, groups,
+        _check(load().ddpo_groupnorm_fwd_planes(_p(x), int(ld_x or C), _p(pl.hi), _p(pl.lo), pl.ld, _p(gamma), _p(beta), B, HW, C, groups,
                                                 float(eps), int(bool(silu)), _p(ws), _p(stats), _stream()), "ddpo_groupnorm_fwd_planes")
         return (pl, stats) if return_stats else pl
     if out is None:
@@ -445,7 +495,7 @@ def layernorm(x, gamma, beta, eps=1e-5, out=None, planes=False):
     rows, C = x.shape
     if planes:
         pl = Planes(rows, C, x.device)
-        _check(load().ddpo_layernorm_fwd_planes(_p(x), _p(pl.hi), _p(pl.lo), _p(gamma), _p(beta), rows, C, float(eps), _stream()),
+        _check(load().ddpo_layernorm_fwd_planes(_p(x), _p(pl.hi), _p(pl.lo), _p(gamma), _p(beta), rows, C, float(eps), int(pl.kblocked), _stream()),
                "ddpo_layernorm_fwd_planes")
         return pl
     if out is None:
@@ -530,7 +580,7 @@ def linear_geglu(x, w, out=None, planes_out=False):
         if current_datapath() != "bf16x3":
             raise DdpoHipError("plane-emitting linear_geglu needs the bf16x3 datapath")
         opl = Planes(M, N // 2, x.device)
-        d.out_hi, d.out_lo, d.ld_planes = opl.hi.data_ptr(), opl.lo.data_ptr(), N // 2
+        d.out_hi, d.out_lo, d.ld_planes = opl.hi.data_ptr(), opl.lo.data_ptr(), opl.ld
     else:
         if out is None:
             out = torch.empty(M, N // 2, dtype=torch.float32, device=x.device)
@@ -546,7 +596,7 @@ def linear_geglu(x, w, out=None, planes_out=False):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     if pl is not None:
-        _check(load().ddpo_gemm_conv_fwd_bf16_planes(byref(d), _p(pl.hi), _p(pl.lo), K, _p(g["hi"]), _p(g["lo"]), K, None, 0, _stream()),
+        _check(load().ddpo_gemm_conv_fwd_bf16_planes(byref(d), _p(pl.hi), _p(pl.lo), pl.ld, _p(g["hi"]), _p(g["lo"]), K, None, 0, _stream()),
                "ddpo_gemm_conv_fwd_bf16_planes")
     else:
         _check(load().ddpo_gemm_conv_fwd_bf16(byref(d), _p(g["hi"]), _p(g["lo"]), K, npass, None, 0, _stream()), "ddpo_gemm_conv_fwd_bf16")
@@ -594,7 +644,7 @@ def gemm_conv(src, w, *, M, N, K, bias=None, rowbias=None, rows_per_batch=0, res
         if planes_out not in ("both", "only"):
             raise ValueError(planes_out)
         opl = Planes(M, N, src.device)
-        d.out_hi, d.out_lo, d.ld_planes = opl.hi.data_ptr(), opl.lo.data_ptr(), N
+        d.out_hi, d.out_lo, d.ld_planes = opl.hi.data_ptr(), opl.lo.data_ptr(), opl.ld
     if out is None and planes_out != "only":
         out = torch.empty(M, N, dtype=torch.float32, device=src.device)
     if residual is not None:
@@ -620,7 +670,7 @@ def gemm_conv(src, w, *, M, N, K, bias=None, rowbias=None, rows_per_batch=0, res
     if pl is not None:
         hi, lo, ldw, npass = route
         ws = _scratch(SPLITK_WS_BYTES, src.device, "splitk")
-        _check(load().ddpo_gemm_conv_fwd_bf16_planes(byref(d), _p(pl.hi), _p(pl.lo), int(pl.hi.shape[1]), _p(hi), _p(lo), ldw, _p(ws),
+        _check(load().ddpo_gemm_conv_fwd_bf16_planes(byref(d), _p(pl.hi), _p(pl.lo), pl.ld, _p(hi), _p(lo), ldw, _p(ws),
                                                      SPLITK_WS_BYTES, _stream()), "ddpo_gemm_conv_fwd_bf16_planes")
     elif route is not None:
         hi, lo, ldw, npass = route
@@ -808,6 +858,14 @@ def gemm_wgrad(src, dy, dw, *, M, N, K, conv=None, ld_src=None, ld_dy=None, accu
         d.w = dy.data_ptr()
     d.ld_src = int(ld_src if ld_src is not None else (conv["Cin"] if conv else K))
     d.ld_w = int(ld_dy if ld_dy is not None else N)
+    if spl is not None:                  # plane operands carry their own layout (row stride 0 = k-blocked)
+        if ld_src is not None and spl.kblocked:
+            raise DdpoHipError("a column slice of k-blocked planes cannot be a wgrad operand")
+        d.ld_src = spl.ld if ld_src is None else d.ld_src
+    if dpl is not None:
+        if ld_dy is not None and dpl.kblocked:
+            raise DdpoHipError("a column slice of k-blocked planes cannot be a wgrad operand")
+        d.ld_w = dpl.ld if ld_dy is None else d.ld_w
     d.out = dw.data_ptr(); d.ld_out = int(N)
     d.alpha = float(alpha)
     d.M, d.N, d.K = int(M), int(N), int(K)

@@ -21,3 +21,17 @@ def split(key, num=2):
 def normal(key, shape, device="cuda"):
     """jax.random.normal(key, shape, float32) on the device."""
     return L.threefry_normal(key, tuple(shape), device=device)
+
+
+def randint(key, shape, minval, maxval):
+    """jax.random.randint(key, shape, minval, maxval) -> int32 numpy (host; integer-exact combination of two 32-bit Threefry draws,
+    jax 0.4.8 `_randint`; the RWR step's timesteps: /root/reference/ddpo/training/diffusion.py:30-36)."""
+    n = int(np.prod(shape)) if len(shape) else 1
+    k1, k2 = split(key)
+    hi, lo = L.threefry_bits_host(k1, n).astype(np.uint64), L.threefry_bits_host(k2, n).astype(np.uint64)
+    span = np.uint64(max(int(maxval) - int(minval), 1))
+    mult = np.uint64(2 ** 16) % span
+    mult = (mult * mult) % span
+    m32 = np.uint64(0xFFFFFFFF)
+    off = ((((hi % span) * mult) & m32) + (lo % span)) & m32
+    return (np.int64(minval) + (off % span).astype(np.int64)).astype(np.int32).reshape(shape)

@@ -80,6 +80,19 @@ int ddpo_ddim_logprob_ppo_fwd_bwd_grouped(const float* eps_c, const float* eps_u
 
 /* ---- optimizer: optax.chain(clip_by_global_norm, adamw(mu_dtype=bf16)) + AccumulatingTrainState ----
  * pipeline/policy_gradient.py:130-150; ddpo/training/policy_gradient.py:32-48. */
+/* RWR baseline (reward-weighted regression, /root/reference/ddpo/training/diffusion.py:19-90).
+ * ddpo_rwr_noisy_latents: moments (B,h,w,2C) NHWC = the stored VAE posterior (mean | logvar), e1 (B,h,w,C) NHWC and noise (B,C,h,w)
+ *   NCHW standard normals, ts (B) int32 -> latents = (mean + exp(clip(logvar,-30,20)/2) e1) * scale and
+ *   noisy = sqrt(acp[t]) latents + sqrt(1 - acp[t]) noise, both (B,C,h,w) NCHW (FlaxDDPMScheduler.add_noise).
+ * ddpo_rwr_mse_fwd_bwd: eps_c / eps_u / noise (B, chw); noise_pred = eps_u + g (eps_c - eps_u) if train_cfg else eps_c;
+ *   per_sample (B,2) = {mean_chw (noise - noise_pred)^2, w_b * that}; *loss = sum_b w_b loss_b with w_b = weights[b], or 1/B when
+ *   weights == NULL (the batch mean); d_eps_c / d_eps_u = d loss / d eps (closed form).  One workgroup per sample, no atomics. */
+int ddpo_rwr_noisy_latents(const float* moments, const float* e1, const float* noise, const int32_t* ts,
+                           const float* alphas_cumprod, int num_train_timesteps, float scale, float* latents, float* noisy,
+                           int B, int C, int hw, void* stream);
+int ddpo_rwr_mse_fwd_bwd(const float* eps_c, const float* eps_u, const float* noise, const float* weights, float guidance_scale,
+                         int train_cfg, float* d_eps_c, float* d_eps_u, float* per_sample, float* loss, int B, int chw,
+                         void* stream);
 /* out_sq (device double, must be zeroed by the caller or zero_first=1) += sum g^2 */
 int ddpo_grad_sqnorm(const float* g, int64_t n, double* out_sq, int zero_first, void* stream);
 /* One update over flat buffers.  g holds the SUM of accumulated grads; inv_n_acc = 1/(n_acc+1);
@@ -104,7 +117,12 @@ size_t ddpo_groupnorm_stats_floats(int B, int C, int G);
 int ddpo_groupnorm_fwd(const float* x, int ldx, float* y, int ldy, const float* gamma, const float* beta,
                        int B, int HW, int C, int G, float eps, int fuse_silu, void* ws, float* stats, void* stream);
 /* Same, but the result is written as bf16 hi / lo planes (B*HW, ldy) — hi = bf16(y), lo = bf16(y - hi) — the activation
- * operand format of ddpo_gemm_conv_fwd_bf16_planes (the fp32 tensor is not materialised; same bytes). */
+ * operand format of ddpo_gemm_conv_fwd_bf16_planes (the fp32 tensor is not materialised; same bytes).
+ * ACTIVATION-PLANE LAYOUTS (ABI v6; every function that writes or reads activation planes takes the same convention through its
+ * plane row stride ldy / ld_out / ld_planes / lda / ld_src / ld_w):  ld > 0: row-major (rows, ld);  ld == 0: k-blocked
+ * (C / 32, rows, 32), C % 32 == 0 — the 32 channels of one k-tile of consecutive rows are consecutive memory, so every 1 KiB
+ * LDS-DMA piece of the plane-fed GEMM (16 consecutive rows x 64 B) is 8 full cache lines instead of 16 half lines.  `rows` is the
+ * row count of the tensor the planes describe: B*HW here, `rows` / M elsewhere, B*H*W source pixels for a convolution's input. */
 int ddpo_groupnorm_fwd_planes(const float* x, int ldx, uint16_t* y_hi, uint16_t* y_lo, int ldy, const float* gamma,
                               const float* beta, int B, int HW, int C, int G, float eps, int fuse_silu, void* ws,
                               float* stats, void* stream);
@@ -118,7 +136,7 @@ int ddpo_groupnorm_bwd(const float* x, int ldx, const float* dy, int lddy, const
 int ddpo_layernorm_fwd(const float* x, float* y, const float* gamma, const float* beta, int rows, int C,
                        float eps, void* stream);
 int ddpo_layernorm_fwd_planes(const float* x, uint16_t* y_hi, uint16_t* y_lo, const float* gamma, const float* beta,
-                              int rows, int C, float eps, void* stream);      /* planes (rows, C), as above */
+                              int rows, int C, float eps, int kblocked, void* stream);      /* planes (rows, C), or k-blocked (C/32, rows, 32) */
 /* dx = LayerNorm backward (+ dx_add if given; statistics recomputed from x); dgamma/dbeta += (two-stage reduction
  * through ws = ddpo_layernorm_bwd_ws_bytes(rows, C) bytes of 16-byte aligned scratch). */
 size_t ddpo_layernorm_bwd_ws_bytes(int rows, int C);

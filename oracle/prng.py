@@ -65,6 +65,23 @@ def split(key, num=2):
     return random_bits(key, 2 * num).reshape(num, 2)
 
 
+def randint(key, shape, minval, maxval):
+    """jax.random.randint(key, shape, minval, maxval, int32) for in-range bounds (jax 0.4.8 `_randint`): two independent 32-bit
+    draws from split(key) are combined as ((hi % span) * (2^32 % span) + lo % span) % span, all in uint32 arithmetic, which makes
+    the result uniform over spans that do not divide 2^32.  Restated from the published source (the RWR train step draws its
+    timesteps with it: /root/reference/ddpo/training/diffusion.py:30-36); PARITY UNPINNED — no JAX here and no documented values."""
+    n = int(np.prod(shape)) if len(shape) else 1
+    k1, k2 = split(np.asarray(key, dtype=np.uint32))
+    hi, lo = random_bits(k1, n).astype(np.uint64), random_bits(k2, n).astype(np.uint64)
+    span = np.uint64(max(int(maxval) - int(minval), 1))
+    mult = np.uint64(2 ** 16) % span
+    mult = (mult * mult) % span
+    M32 = np.uint64(0xFFFFFFFF)
+    off = (((hi % span) * mult) & M32) + (lo % span)
+    off = (off & M32) % span
+    return (np.int64(minval) + off.astype(np.int64)).astype(np.int32).reshape(shape)
+
+
 def uniform(key, shape, minval=0.0, maxval=1.0):
     n = int(np.prod(shape)) if len(shape) else 1
     bits = random_bits(key, n)

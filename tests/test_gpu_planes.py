@@ -27,13 +27,16 @@ def _bf16x3():
     L.DATAPATH = "bf16x3"
 
 
-def test_split_planes_is_the_loader_split():
+@pytest.mark.parametrize("kblocked", [False, True])
+def test_split_planes_is_the_loader_split(kblocked, monkeypatch):
+    monkeypatch.setattr(L, "A_KBLOCKED", kblocked)
     x = torch.randn(257, 96, device=DEV) * torch.logspace(-6, 4, 96, device=DEV)
     pl = L.split_planes(x)
+    assert pl.kblocked == kblocked and pl.ld == (0 if kblocked else 96) and tuple(pl.hi.shape) == ((3, 257, 32) if kblocked else (257, 96))
     hi_ref = x.bfloat16()                                             # round-to-nearest-even, like v_cvt_pk_bf16_f32
-    assert torch.equal(pl.hi.view(torch.bfloat16), hi_ref)
+    assert torch.equal(pl.plane("hi").view(torch.bfloat16), hi_ref)
     lo_ref = (x - hi_ref.float()).bfloat16()
-    assert torch.equal(pl.lo.view(torch.bfloat16), lo_ref)
+    assert torch.equal(pl.plane("lo").view(torch.bfloat16), lo_ref)
     assert float(((pl.float() - x).abs() / x.abs().clamp_min(1e-30)).max()) < 2.0 ** -15
 
 
@@ -286,3 +289,55 @@ def test_kernel_probe_all_k_loop_variants_bit_identical(mode):
     out = subprocess.run([exe, "gemm2", batch, "2"], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-1000:]
     assert "FAIL" not in out.stdout and out.stdout.count("bit-identical") >= 20
+
+
+@pytest.mark.parametrize("case", [("dense", 4096, 320, 320), ("dense", 1000, 1280, 640), ("dense", 77, 64, 96),
+                                  ("conv", 2, 32, 320, 320, 3, 1, False), ("conv", 2, 16, 64, 96, 3, 2, False), ("conv", 1, 16, 64, 64, 3, 1, True),
+                                  ("conv", 1, 64, 320, 320, 1, 1, False)])
+def test_kblocked_activation_planes_are_bit_identical_to_row_major(monkeypatch, case):
+    """Activation planes stored k-blocked (C / 32, rows, 32) (plane row stride 0 in the C ABI, ABI v6) against row-major (rows, C): every
+    producer (split_planes, GroupNorm, LayerNorm, the plane-emitting GEMM output stage) and every consumer (plane-fed forward GEMM /
+    conv with stride, padding and nearest-2x upsampling in the gather; the weight gradient from activation planes, dY planes, both)
+    must see the same values: forward outputs, emitted planes and weight gradients bit-identical between the two storages."""
+    _bf16x3()
+    res = []
+    for kb in (False, True):
+        monkeypatch.setattr(L, "A_KBLOCKED", kb)
+        L.PACKED.clear()
+        g = torch.Generator().manual_seed(3)
+        if case[0] == "dense":
+            _, M, K, N = case
+            x = torch.randn(M, K, generator=g).to(DEV)
+            w = (torch.randn(K, N, generator=g) / K ** 0.5).to(DEV)
+            b = torch.randn(N, generator=g).to(DEV)
+            dy = torch.randn(M, N, generator=g).to(DEV)
+            L.pack_weights(w)
+            gam, bet = torch.randn(K, generator=g).to(DEV), torch.randn(K, generator=g).to(DEV)
+            pl = L.layernorm(x, gam, bet, planes=True)
+            assert pl.kblocked == kb
+            out, opl = L.linear(pl, w, b, planes_out="both")
+            dw1, dw2, dw3 = (torch.zeros_like(w) for _ in range(3))
+            L.gemm_wgrad(pl, dy, dw1, M=M, N=N, K=K)
+            L.gemm_wgrad(pl, L.split_planes(dy), dw2, M=M, N=N, K=K)
+            L.gemm_wgrad(x, L.split_planes(dy), dw3, M=M, N=N, K=K)
+            res.append([out, opl.float(), pl.float(), dw1, dw2, dw3])
+        else:
+            _, B, H, Cin, Cout, ks, stride, ups = case
+            x = torch.randn(B * H * H, Cin, generator=g).to(DEV)
+            w = (torch.randn(ks, ks, Cin, Cout, generator=g) / (ks * ks * Cin) ** 0.5).to(DEV)
+            b = torch.randn(Cout, generator=g).to(DEV)
+            L.pack_weights(w)
+            gam, bet = torch.randn(Cin, generator=g).to(DEV), torch.randn(Cin, generator=g).to(DEV)
+            pl = L.groupnorm(x, B, H * H, gam, bet, 32, 1e-5, True, planes=True)
+            assert pl.kblocked == kb
+            (out, opl), OH, OW = L.conv2d(pl, w, b, B, H, H, Cin, Cout, ks, stride=stride, upsample=ups, planes_out="both")
+            dy = torch.randn(B * OH * OW, Cout, generator=g).to(DEV)
+            dw1, dw2 = torch.zeros_like(w), torch.zeros_like(w)
+            L.conv2d_wgrad(pl, dy, dw1, B, H, H, Cin, Cout, ks, stride=stride, upsample=ups)
+            L.conv2d_wgrad(pl, L.split_planes(dy), dw2, B, H, H, Cin, Cout, ks, stride=stride, upsample=ups)
+            res.append([out, opl.float(), pl.float(), dw1, dw2])
+    for i, (a, b_) in enumerate(zip(*res)):
+        if i >= 3:          # weight gradients: fp32 atomics over the pixel splits -> equal up to the summation order
+            assert float((a - b_).abs().max()) <= 2e-6 * float(b_.abs().max()) + 1e-7
+        else:
+            assert torch.equal(a, b_), i
