@@ -155,7 +155,33 @@ def evaluate_callbacks(fns, images, prompts, metadata):
     return {key: fn(images, prompts, metadata) for key, fn in fns.items()}
 
 
+def vae_fn(devices=None, dtype="float32", jit=True, encoder=None):
+    """The `vae` field of the RWR sampler (reference :37-57): images (N,H,W,3) in [0,1] -> VAE posterior moments
+    concat([mean, logvar], -1) (N,H/8,W/8,8) from the engine's VAE encoder (ddpo_amd/models/vae.py:VAEEncoder).  The reference
+    loads the SD-1.4 Flax VAE itself; here the caller hands the loaded encoder over (`set_vae_encoder`, pipeline/sample.py) —
+    nothing is downloaded."""
+    import torch
+    enc = encoder if encoder is not None else _VAE_ENCODER.get("encoder")
+    if enc is None:
+        raise RuntimeError("the `vae` callback needs a loaded VAE encoder: call ddpo_amd.training.callbacks.set_vae_encoder(encoder) first")
+
+    def _fn(images, prompts=None, metadata=None):
+        with torch.no_grad():
+            m = enc.encode(torch.as_tensor(np.asarray(images, dtype=np.float32)))
+        return m.cpu().numpy(), {}
+
+    return _fn
+
+
+_VAE_ENCODER = {}
+
+
+def set_vae_encoder(encoder):
+    _VAE_ENCODER["encoder"] = encoder
+
+
 callback_fns = {
+    "vae": vae_fn,
     "jpeg": jpeg_fn,
     "neg_jpeg": neg_jpeg_fn,
     "aesthetic": aesthetic_fn,

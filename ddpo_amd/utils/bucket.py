@@ -1,0 +1,249 @@
+"""Sample store of the RWR baseline on the LOCAL filesystem.
+
+The reference writes the sampler's output through `utils.RemoteWriter` (HDF5 shards uploaded to a GCS bucket,
+/root/reference/ddpo/utils/hdf5.py:72-300) and reads it back through `RemoteReader` / `H5Reader` + `BucketDataset` +
+`get_bucket_loader` (/root/reference/ddpo/datasets/bucket.py).  Neither h5py nor a bucket exists here; the same roles and call
+surface are kept on plain `.npz` shards in a directory:
+
+  LocalWriter(savepath, split_size)            configure(field, encode_fn=, decode_fn=) / add_batch(batch, mask=) -> n added / close()
+  LocalReader(loadpath)                        len / reader[i] -> {field: value} (+ "weights" once make_weights ran) /
+                                               make_weights(field, temperature, by_prompt)   (hdf5.py:437-461: softmax_ref * N, or per prompt)
+  BucketDataset, collate_fn, get_bucket_loader the dataset / loader of datasets/bucket.py: caption choice, tokenisation, uncond ids,
+                                               drop_last batching in storage order, shard() over ranks
+  Percentile / StreamingPercentile / Threshold / make_masker, StreamingAverage, softmax_ref       (utils/logger.py:32-94, utils/array.py:32-41)
+Images are stored JPEG-encoded (`encode_jpeg`, quality 95) exactly as the reference configures its `images` field."""
+import glob
+import io
+import json
+import os
+import random
+
+import numpy as np
+from PIL import Image
+
+
+# ------------------------------------------------------------------------------------------------ small helpers of utils/
+def softmax_ref(x, temperature=1.0):
+    assert x.ndim == 1
+    x = x * temperature
+    z = x - x.max()
+    numer = np.exp(z)
+    return numer / numer.sum()
+
+
+class StreamingAverage:
+    def __init__(self):
+        self.n, self.avg = 0, 0
+
+    def __call__(self, x):
+        self.n += 1
+        self.avg = self.avg * (self.n - 1) / self.n + x / self.n
+
+
+class Masker:
+    def __repr__(self):
+        return f"[ {self._name} | {self.p} ]"
+
+    def mask(self, xs):
+        return xs >= self.p
+
+
+class Percentile(Masker):
+    def __init__(self, q=90, maxsize=5e6):
+        self.q, self._name = q, f"percentile: {q}"
+
+    def __call__(self, xs):
+        if xs.ndim == 2:
+            xs = xs.squeeze(axis=-1)
+        self.p = np.percentile(xs, self.q)
+        return super().mask(xs)
+
+
+class StreamingPercentile(Masker):
+    def __init__(self, q=90, maxsize=5e6):
+        self.q, self.xs, self.size, self._name = q, np.zeros(int(maxsize)), 0, f"streaming_percentile: {q}"
+
+    def __call__(self, xs):
+        if xs.ndim == 2:
+            xs = xs.squeeze(axis=-1)
+        n = len(xs)
+        self.xs[self.size:self.size + n] = xs[:]
+        self.size += n
+        self.p = np.percentile(self.xs[:self.size], self.q)
+        return super().mask(xs)
+
+
+class Threshold(Masker):
+    def __init__(self, threshold=0.95):
+        self.p, self._name = threshold, f"threshold: {threshold}"
+
+    def __call__(self, xs):
+        return super().mask(xs)
+
+
+def make_masker(mode, param):
+    return {"percentile": Percentile, "streaming_percentile": StreamingPercentile, "threshold": Threshold}[mode](param)
+
+
+def decode_jpeg(buf):
+    return np.asarray(Image.open(io.BytesIO(np.asarray(buf, dtype=np.uint8).tobytes())))
+
+
+# ------------------------------------------------------------------------------------------------ writer / reader
+class LocalWriter:
+    """add_batch(batch, mask) appends the masked rows field by field; every `split_size` rows a shard `<rank>_<i>.npz` is closed."""
+
+    def __init__(self, savepath, split_size=1000, rank=0):
+        self.savepath, self.split_size, self.rank = savepath, int(split_size), int(rank)
+        os.makedirs(savepath, exist_ok=True)
+        self._encode, self._rows, self._shard, self._total = {}, [], 0, 0
+
+    def configure(self, field, max_size=None, vlen=False, encode_fn=None, decode_fn=None):
+        self._encode[field] = encode_fn
+
+    def __len__(self):
+        return self._total
+
+    def add_batch(self, batch, mask=None):
+        sizes = [len(v) for v in batch.values()]
+        assert len(set(sizes)) == 1, f"Batch sizes must be equal, got {sizes}"
+        idx = range(sizes[0]) if mask is None else np.where(np.asarray(mask).reshape(-1))[0]
+        for i in idx:
+            row = {}
+            for k, v in batch.items():
+                x = v[i]
+                enc = self._encode.get(k)
+                row[k] = enc(x) if enc is not None else x
+            self._rows.append(row)
+            self._total += 1
+            if len(self._rows) >= self.split_size:
+                self._flush()
+        return len(idx)
+
+    def _flush(self):
+        if not self._rows:
+            return
+        cols = {}
+        for k in self._rows[0]:
+            vals = [r[k] for r in self._rows]
+            arr = np.empty(len(vals), dtype=object)
+            arr[:] = vals
+            cols[k] = arr
+        np.savez(os.path.join(self.savepath, f"{self.rank}_{self._shard:05d}.npz"), **cols)
+        self._rows, self._shard = [], self._shard + 1
+
+    def close(self, metadata=None):
+        self._flush()
+        if metadata is not None and self.rank == 0:
+            with open(os.path.join(self.savepath, "metadata.json"), "w") as f:
+                json.dump(metadata, f, indent=2, default=str)
+
+
+class LocalReader:
+    def __init__(self, loadpath):
+        files = sorted(glob.glob(os.path.join(loadpath, "*.npz")))
+        if not files:
+            raise FileNotFoundError(f"no sample shards (*.npz) in '{loadpath}'")
+        self._cols = {}
+        for f in files:
+            with np.load(f, allow_pickle=True) as z:
+                for k in z.files:
+                    self._cols.setdefault(k, []).extend(list(z[k]))
+        self._keys = list(self._cols)
+        self.weighted, self.weights = False, None
+
+    def __len__(self):
+        return len(self._cols[self._keys[0]])
+
+    def get(self, idx, field):
+        v = self._cols[field][idx]
+        return np.stack([np.asarray(x) for x in v]) if isinstance(idx, slice) else v
+
+    def __getitem__(self, idx):
+        batch = {k: self._cols[k][idx] for k in self._keys}
+        if self.weighted:
+            batch["weights"] = self.weights[idx]
+        return batch
+
+    def make_weights(self, field, temperature, by_prompt):
+        labels = np.asarray(self.get(slice(0, len(self)), field), dtype=np.float64).squeeze()
+        if by_prompt:
+            prompts = np.asarray(self.get(slice(0, len(self)), "inference_prompts")).squeeze()
+            self.weights = np.empty_like(labels)
+            for prompt in np.unique(prompts):
+                mask = prompts == prompt
+                self.weights[mask] = softmax_ref(labels[mask], temperature=temperature) * mask.sum()
+        else:
+            self.weights = softmax_ref(labels, temperature=temperature) * len(self)
+        self.weighted = True
+        cumsum = np.cumsum(np.sort(self.weights)[::-1] / len(self))
+        n = ((cumsum <= 0.9) * np.arange(len(cumsum))).max()
+        print(f"[ utils/bucket ] Weights sanity check: {n} / {len(cumsum)} ({(n / len(cumsum)):.3}%) samples account for 90% of the weight | "
+              f"temperature: {temperature}")
+
+
+# ------------------------------------------------------------------------------------------------ dataset / loader (datasets/bucket.py)
+class BucketDataset:
+    def __init__(self, reader):
+        self.reader = reader
+        self._max_size, self._offset = None, 0
+        self._shuffled = np.arange(len(self))
+
+    def __len__(self):
+        return self._max_size or len(self.reader)
+
+    def __getitem__(self, idx):
+        worker_idx = self._offset + idx
+        shuffled_idx = int(self._shuffled[worker_idx])
+        x = dict(self.reader[shuffled_idx])
+        caption = x["training_prompts"]
+        if isinstance(caption, (list, np.ndarray)):
+            caption = random.choice(list(caption))          # select_caption
+        x["text"] = caption
+        x.update(idx=worker_idx, shuffled_idx=shuffled_idx)
+        return x
+
+    def shuffle(self):
+        self._shuffled = np.random.permutation(self._shuffled)
+
+    def shard(self, host_id=0, n_hosts=1):
+        n = len(self) // n_hosts
+        self._max_size, self._offset = n, host_id * n
+
+    def make_weights(self, *a, **kw):
+        self.reader.make_weights(*a, **kw)
+
+    def subsample(self, N):
+        self._max_size = N
+
+
+def collate_fn(tokenizer, examples, image_field="vae", text_field="input_ids"):
+    pixel_values = np.stack([np.asarray(e[image_field]) for e in examples]).astype(np.float32)
+    captions = [str(e["text"]) for e in examples]
+    labels = {k: np.stack([np.asarray(e[k]) for e in examples]) for k in ("aesthetic", "consistency", "jpeg", "neg_jpeg", "labels", "weights")
+              if k in examples[0]}
+    tok = lambda texts: tokenizer(texts, padding="max_length", max_length=tokenizer.model_max_length, return_tensors="np").input_ids
+    return {image_field: pixel_values, text_field: tok(captions), "idxs": np.stack([e["idx"] for e in examples]),
+            "shuffled_idxs": np.stack([e["shuffled_idx"] for e in examples]), "uncond_text": tok([""] * len(examples)), **labels}
+
+
+class _Loader:
+    """torch DataLoader(shuffle=False, drop_last=True) of the reference, without worker processes."""
+
+    def __init__(self, dataset, tokenizer, batch_size):
+        self.dataset, self.tokenizer, self.batch_size = dataset, tokenizer, int(batch_size)
+
+    def __len__(self):
+        return len(self.dataset) // self.batch_size
+
+    def __iter__(self):
+        for b in range(len(self)):
+            yield collate_fn(self.tokenizer, [self.dataset[b * self.batch_size + i] for i in range(self.batch_size)])
+
+
+def get_bucket_loader(loadpath, tokenizer, batch_size, resolution=None, max_train_samples=None, host_id=0, n_hosts=1):
+    dataset = BucketDataset(LocalReader(loadpath))
+    if max_train_samples is not None:
+        dataset.subsample(max_train_samples)
+    dataset.shard(host_id, n_hosts)
+    return dataset, _Loader(dataset, tokenizer, batch_size)

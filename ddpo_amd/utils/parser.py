@@ -129,7 +129,9 @@ class Parser:
     def eval_fstrings(self, args):
         for key, old in list(args._dict.items()):
             if isinstance(old, str) and old.startswith("f:"):
-                new = old[2:].format(**{k: getattr(args, k) for k in vars(args) if not k.startswith("_")})
+                # a real f-string evaluation, like the reference ("f:models/{iteration+1}" needs expressions, not only names)
+                ns = {k: getattr(args, k) for k in vars(args) if not k.startswith("_")}
+                new = eval("f" + repr(old[2:]), {"__builtins__": {}}, ns)
                 print(f"[ utils/setup ] Lazy fstring | {key} : {old} --> {new}")
                 args.set(key, new)
 

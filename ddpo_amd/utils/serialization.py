@@ -258,6 +258,27 @@ def load_unet(loadpath=None, epoch="latest", pretrained_model="duongna/stable-di
     return pipeline, params
 
 
+def load_vae_encoder(pretrained_model="duongna/stable-diffusion-v1-4-flax", cache="cache", device="cuda", seed=0):
+    """The VAE ENCODER half (+ quant_conv) of the same checkpoint `load_unet` reads (`<dir>/vae`, any of its three layouts): what the
+    reference's `vae` callback loads for the RWR sampler (/root/reference/ddpo/training/callbacks.py:37-41).  Refuses missing weights
+    unless DDPO_ALLOW_SYNTHETIC=1 (then: deterministic random init, `encoder.synthetic_weights = True`)."""
+    from ..models.vae import VAEEncoder
+    from .. import lib as L
+    family = model_family(pretrained_model)
+    enc = VAEEncoder(VAEConfig.named("tiny" if family.startswith("tiny") else "sd"), device)
+    local = resolve_pretrained(pretrained_model, cache)
+    layout = load_component(enc.params, local, "vae") if local is not None else None
+    if layout is None:
+        if not allow_synthetic():
+            raise FileNotFoundError(f"no VAE weights found for pretrained_model='{pretrained_model}' (the `vae` callback of pipeline/sample.py needs "
+                                    f"the encoder); set DDPO_ALLOW_SYNTHETIC=1 for a seeded random-init encoder (benchmarks / tests only)")
+        enc.params.init_synthetic(seed + 5)
+    enc.synthetic_weights = layout is None
+    if L.DATAPATH != "fp32":
+        enc.params.pack_bf16(bwd=False)
+    return enc
+
+
 def latest_checkpoint(ckpt_dir):
     if not os.path.isdir(ckpt_dir):
         return None

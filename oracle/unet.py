@@ -176,6 +176,30 @@ def vae_decoder_param_shapes(cfg: VAECfg):
     return d
 
 
+def vae_encoder_param_shapes(cfg: VAECfg, in_channels=3):
+    """diffusers 0.12.1 FlaxEncoder + quant_conv (FlaxAutoencoderKL.encode): 34,163,664 parameters for the SD VAE (83,653,863 of the whole AutoencoderKL minus the decoder half 49,490,199)."""
+    d = OrderedDict()
+    boc = cfg.block_out_channels
+    _conv(d, "encoder.conv_in", in_channels, boc[0], 3)
+    ch = boc[0]
+    for i, out_c in enumerate(boc):
+        for j in range(cfg.layers_per_block):
+            _resnet(d, f"encoder.down_blocks_{i}.resnets_{j}", ch, out_c, 0)
+            ch = out_c
+        if i != len(boc) - 1:
+            _conv(d, f"encoder.down_blocks_{i}.downsamplers_0.conv", ch, ch, 3)
+    _resnet(d, "encoder.mid_block.resnets_0", ch, ch, 0)
+    a = "encoder.mid_block.attentions_0"
+    _norm(d, a + ".group_norm", ch)
+    for n in ("query", "key", "value", "proj_attn"):
+        _dense(d, f"{a}.{n}", ch, ch)
+    _resnet(d, "encoder.mid_block.resnets_1", ch, ch, 0)
+    _norm(d, "encoder.conv_norm_out", ch)
+    _conv(d, "encoder.conv_out", ch, 2 * cfg.latent_channels, 3)
+    _conv(d, "quant_conv", 2 * cfg.latent_channels, 2 * cfg.latent_channels, 1)
+    return d
+
+
 def count_params(shapes):
     return sum(math.prod(s) for s in shapes.values())
 
@@ -368,3 +392,36 @@ def vae_decode(p, cfg: VAECfg, latents):
     h = TF.silu(_gn(p, "decoder.conv_norm_out", h, G, 1e-6))
     img = _conv2d(p, "decoder.conv_out", h)
     return (img / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1)
+
+
+def _vae_mid_attention(p, a, h, G):
+    B, C, H, W = h.shape
+    t = _gn(p, a + ".group_norm", h, G, 1e-6).permute(0, 2, 3, 1).reshape(B, H * W, C)
+    q, k, v = (_dense_f(p, f"{a}.{n}", t) for n in ("query", "key", "value"))
+    scale = 1.0 / math.sqrt(math.sqrt(C))
+    s = torch.softmax((q * scale) @ (k * scale).transpose(-1, -2), dim=-1)
+    t = _dense_f(p, a + ".proj_attn", s @ v)
+    return t.reshape(B, H, W, C).permute(0, 3, 1, 2) + h
+
+
+def vae_encode(p, cfg: VAECfg, images):
+    """The `vae` callback of the RWR sampler (/root/reference/ddpo/training/callbacks.py:37-57): images (B,H,W,3) in [0,1] -> NCHW,
+    (x - 0.5) / 0.5, FlaxAutoencoderKL.encode -> concat([mean, logvar], -1) (B,h,w,2*latent) NHWC with logvar clipped to [-30, 20]
+    (FlaxDiagonalGaussianDistribution clips in its constructor).  Down-samplers pad (0,1,0,1) and convolve with stride 2, no padding."""
+    G = cfg.norm_groups
+    h = (images.permute(0, 3, 1, 2) - 0.5) / 0.5
+    h = _conv2d(p, "encoder.conv_in", h)
+    n = len(cfg.block_out_channels)
+    for i in range(n):
+        for j in range(cfg.layers_per_block):
+            h = _resnet_f(p, f"encoder.down_blocks_{i}.resnets_{j}", h, None, G, 1e-6)
+        if i != n - 1:
+            h = _conv2d(p, f"encoder.down_blocks_{i}.downsamplers_0.conv", TF.pad(h, (0, 1, 0, 1)), stride=2, pad=0)
+    h = _resnet_f(p, "encoder.mid_block.resnets_0", h, None, G, 1e-6)
+    h = _vae_mid_attention(p, "encoder.mid_block.attentions_0", h, G)
+    h = _resnet_f(p, "encoder.mid_block.resnets_1", h, None, G, 1e-6)
+    h = TF.silu(_gn(p, "encoder.conv_norm_out", h, G, 1e-6))
+    h = _conv2d(p, "encoder.conv_out", h)
+    m = _conv2d(p, "quant_conv", h, pad=0).permute(0, 2, 3, 1)
+    C = cfg.latent_channels
+    return torch.cat([m[..., :C], m[..., C:].clamp(-30.0, 20.0)], dim=-1)

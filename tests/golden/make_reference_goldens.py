@@ -173,13 +173,15 @@ def main():
     sys.modules["ref_config"] = cfg_pkg
     load_by_path("ref_config.user", os.path.join(REF, "config/user.py"))
     base_mod = load_by_path("ref_config.base", os.path.join(REF, "config/base.py"))
-    cfg = {"base_pg": jsonable(base_mod.base["pg"]), "datasets": {}}
+    cfg = {"base_pg": jsonable(base_mod.base["pg"]), "base_sample": jsonable(base_mod.base["sample"]), "base_train": jsonable(base_mod.base["train"]),
+           "datasets": {}}
     for name in dir(base_mod):
         val = getattr(base_mod, name)
         if name.startswith("_") or name == "base" or not isinstance(val, dict):
             continue
         if "pg" in val or "common" in val:
-            cfg["datasets"][name] = {"common": jsonable(val.get("common", {})), "pg": jsonable(val.get("pg", {}))}
+            cfg["datasets"][name] = {"common": jsonable(val.get("common", {})), "pg": jsonable(val.get("pg", {})),
+                                     "sample": jsonable(val.get("sample")), "train": jsonable(val.get("train"))}
     out["config"] = cfg
 
     # ---------------------------------------------------------------- jpeg rewards

@@ -71,11 +71,14 @@ def test_config_flag_surface_matches_reference():
         if k in ("logbase",):                  # site-specific (the reference points at a GCS bucket)
             continue
         assert mine[k] == v, f"default of {k}: {mine[k]!r} != reference {v!r}"
+    # the `sample` / `train` experiments of the RWR baseline (pipeline/sample.py, pipeline/finetune.py): defaults and per-dataset overrides equal
+    for sect in ("sample", "train"):
+        assert _norm(C.base[sect]) == ref["base_" + sect], sect
     for name, ds in ref["datasets"].items():
-        if name.endswith("_rwr"):              # RWR baselines: out of scope
-            continue
         assert hasattr(C, name), f"missing dataset config {name}"
         got = getattr(C, name)
+        for sect in ("sample", "train"):
+            assert _norm(got.get(sect)) == ds[sect], f"{name}.{sect}"
         for sect in ("common", "pg"):
             for k, v in ds[sect].items():
                 mine_v = _norm(got.get(sect, {}).get(k))
