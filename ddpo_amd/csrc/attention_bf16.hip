@@ -406,7 +406,7 @@ __global__ void __launch_bounds__(256, (DVP <= 32 ? 4 : (DKP <= 48 ? 3 : 2))) at
 }
 
 // ------------------------------------------------------------------------------------------------
-// LDS-DMA variant of the packed-image kernel (DDPO_ATTN_DMA=1; images whose K part and V part are whole KiB: d = 40, 64).
+// LDS-DMA variant of the packed-image kernel (images whose K part and V part are whole KiB: d = 40, 64).
 // The image of a key tile is already the exact LDS layout, lane-linear — so instead of 16-byte loads into registers one tile ahead
 // and a ds_write_b128 pass behind two barriers, the K part and the V part go global -> LDS directly (buffer_load_dwordx4 ... lds,
 // 1 KiB per wave instruction): no staging registers (32 VGPRs), no LDS write instructions.  Three LDS regions keep three workgroups
@@ -620,18 +620,13 @@ static int launch_attn_images(const float* q, int ldq, const uint4* img, float* 
   using I = AttnImg<D, DKP, DVP>;
   dim3 grid((Nq + 127) / 128, B * heads);
   const int ntiles = (Nk + I::KT - 1) / I::KT;
-  // DDPO_ATTN_DMA: 1 (default) = LDS-DMA image streaming (1.50 -> 1.42 ms on 4096^2, d = 40, batch 16: profiles/r02_probe_attn_dma.log);
-  // 0 = the register-staged kernel; 2 = DMA + two query blocks per wave (1.40 ms, but 256 VGPRs with a few spilled: not the default)
-  static const int dma_mode = [] { const char* e = getenv("DDPO_ATTN_DMA"); return e ? atoi(e) : 1; }();
+  // LDS-DMA image streaming wherever the image's K and V^T parts are whole KiB (d = 40, 64): 1.50 -> 1.42 ms on 4096^2, d = 40, batch 16
+  // (profiles/r02_probe_attn_dma.log); the register-staged kernel below takes the other head sizes (d = 80) and >= 2 GiB image sets.
+  // (Two query blocks per wave on top measured 1.40 ms at 256 VGPRs with spills — not kept.)
   if constexpr ((2 * I::K_BYTES) % 1024 == 0 && (2 * I::VT_BYTES) % 1024 == 0) {
-    if (dma_mode && (int64_t)ntiles * I::BYTES < 0x7FFFFFFF) {
-      // DDPO_ATTN_DMA=2: two query blocks per wave where that still leaves >= 512 workgroups (two per CU)
-      if (dma_mode == 2 && Nq >= 512 && (long)((Nq + 255) / 256) * B * heads >= 512)
-        hipLaunchKernelGGL((attn_fwd_bf16_dma_kernel<D, DKP, DVP, 2>), dim3((Nq + 255) / 256, B * heads), dim3(256), 0, st, q, ldq, img, o, ldo, lse,
-                           heads, Nq, Nk, ntiles, scale * 1.4426950408889634f);
-      else
-        hipLaunchKernelGGL((attn_fwd_bf16_dma_kernel<D, DKP, DVP, 1>), grid, dim3(256), 0, st, q, ldq, img, o, ldo, lse, heads, Nq, Nk, ntiles,
-                           scale * 1.4426950408889634f);
+    if ((int64_t)ntiles * I::BYTES < 0x7FFFFFFF) {
+      hipLaunchKernelGGL((attn_fwd_bf16_dma_kernel<D, DKP, DVP, 1>), grid, dim3(256), 0, st, q, ldq, img, o, ldo, lse, heads, Nq, Nk, ntiles,
+                         scale * 1.4426950408889634f);
       DDPO_LAUNCH_CHECK();
       return DDPO_OK;
     }

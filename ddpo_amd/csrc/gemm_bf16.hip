@@ -570,8 +570,8 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
         if (conv && tap < ntaps) set_tap(tap);
       }
     };
-    if constexpr (APL == 4 || APL == 5) {
-      // Plain schedule for the TALL 256x320 tile (64 x 160 per wave: 160 accumulator registers leave room for ONE fragment set;
+    if constexpr (APL == 5) {
+      // Schedule of the TALL 256x320 tile (64 x 160 per wave: 160 accumulator registers leave room for ONE fragment set;
       // the second wave of the SIMD covers the LDS latency).  28 fragment reads and 9 LDS-DMA pieces feed 60 MFMAs per wave and
       // k-tile, against 24 + 7 for 30 MFMAs on the 128x320 tile: 36 % fewer L2 and 42 % fewer LDS bytes per MFMA.
       const bool late = (d.splits & 1) != 0 && wv >= NW / 2;
@@ -592,8 +592,8 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
         if (!DBG_ABL(2)) mma(g, 0, TM * TN);
         if (DBG_ABL(2)) asm volatile("" :: "v"(g.ah[0]), "v"(g.bl[TN - 1]), "v"(g.al[TM - 1]), "v"(g.bh[0]));
       };
-      if constexpr (APL == 5) {
-        // ROTATED schedule (round 3).  The plain loop above makes both waves of a SIMD do the same thing at the same time: after the
+      {
+        // ROTATED schedule (round 3).  A plain loop (every wave: wait, barrier, request, read ks = 0, multiply, read ks = 1, multiply) makes both waves of a SIMD do the same thing at the same time: after the
         // barrier both request fragments (nobody computes), then both compute.  Here the upper half of the waves runs the SAME
         // per-k-tile work shifted by half a phase: it carries the ks = 1 fragments of tile kt - 1 ACROSS the barrier and multiplies them
         // while the lower half issues its LDS-DMA pieces and reads the ks = 0 fragments of tile kt; from then on one wave of every SIMD
@@ -633,17 +633,8 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
           if (kt < nk) step5(kt, std::integral_constant<int, 0>{});
           mma(g, 0, TM * TN);                            // ks = 1 of the last tile
         }
-      } else {
-      fill(0);
-      int kt = 0;
-#pragma unroll 1
-      for (; kt + 1 < nk; kt += 2) {
-        step4(kt, std::integral_constant<int, 0>{});
-        step4(kt + 1, std::integral_constant<int, 1>{});
       }
-      if (kt < nk) step4(kt, std::integral_constant<int, 0>{});
-      }
-    } else if constexpr (APL == 3 || APL == 6) {
+    } else if constexpr (APL == 3) {
       // Mode 2's shape with the WEIGHT operand three LDS stages deep: [A s0 | A s1 | W s0 | W s1 | W s2] (128x320: 2 x 16 KB +
       // 3 x 40 KB = 152 KB).  At the barrier of k-tile s the activation pieces of tile s + 2 and the weight pieces of tile s + 3
       // are requested, in that order; the wait in front of the next barrier is a COUNTED vmcnt(NB): everything but the newest NB
@@ -672,12 +663,6 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
           asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                        :: "s"(lw + i * (PAIRS * 1024)), "v"(bvoff[i]), "s"(rs_w), "s"(so_w) : "memory");
         ++kw_next;
-      };
-      auto fill_w_piece = [&](int stage, int i) {            // one piece of the weight tile kw_next (the caller advances kw_next after the last); i constant after inlining
-        const uint32_t so_w = __builtin_amdgcn_readfirstlane((uint32_t)kw_next * w_kt_b);
-        const uint32_t lw = __builtin_amdgcn_readfirstlane(lds_w3 + stage * W_STAGE + i * (PAIRS * 1024));
-        asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                     :: "s"(lw), "v"(bvoff[i]), "s"(rs_w), "s"(so_w) : "memory");
       };
       // stage offsets are RUNTIME scalars (one v_add per fragment read): with compile-time stages the 152 KB image exceeds the
       // 64 KB reach of the ds_read offset field, the compiler keeps one address register per (stage, fragment) and spills
@@ -711,27 +696,6 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
         DBG_WMID();
         __builtin_amdgcn_s_barrier();
         DBG_W1();
-        if constexpr (APL == 6) {
-          // SPREAD (round 3): the pieces are not issued as one burst behind the barrier (eight waves x seven pieces queue on the CU's one
-          // address path while nobody multiplies) but interleaved with the ks = 1 MFMAs, one weight piece behind each 32x32 block: the
-          // activation pieces (needed one k-tile earlier than the weights) first, then [block, piece] pairs.  Same request ORDER per wave
-          // (activations, then weights), so the counted vmcnt(NB) in front of the next barrier means what it meant.
-          static_assert(NB <= TM * TN, "one weight piece per accumulator block");
-          if (kt + 2 < nk) fill_a(as);
-          if (kt + 1 < nk) ldfrag3(as_n * A_STAGE, ws_n * W_STAGE, 0, g0);
-          __builtin_amdgcn_sched_barrier(0);
-          const bool wreq = kt + 3 < nk;
-#pragma unroll
-          for (int j = 0; j < TM * TN; ++j) {
-            mma(g1, j, j + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            if (j < NB && wreq) fill_w_piece(ws, j);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-          if (wreq) ++kw_next;
-          as = as_n; ws = ws_n;
-          continue;
-        }
         if (!late && !DBG_ABL(1)) {                        // activation tile kt + 2, then weight tile kt + 3, into the stages just freed
           if (kt + 2 < nk) fill_a(as);
           if (kt + 3 < nk) fill_w(ws);
@@ -750,42 +714,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
         as = as_n; ws = ws_n;
       }
     } else {
-      // Barrier in the MIDDLE of the k-tile (the register-staged loop's shape): on entry the ks = 0 fragments of tile kt are in
-      // registers; its ks = 1 fragments are requested and the ks = 0 MFMAs run under them; then everybody waits for tile kt + 1
-      // to have landed and for its own reads of tile kt's stage to have returned, the barrier publishes both facts, tile kt + 2 is
-      // requested into the stage just freed, the ks = 0 fragments of tile kt + 1 are requested and the ks = 1 MFMAs run under them.
-      const bool late = (d.splits & 1) != 0 && wv >= NW / 2;          // staggered request (see DDPO_APL_MODE)
-      Frag g0, g1;
-      fill(0);
-      if (nk > 1) fill(1);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      DBG_T(1);
-      ldfrag(0, 0, g0);
-      auto step2 = [&](int kt, auto cur_c) {
-        constexpr int cur = decltype(cur_c)::value;
-        ldfrag(cur, 1, g1);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(g0, 0, TM * TN);
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (kt + 2 < nk && !late) fill(cur);
-        if (kt + 1 < nk) ldfrag(cur ^ 1, 0, g0);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(g1, 0, (TM * TN) / 2);
-        __builtin_amdgcn_sched_barrier(0);
-        if (kt + 2 < nk && late) fill(cur);
-        mma(g1, (TM * TN) / 2, TM * TN);
-        __builtin_amdgcn_sched_barrier(0);
-      };
-      int kt = 0;
-#pragma unroll 1
-      for (; kt + 1 < nk; kt += 2) {
-        step2(kt, std::integral_constant<int, 0>{});
-        step2(kt + 1, std::integral_constant<int, 1>{});
-      }
-      if (kt < nk) step2(kt, std::integral_constant<int, 0>{});
+      static_assert(APL == 3 || APL == 5, "plane-fed k-loops: 3 = three weight stages (128-row tiles), 5 = tall tile");
     }
   } else {
     const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(d.src);
@@ -1160,7 +1089,7 @@ static bool planes_out_ok(const ddpo_gemm_desc& d) {
 }
 
 // buffer-addressed fast path: k-tiles never straddle a tap and every byte offset fits the 31-bit buffer range
-static bool g_force_generic = false;
+static bool g_force_generic = false;          // only ever set through the debug hook below (probe builds)
 static bool buf_path_ok(const ddpo_gemm_desc& d, int ldw) {
   if (g_force_generic) return false;
   const int64_t lim = 0x7FFFFFFF;
@@ -1176,7 +1105,9 @@ static bool buf_path_ok(const ddpo_gemm_desc& d, int ldw) {
   }
   return true;
 }
+#ifdef DDPO_DEBUG_HOOKS      // tools/native builds only: not part of libddpo_hip.so's ABI
 extern "C" void ddpo_debug_force_generic_gemm(int on) { g_force_generic = on != 0; }
+#endif
 
 template <int BM, int BN, int NPASS, int WM = 2, int WN = 2, int APL = 0>
 static int launch_bf16(const ddpo_gemm_desc& d, const uint16_t* w_hi, const uint16_t* w_lo, int ldw, float* ws, size_t ws_bytes,
@@ -1197,7 +1128,7 @@ static int launch_bf16(const ddpo_gemm_desc& d, const uint16_t* w_hi, const uint
   splits = (nk_total + ktps - 1) / ktps;
   float* part = splits > 1 ? ws : nullptr;
   constexpr int NPL = (NPASS == 3) ? 2 : 1;
-  size_t lds = (APL == 3 || APL == 6) ? NPL * (size_t)(2 * BM + 3 * BN) * 64 : 2 * NPL * (size_t)(BM + BN) * 64;     // APL 3: three weight stages
+  size_t lds = (APL == 3) ? NPL * (size_t)(2 * BM + 3 * BN) * 64 : 2 * NPL * (size_t)(BM + BN) * 64;     // APL 3: three weight stages
   if (lds < (size_t)BM * BN * 4) lds = (size_t)BM * BN * 4;     // the epilogue transposes the C tile through LDS
   static bool attr_set = false;
   if (!attr_set) {
@@ -1298,37 +1229,6 @@ static int launch_bf16_tall(const ddpo_gemm_desc& d, const uint16_t* w_hi, const
   return DDPO_OK;
 }
 
-// timing ablations of the 128x128 bf16x3 k-loop (results are WRONG for mode != 0); used by tools/ablate_gemm.py only
-template <int ABL>
-static void launch_abl(const ddpo_gemm_desc& d, const uint16_t* w_hi, const uint16_t* w_lo, int ldw, hipStream_t st) {
-  const int tiles_m = (d.M + 127) / 128, tiles_n = (d.N + 127) / 128, nblk = tiles_m * tiles_n;
-  const size_t lds = 2 * 2 * (size_t)(128 + 128) * 64;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_bf16_buf_kernel<128, 128, 3, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  const int nk = d.K / BF_BK;
-  hipLaunchKernelGGL((gemm_conv_bf16_buf_kernel<128, 128, 3, ABL>), dim3(nblk, 1), dim3(BF_THREADS), lds, st, d, w_hi, w_lo, ldw, tiles_m, tiles_n,
-                     nblk, (nk + 1) & ~1, (float*)nullptr);
-}
-extern "C" int ddpo_debug_gemm_ablate(const ddpo_gemm_desc* dp, const uint16_t* w_hi, const uint16_t* w_lo, int ldw, int mode, void* stream) {
-  if (!dp || !buf_path_ok(*dp, ldw)) return DDPO_EINVAL;
-  hipStream_t st = as_stream(stream);
-  switch (mode) {
-    case 0: launch_abl<0>(*dp, w_hi, w_lo, ldw, st); break;
-    case 1: launch_abl<1>(*dp, w_hi, w_lo, ldw, st); break;
-    case 2: launch_abl<2>(*dp, w_hi, w_lo, ldw, st); break;
-    case 6: launch_abl<6>(*dp, w_hi, w_lo, ldw, st); break;
-    case 7: launch_abl<7>(*dp, w_hi, w_lo, ldw, st); break;
-    case 8: launch_abl<8>(*dp, w_hi, w_lo, ldw, st); break;
-    case 15: launch_abl<15>(*dp, w_hi, w_lo, ldw, st); break;
-    case 16: launch_abl<16>(*dp, w_hi, w_lo, ldw, st); break;
-    case 31: launch_abl<31>(*dp, w_hi, w_lo, ldw, st); break;
-    case 47: launch_abl<47>(*dp, w_hi, w_lo, ldw, st); break;
-    case 63: launch_abl<63>(*dp, w_hi, w_lo, ldw, st); break;
-    default: return DDPO_EINVAL;
-  }
-  DDPO_LAUNCH_CHECK();
-  return DDPO_OK;
-}
-
 // Tile-shape / split-K selection shared by the fp32-fed and the plane-fed entry points: the SAME rules, so both produce
 // bit-identical results for the same layer (APL is only instantiated for npass == 3).
 template <int APL>
@@ -1340,23 +1240,19 @@ static int dispatch_bf16(const ddpo_gemm_desc& d, const uint16_t* w_hi, const ui
     return npass == 3 ? launch_bf16<128, 128, 3, 2, 2, APL>(d, w_hi, w_lo, ldw, nullptr, 0, st) : launch_bf16<128, 128, 1>(d, w_hi, w_lo, ldw, nullptr, 0, st);
   }
   float* wsf = (ws && !(reinterpret_cast<uintptr_t>(ws) & 15)) ? reinterpret_cast<float*>(ws) : nullptr;
-  static const int wide_mode = [] { const char* e = getenv("DDPO_GEMM_WIDE"); return e ? atoi(e) : 1; }();   // tuning knob: 0 disables 128x320
+  constexpr int wide_mode = 1;
   // 128x320 tiles (one workgroup per CU) when they, times the split of the reduction, give every CU a workgroup; a
   // many-column GEMM with a very short reduction is better on 128x128 (measured: K=320, N=2560; the 160 KB epilogue image)
   if constexpr (APL != 0) {
     // 256x320 tiles where they still give every CU a workgroup (the 64x64-latent level): 345 / 428 TF against 320 / 390 for the
-    // 128x320 tile on conv 320->320 / 960->320 (bit-identical; round-2 probe).  DDPO_APL_TALL=0 switches them off.
-    static const int tall_mode = [] { const char* e = getenv("DDPO_APL_TALL"); return e ? atoi(e) : 1; }();
+    // 128x320 tile on conv 320->320 / 960->320 (bit-identical; round-2 probe).
+    constexpr int tall_mode = 1;
     // ... and where their last round of 256 is not much emptier than the 128x320 grid's: 256 tall tiles (SD-1.5, 64x64 latents at batch 16)
     // are exactly one round; 576 (SD-2.1, 96x96) are 2.25 rounds = 3 rounds of time, where 1152 wide tiles waste half a round of five
     const long ntall = (long)((d.M + 255) / 256) * (d.N / 320), nwide = (long)((d.M + 127) / 128) * (d.N / 320);
     const double eff_tall = (double)ntall / (double)(((ntall + 255) / 256) * 256), eff_wide = (double)nwide / (double)(((nwide + 255) / 256) * 256);
-    if (tall_mode && d.N % 320 == 0 && d.epilogue == 0 && ntall >= 200 && (tall_mode == 2 || eff_tall * 1.08 >= eff_wide))     // DDPO_APL_TALL=2: without the round rule (A/B)
-    {
-      // DDPO_TALL_ROT (default 1): rotated schedule, the two waves of a SIMD alternate between fragment reads / DMA issue and MFMAs
-      static const int tall_rot = [] { const char* e = getenv("DDPO_TALL_ROT"); return e ? atoi(e) : 1; }();
-      return tall_rot ? launch_bf16_tall<5>(d, w_hi, w_lo, ldw, st) : launch_bf16_tall<4>(d, w_hi, w_lo, ldw, st);
-    }
+    if (tall_mode && d.N % 320 == 0 && d.epilogue == 0 && ntall >= 200 && eff_tall * 1.08 >= eff_wide)
+      return launch_bf16_tall<5>(d, w_hi, w_lo, ldw, st);
   }
   const int wsplits = wide_splits(d, wsf != nullptr, ws_bytes);
   if (wide_mode && d.N % 320 == 0 && d.M >= 512 && buf_path_ok(d, ldw) && !(d.K / BF_BK < 16 && d.N > 1280) &&
@@ -1365,11 +1261,11 @@ static int dispatch_bf16(const ddpo_gemm_desc& d, const uint16_t* w_hi, const ui
     return npass == 3 ? launch_bf16_wide<3, APL>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st) : launch_bf16_wide<1>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st);
   }
   const long t128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128);
-  static const long big_min = [] { const char* e = getenv("DDPO_GEMM_BIG_MIN"); return e ? atol(e) : 256L; }();   // tuning knob (tools/)
+  constexpr long big_min = 256;
   // 128x128 tiles need >= 512 of them to fill both workgroup slots of every CU; a short reduction on 256..511 of them (the 16x16
   // level's q / k / v / out projections: M = 4096, N = K = 1280 -> 320 tiles) runs ~15 % faster on 640 tiles of 128x64, three per CU
-  // (probe, cold weights: 0.084 -> 0.070 ms fp32-fed; profiles/r02_probe_tiles_small.log).  DDPO_GEMM_MID64=0 restores 128x128.
-  static const int mid64 = [] { const char* e = getenv("DDPO_GEMM_MID64"); return e ? atoi(e) : 1; }();
+  // (probe, cold weights: 0.084 -> 0.070 ms fp32-fed; profiles/r02_probe_tiles_small.log).
+  constexpr int mid64 = 1;
   const bool mid_short = mid64 && t128 < 512 && d.K / BF_BK <= 64;
   const bool big = (d.N % 128 == 0) && t128 >= big_min && !mid_short;
   if (npass == 3)
@@ -1423,22 +1319,15 @@ extern "C" int ddpo_gemm_conv_fwd_bf16_planes(const ddpo_gemm_desc* dp, const ui
   d.w = reinterpret_cast<const float*>(a_lo);
   d.ld_src = lda;
   if (!buf_path_ok(d, ldw)) return DDPO_EINVAL;      // Cin (K) % 32 == 0 and 31-bit byte offsets: callers keep such layers on the fp32-fed entry
-  // DDPO_APL_MODE (tuning knob, read once): 2 = two LDS stages, barrier in the middle of the k-tile with the fragment reads
-  // software-pipelined across it; 3 = the same with the weight operand three LDS stages deep (requested two k-tiles ahead, counted
-  // vmcnt); +4 (6 / 7) = the upper half of the waves requests its pieces half a k-tile later than the lower half, so the two waves of a
-  // SIMD alternate between DMA issue and MFMAs.  Measured on the SD-1.5 layers at batch 16 (profiles/r01_probe_gemm_planes_modes.md and
-  // round 2): warm, 6 ~ 7 > 2; with the caches flushed before every launch (weights cold = the in-model condition) 7 keeps its gain
-  // (400 TF on conv 960->320 @ 64^2) while 6 drops to 359.  7 is the default.  Rejected after measurement and removed in round 2: the
-  // plain wait / barrier / request / compute loop (mode 1), s_setprio around the MFMA clusters (10 / 14: no effect), the four-wave
-  // 128x320 tile (slower), a 128x160 tile with two workgroups per CU for short reductions (no gain, profiles/r02_probe_n160.log).
-  static const int apl_mode = [] { const char* e = getenv("DDPO_APL_MODE"); return e ? atoi(e) : 7; }();
-  d.splits = (apl_mode & 4) ? 1 : 0;                 // `splits` is a wgrad-only field: the forward kernel reads it as the stagger flag
+  // k-loop of the 128-row tiles: weights three LDS stages deep (requested two k-tiles ahead, counted vmcnt), activations two; the upper half
+  // of the waves requests its pieces half a k-tile later than the lower half (d.splits bit 0), so the two waves of a SIMD alternate between
+  // DMA issue and MFMAs.  Measured and removed (rounds 1-3): the plain wait / barrier / request / compute loop, two weight stages, no stagger,
+  // s_setprio around the MFMA clusters, four-wave 128x320 and 128x160 tiles, requests spread one per accumulator block (profiles/r03_probe_kloop.log).
+  d.splits = 1;                                      // `splits` is a wgrad-only field: the forward kernel reads bit 0 as the stagger flag
 #ifdef DDPO_KLOOP_TIMING
   { const char* e = getenv("DDPO_DBG_ABL"); if (e) d.splits |= atoi(e) << 4; }
 #endif
-  if ((apl_mode & 3) == 3 && (apl_mode & 8)) return dispatch_bf16<6>(d, w_hi, w_lo, ldw, 3, ws, ws_bytes, as_stream(stream));      // 11 / 15: three weight stages, requests spread over the MFMA blocks
-  if ((apl_mode & 3) == 3) return dispatch_bf16<3>(d, w_hi, w_lo, ldw, 3, ws, ws_bytes, as_stream(stream));      // three weight stages (7 = + stagger)
-  return dispatch_bf16<2>(d, w_hi, w_lo, ldw, 3, ws, ws_bytes, as_stream(stream));
+  return dispatch_bf16<3>(d, w_hi, w_lo, ldw, 3, ws, ws_bytes, as_stream(stream));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1873,9 +1762,9 @@ static int wgrad_bf16x3(const ddpo_gemm_desc* dp, const uint16_t* a_hi, const ui
   splits = (d.M + mps - 1) / mps;
   hipStream_t st = as_stream(stream);
   const dim3 grid(tiles, splits), blk(BF_THREADS);
-  // row loader for the regular layers (default; DDPO_WGRAD_ROWS=0 = always the per-pixel loader): conv 320->320 @ 64^2, U-Net batch 64:
+  // row loader for the regular layers (the per-pixel loader takes the rest): conv 320->320 @ 64^2, U-Net batch 64:
   // 2.54 -> 2.05 ms (190 -> 236 TF), profiles/r02_ab_wgrad_rows.log
-  static const int rows_mode = [] { const char* e = getenv("DDPO_WGRAD_ROWS"); return e ? atoi(e) : 1; }();
+  constexpr int rows_mode = 1;
   const bool conv_ = d.ksize > 0;
   const bool simple_ = !conv_ || (d.stride == 1 && d.upsample == 0 && d.OH == d.H && d.OW == d.W);
   const int64_t lda_b = d.ld_src ? d.ld_src : (conv_ ? d.Cin : d.K), ldb_b = d.ld_w ? d.ld_w : d.N;      // k-blocked planes: the same bytes in all

@@ -87,8 +87,6 @@ _SIGS = {
     "ddpo_attention_fwd_bf16x3": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int,
                                           c_int, c_int, c_int, c_float, c_void_p, c_size_t, c_void_p]),
     "ddpo_attention_fwd_bf16x3_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
-    "ddpo_debug_force_generic_gemm": (None, [c_int]),
-    "ddpo_debug_gemm_ablate": (c_int, [POINTER(GemmDesc), c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "ddpo_attention_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "ddpo_attention_bwd_bf16x3": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -271,14 +271,6 @@ int ddpo_attention_bwd_bf16x3(const float* q, int ldq, const float* k, int ldk, 
                               const float* d_o, const float* lse, float* dvec, float* dq, float* dk, float* dv,
                               int B, int heads, int Nq, int Nk, int d, float scale, void* stream);
 
-/* Diagnostics, not used by the product path (tools/ablate_gemm.py, tools/bench_kernels.py):
- *   ddpo_debug_force_generic_gemm(1) routes every bf16 GEMM through the pointer-addressed generic kernel (A/B timing);
- *   ddpo_debug_gemm_ablate launches the 128x128 bf16x3 k-loop with parts removed (mode bits: 1 global loads, 2 split +
- *   LDS stores, 4 barriers, 8 fragment reads, 16 epilogue stores, 32 prologue loads) — results are WRONG by design.
- * Environment tuning knobs read once by ddpo_gemm_conv_fwd_bf16: DDPO_GEMM_WIDE=0 disables the 128x320 tiles,
- * DDPO_GEMM_BIG_MIN=<tiles> moves the 128x128 / 128x64 switch-over (default 256). */
-void ddpo_debug_force_generic_gemm(int on);
-int ddpo_debug_gemm_ablate(const ddpo_gemm_desc* d, const uint16_t* w_hi, const uint16_t* w_lo, int ldw, int mode, void* stream);
 
 /* Small element-wise pieces. */
 int ddpo_geglu_fwd(const float* x, float* y, int64_t rows, int F, void* stream);      /* y = x[:, :F] * gelu_tanh(x[:, F:]) */

@@ -271,22 +271,21 @@ def test_unet_and_vae_forward_unchanged_by_planes(model, monkeypatch):
     assert torch.equal(img_fp, img_pl)
 
 
-@pytest.mark.parametrize("mode", [2, 6, 3, 7, "tall"])
-def test_kernel_probe_all_k_loop_variants_bit_identical(mode):
-    """tools/native/kernel_probe gemm2 compares the plane-fed kernel with the fp32-fed one output by output on 23 layer shapes
-    (conv borders, strides, upsampling, ragged M / N, split-K) and exits non-zero on any mismatch.  DDPO_APL_MODE is read once
-    per process, so each k-loop variant gets its own probe process.  (Mode 1, the s_setprio variants 10 / 14 and the four-wave tile
-    were measured slower or equal in round 2 and removed from the library.)"""
+@pytest.mark.parametrize("batch,wkblk", [("4", "0"), ("4", "1"), ("16", "0"), ("16", "1")])
+def test_kernel_probe_plane_fed_kernels_bit_identical(batch, wkblk):
+    """tools/native/kernel_probe gemm2 compares the plane-fed kernels with the fp32-fed ones output by output on 26 layer shapes
+    (conv borders, strides, upsampling, ragged M / N, split-K) through the C ABI alone (no torch) and exits non-zero on any mismatch.
+    Batch 4 keeps every layer on the 128-row tiles (three weight stages, staggered requests); batch 16 moves the 64x64-level layers to
+    the 256x320 tile (rotated schedule).  Both forward weight-plane layouts (row-major, k-blocked).  The k-loop variants that lost
+    their measurements (two weight stages, no stagger, plain tall loop, spread requests, s_setprio, four-wave tiles) are no longer in
+    the library (profiles/r02_ab_apl_mode.log, profiles/r03_probe_kloop.log)."""
     import os
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = os.path.join(root, "tools", "native", "kernel_probe")
     if not os.path.exists(exe):
         pytest.skip("tools/native/kernel_probe not built (python __graft_entry__.py)")
-    env, batch = dict(os.environ, DDPO_APL_MODE=str(mode), DDPO_APL_TALL="0"), "4"
-    if mode == "tall":                                  # 256x320 tiles (DDPO_APL_TALL=1) apply from 200 tiles on: batch 16 at the 64^2 level
-        env, batch = dict(os.environ, DDPO_APL_TALL="1", DDPO_APL_MODE="6"), "16"
-    out = subprocess.run([exe, "gemm2", batch, "2"], env=env, capture_output=True, text=True, timeout=300)
+    out = subprocess.run([exe, "gemm2", batch, "2"], env=dict(os.environ, PROBE_WKBLK=wkblk), capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-1000:]
     assert "FAIL" not in out.stdout and out.stdout.count("bit-identical") >= 20
 

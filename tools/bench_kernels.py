@@ -53,9 +53,7 @@ def attn_case(B, heads, Nq, Nk, d):
 
 if __name__ == "__main__":
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-    if os.environ.get("DDPO_GEMM_GENERIC") == "1":       # A/B: route every bf16 GEMM through the generic (pointer-addressed) kernel
-        L.load().ddpo_debug_force_generic_gemm(1)
-    print(f"batch {B} datapath {L.DATAPATH} generic={os.environ.get('DDPO_GEMM_GENERIC', '0')}")
+    print(f"batch {B} datapath {L.DATAPATH}")
     for (H, Cin, Cout, ks, st, up) in [(64, 320, 320, 3, 1, False), (32, 640, 640, 3, 1, False), (16, 1280, 1280, 3, 1, False),
                                        (8, 1280, 1280, 3, 1, False), (64, 960, 320, 3, 1, False), (32, 1920, 640, 3, 1, False),
                                        (16, 2560, 1280, 3, 1, False), (8, 2560, 1280, 3, 1, False), (32, 640, 640, 3, 1, True),

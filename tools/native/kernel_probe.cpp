@@ -543,10 +543,8 @@ int main(int argc, char** argv) {
   const int B = argc > 2 ? atoi(argv[2]) : 16, iters = argc > 3 ? atoi(argv[3]) : 10;
   hipDeviceProp_t prop;
   HIP_OK(hipGetDeviceProperties(&prop, 0));
-  printf("# %s (%s, %d CUs), libddpo_hip ABI v%d, mode %s, batch %d, DDPO_GEMM_WIDE=%s DDPO_GEMM_BIG_MIN=%s DDPO_APL_MODE=%s DDPO_APL_TALL=%s PROBE_COLD=%s\n",
-         prop.name, prop.gcnArchName, prop.multiProcessorCount, ddpo_abi_version(), mode.c_str(), B,
-         getenv("DDPO_GEMM_WIDE") ? getenv("DDPO_GEMM_WIDE") : "-", getenv("DDPO_GEMM_BIG_MIN") ? getenv("DDPO_GEMM_BIG_MIN") : "-",
-         getenv("DDPO_APL_MODE") ? getenv("DDPO_APL_MODE") : "-", getenv("DDPO_APL_TALL") ? getenv("DDPO_APL_TALL") : "-",
+  printf("# %s (%s, %d CUs), libddpo_hip ABI v%d, mode %s, batch %d, PROBE_WKBLK=%s PROBE_COLD=%s\n", prop.name, prop.gcnArchName,
+         prop.multiProcessorCount, ddpo_abi_version(), mode.c_str(), B, getenv("PROBE_WKBLK") ? getenv("PROBE_WKBLK") : "-",
          getenv("PROBE_COLD") ? getenv("PROBE_COLD") : "-");
   int rc;
   if (mode == "gemm") rc = probe_gemm(B, iters);

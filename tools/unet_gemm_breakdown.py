@@ -65,7 +65,7 @@ else:
     pl = measure(True)
     tot2 = sum(a[1] for a in pl.values())
     print(f"planes  : total gemm/conv ms {tot2:.2f}; {sum(a[2] for a in pl.values())/tot2/1e9:.1f} TF avg; "
-          f"{sum(a[0] for a in pl.values() if a[3])} launches plane-fed (DDPO_APL_MODE={os.environ.get('DDPO_APL_MODE', 'default')})")
+          f"{sum(a[0] for a in pl.values() if a[3])} launches plane-fed")
     for sh, a in sorted(base.items(), key=lambda kv: -kv[1][1])[:32]:
         b = pl.get(sh)
         if b is None:
