@@ -644,11 +644,40 @@ class UNet2DCondition:
         return out
 
     # -------------------------------------------------------------------------------- backward
-    def backward(self, tape, d_out):
+    class _Progress:
+        """Which suffix of the flat gradient buffer is final: blocks report themselves by name prefix, the answer is the offset of the
+        first parameter of the longest fully-reported run of parameters at the END of the buffer (independent of how resnets and
+        attentions of a block interleave in the layout)."""
+
+        def __init__(self, offsets):
+            self.names = list(offsets)
+            self.offs = [offsets[n] for n in self.names]
+            self.fin = [False] * len(self.names)
+            self.ptr = len(self.names)                   # parameters [ptr:] are final
+
+        def report(self, prefix):
+            for i, n in enumerate(self.names):
+                if n.startswith(prefix):
+                    self.fin[i] = True
+            while self.ptr > 0 and self.fin[self.ptr - 1]:
+                self.ptr -= 1
+            return self.offs[self.ptr] if self.ptr < len(self.offs) else None
+
+    def backward(self, tape, d_out, on_ready=None):
         """Accumulates d loss / d params into self.grads given d loss / d output (B,C_out,H,W) and the tape of `forward`.
-        (The latents and the text context are not differentiated: DDPO only needs parameter gradients.)"""
+        (The latents and the text context are not differentiated: DDPO only needs parameter gradients.)
+        on_ready(lo): called after the kernels of each block have been queued — every gradient at flat offset >= lo is then final
+        on this stream (the backward runs through the parameters from the end of the buffer to its start); the data-parallel
+        trainer hangs the bucketed all-reduce on it (training/distributed.GradBucketer)."""
         P, cfg = self.params, self.cfg
         G = self.ensure_grads()
+        prog = UNet2DCondition._Progress(self.params.offsets) if on_ready is not None else None
+
+        def done(prefix):
+            if prog is not None:
+                lo = prog.report(prefix + ".")
+                if lo is not None:
+                    on_ready(lo)
         kind, head = tape[0]
         assert kind == "head"
         tctx = dict(temb_act=head["temb_act"], d_temb_act=None)
@@ -662,12 +691,16 @@ class UNet2DCondition:
         d = L.conv2d_dgrad(d, P["conv_out.kernel"], B, H, W, x.C, cfg.out_channels, 3)
         d = L.groupnorm_bwd(x.t, d, tail["st"], P["conv_norm_out.scale"], B, x.HW, cfg.norm_groups, True,
                             G["conv_norm_out.scale"], G["conv_norm_out.bias"])
+        done("conv_out")
+        done("conv_norm_out")
         skip_grads = []          # filled by the (reversed) up path: ends up in forward production order, consumed from the end
         for kind, r in reversed(tape[1:-1]):
             if kind == "resnet":
                 d = resnet_backward(P, G, r, d, tctx)
+                done(r["name"])
             elif kind == "transformer":
                 d = self._transformer_backward(r, d)
+                done(r["name"])
             elif kind == "concat":
                 rows = d.shape[0]
                 d_h = torch.empty(rows, r["c0"], dtype=torch.float32, device=self.device)
@@ -682,11 +715,13 @@ class UNet2DCondition:
                 L.colsum_accum(d, G[name + ".bias"])
                 d_up = L.conv2d_dgrad(d, P[name + ".kernel"], xx.B, 2 * xx.H, 2 * xx.W, xx.C, xx.C, 3)
                 d = L.sumpool2x2(d_up, xx.B, xx.H, xx.W, xx.C)
+                done(name)
             elif kind == "down":
                 xx, name = r["x"], r["name"]
                 L.conv2d_wgrad(xx.t, d, G[name + ".kernel"], xx.B, xx.H, xx.W, xx.C, xx.C, 3, stride=2, pad=1)
                 L.colsum_accum(d, G[name + ".bias"])
                 d = L.conv2d_dgrad(d, P[name + ".kernel"], xx.B, xx.H, xx.W, xx.C, xx.C, 3, stride=2)
+                done(name)
             elif kind == "skip_push":
                 # the activation produced just before this marker was also a skip connection: add its up-path grad.
                 d = L.add(d, skip_grads.pop())

