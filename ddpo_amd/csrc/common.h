@@ -70,4 +70,35 @@ __host__ __device__ __forceinline__ int64_t plane_off(int64_t row, int c, int ld
   return ld ? row * ld + c : ((int64_t)(c >> 5) * rows + row) * 32 + (c & 31);
 }
 
+// ---- "f16mx" operand format (ABI v7): x ~= h + l with h = f16(x) (round to nearest even) and the 8-bit parts the CROSS terms of
+// a product use: a*b ~= a_h*b_h (16-bit MFMA) + a_h8*b_l8 + a_l8*b_h8 (ONE block-scaled 8-bit MFMA, v_mfma_scale_f32_32x32x64_f8f6f4,
+// lanes 0-31 carrying the first pair and lanes 32-63 the second).  ACTIVATIONS: e5m2 at a FIXED scale — h8 = e5m2(h) (the f16 value
+// rounded to two mantissa bits; same exponent range, so no block scale has to be computed, stored or fetched), l8 = e5m2(l * 2^11)
+// (|l| <= 2^-11 |x|).  Two planes of the geometry of the bf16 hi / lo planes: `p16` holds h, `p8` holds per 32-channel block the
+// 64 bytes [h8 x 32 | l8 x 32].  WEIGHTS: e4m3 with one power-of-two scale per output column (ddpo_pack_weights_f16mx).
+typedef _Float16 mx_half2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void mx_split4(const float4 v, uint2& h16, uint32_t& h8, uint32_t& l8) {
+  const float lim = 65504.f;              // f16 range: larger magnitudes saturate (Stable Diffusion runs in f16 end to end)
+  const _Float16 a = (_Float16)fminf(fmaxf(v.x, -lim), lim), b = (_Float16)fminf(fmaxf(v.y, -lim), lim);
+  const _Float16 c = (_Float16)fminf(fmaxf(v.z, -lim), lim), e = (_Float16)fminf(fmaxf(v.w, -lim), lim);
+  h16.x = __builtin_bit_cast(uint32_t, mx_half2{a, b});
+  h16.y = __builtin_bit_cast(uint32_t, mx_half2{c, e});
+  const float ha = (float)a, hb = (float)b, hc = (float)c, he = (float)e;
+  int p = __builtin_amdgcn_cvt_pk_bf8_f32(ha, hb, 0, false);
+  h8 = (uint32_t)__builtin_amdgcn_cvt_pk_bf8_f32(hc, he, p, true);
+  p = __builtin_amdgcn_cvt_pk_bf8_f32((v.x - ha) * 2048.f, (v.y - hb) * 2048.f, 0, false);
+  l8 = (uint32_t)__builtin_amdgcn_cvt_pk_bf8_f32((v.z - hc) * 2048.f, (v.w - he) * 2048.f, p, true);
+}
+// 4 consecutive channels c .. c+3 (c % 4 == 0) of `row` into the two f16mx planes (p16 / p8 addressed like bf16 planes: plane_off)
+__device__ __forceinline__ void mx_store4(uint16_t* __restrict__ p16, uint16_t* __restrict__ p8, int64_t row, int c, int ld, int64_t rows,
+                                          const float4 v) {
+  uint2 h16;
+  uint32_t h8, l8;
+  mx_split4(v, h16, h8, l8);
+  *reinterpret_cast<uint2*>(p16 + plane_off(row, c, ld, rows)) = h16;
+  char* b = reinterpret_cast<char*>(p8 + plane_off(row, c & ~31, ld, rows)) + (c & 31);
+  *reinterpret_cast<uint32_t*>(b) = h8;
+  *reinterpret_cast<uint32_t*>(b + 32) = l8;
+}
+
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }

@@ -57,6 +57,9 @@ extern "C" int ddpo_debug_kloop_times(unsigned long long* host, int n_wg) {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 #define BF_BK 32
 #define BF_THREADS 256
@@ -67,10 +70,25 @@ __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t&
   lo = cvt_pk_bf16(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xFFFF0000u));
 }
 
+// the f16mx cross-term MFMA: A = e5m2 (cbsz 1), B = e4m3 (blgp 0); the weight scale is byte `opb` of `sb` (op_sel is an immediate: the
+// switch folds away in unrolled callers)
+__device__ __forceinline__ f32x16 mx_mfma(const i32x8 a, const i32x8 b, const f32x16 c, int sa, int opb, int sb) {
+  switch (opb) {
+    case 0: return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 1, 0, 0, sa, 0, sb);
+    case 1: return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 1, 0, 0, sa, 1, sb);
+    case 2: return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 1, 0, 0, sa, 2, sb);
+    default: return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 1, 0, 0, sa, 3, sb);
+  }
+}
+
 __device__ __forceinline__ int swz_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }   // bytes
 
 // plane-emitting output stage: 4 consecutive output values -> 4 bf16 hi + 4 bf16 lo (the split the fp32-fed loader would apply)
 __device__ __forceinline__ void store_planes4(const ddpo_gemm_desc& d, int64_t row, int col, const float4 v) {
+  if (d.planes_fmt == 1) {                                            // f16mx planes (common.h)
+    mx_store4(d.out_hi, d.out_lo, row, col, d.ld_planes, d.M, v);
+    return;
+  }
   uint2 h, l;
   split4(v, h, l);
   const int64_t o = plane_off(row, col, d.ld_planes, d.M);           // ld_planes == 0: k-blocked planes (ncols / 32, M, 32)
@@ -397,7 +415,9 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
   constexpr int BCH = (BN + BR - 1) / BR;
   constexpr bool BFULL = (BN % BR) == 0;                // else the last W pass covers only part of the threads
   static_assert(BM % AR == 0 && WTM % 32 == 0 && WTN % 32 == 0, "tile / wave-grid mismatch");
-  constexpr int NPL = (NPASS == 3) ? 2 : 1;
+  constexpr bool MX = NPASS == 4;                       // f16mx datapath (plane-fed only): f16 plane + 8-bit plane per operand
+  static_assert(!MX || APL == 3, "the f16mx datapath exists on the plane-fed 128-row tiles only");
+  constexpr int NPL = (NPASS >= 3) ? 2 : 1;
   constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int STAGE = NPL * (A_BYTES + B_BYTES);
@@ -446,7 +466,11 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
   // Fragment loads are software-pipelined by hand across the barrier: the ks=0 fragments of the NEXT k-tile are requested
   // right after the barrier that publishes it and the second half of the current tile's ks=1 MFMAs is issued behind them,
   // so the LDS latency is covered by matrix work instead of stalling the wave at the top of every k-tile.
-  struct Frag { bf16x8 ah[TM], al[TM], bh[TN], bl[TN]; };
+  // f16mx: the 16-bit fragments are f16 (same bytes, same offsets), and at ks = 1 each operand's 32 bytes of the 8-bit plane are read as
+  // one fragment: lanes 0-31 the chunks 0, 1 of the row (A: h8, W: l8), lanes 32-63 the chunks 2, 3 (A: l8, W: h8) — the two cross terms
+  // of the k-tile ride in the two lane halves of ONE 32x32x64 MFMA.  Chunk c sits at a_ld0 ^ (16 * (c ^ khalf)) (swz_off is an XOR).
+  struct Frag { bf16x8 ah[TM], al[TM], bh[TN], bl[TN]; i32x8 a8[TM], b8[TN]; };
+  const int a_x0 = a_ld0 ^ (khalf * 48), a_x1 = a_ld0 ^ (16 + khalf * 16), b_x0 = b_ld0 ^ (khalf * 48), b_x1 = b_ld0 ^ (16 + khalf * 16);
   auto ldfrag_at = [&](const char* sa, const char* sb, int ks, Frag& f) {
     const char* pa = sa + (ks ? a_ld1 : a_ld0);
     const char* pb = sb + (ks ? b_ld1 : b_ld0);
@@ -454,23 +478,50 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
     for (int i = 0; i < TM; ++i) {
       f.ah[i] = *reinterpret_cast<const bf16x8*>(pa + i * 2048);
       if (NPASS == 3) f.al[i] = *reinterpret_cast<const bf16x8*>(pa + A_BYTES + i * 2048);
+      if (MX && ks) {
+        const i32x4 x = *reinterpret_cast<const i32x4*>(sa + a_x0 + A_BYTES + i * 2048), y = *reinterpret_cast<const i32x4*>(sa + a_x1 + A_BYTES + i * 2048);
+        f.a8[i] = i32x8{x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
+      }
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       f.bh[j] = *reinterpret_cast<const bf16x8*>(pb + j * 2048);
       if (NPASS == 3) f.bl[j] = *reinterpret_cast<const bf16x8*>(pb + B_BYTES + j * 2048);
+      if (MX && ks) {
+        const i32x4 x = *reinterpret_cast<const i32x4*>(sb + b_x0 + B_BYTES + j * 2048), y = *reinterpret_cast<const i32x4*>(sb + b_x1 + B_BYTES + j * 2048);
+        f.b8[j] = i32x8{x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
+      }
     }
   };
   auto ldfrag = [&](int cur, int ks, Frag& f) {
     const char* sa = smem + cur * STAGE;
     ldfrag_at(sa, sa + NPL * A_BYTES, ks, f);
   };
-  auto mma = [&](const Frag& f, int tbeg, int tend) {       // 32x32 blocks [tbeg, tend) of the wave tile, row-major
+  // f16mx block scales (E8M0 bytes, 2^(byte - 127)): activations are stored at scale 1 (h8) and 2^-11 (l8 = l * 2^11); a weight column
+  // at its own scale s_n (h8) and s_n * 2^-11 (l8).  Lane half 0 multiplies a_h8 * w_l8, lane half 1 a_l8 * w_h8.
+  int mx_sa = 0, mx_sbp[(TN + 3) / 4];          // weight scales: byte (j & 3) of register j >> 2 (the MFMA's op_sel picks the byte)
+  if constexpr (MX) {
+    mx_sa = khalf ? 127 - 11 : 127;
+#pragma unroll
+    for (int q = 0; q < (TN + 3) / 4; ++q) mx_sbp[q] = 0;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * WTN + j * 32 + (lane & 31);
+      const int sc = n < d.N ? (int)d.w_scale[n] : 127;
+      mx_sbp[j >> 2] |= (khalf ? sc : sc - 11) << (8 * (j & 3));
+    }
+  }
+  auto mma = [&](const Frag& f, int tbeg, int tend, int ks = 0) {       // 32x32 blocks [tbeg, tend) of the wave tile, row-major
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         if (i * TN + j < tbeg || i * TN + j >= tend) continue;
+        if constexpr (MX) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f.ah[i]), __builtin_bit_cast(f16x8, f.bh[j]), acc[i][j], 0, 0, 0);
+          if (ks) acc[i][j] = mx_mfma(f.a8[i], f.b8[j], acc[i][j], mx_sa, j & 3, mx_sbp[j >> 2]);
+          continue;
+        }
         if (NPASS == 3) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
@@ -482,7 +533,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
 
   if constexpr (APL != 0) {
     // ---------------- LDS-DMA path: A planes + W planes straight into the swizzled LDS image ----------------
-    static_assert(NPASS == 3, "the plane-fed path is the bf16x3 datapath");
+    static_assert(NPASS == 3 || NPASS == 4, "the plane-fed path is the bf16x3 / f16mx datapath");
     constexpr int NW = WM * WN, PAIRS = NW / 2;          // even waves move hi planes, odd waves lo planes
     constexpr int GA = BM / 16, GB = BN / 16;            // 16-row groups = 1 KiB LDS-DMA pieces per plane
     static_assert(NW % 2 == 0 && GA % PAIRS == 0 && GB % PAIRS == 0, "pieces must divide evenly over the wave pairs");
@@ -702,14 +753,14 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
         }
         if (kt + 1 < nk) ldfrag3(as_n * A_STAGE, ws_n * W_STAGE, 0, g0);
         __builtin_amdgcn_sched_barrier(0);
-        if (!DBG_ABL(2)) mma(g1, 0, (TM * TN) / 2);
+        if (!DBG_ABL(2)) mma(g1, 0, (TM * TN) / 2, 1);
         else asm volatile("" :: "v"(g1.ah[0]), "v"(g1.bl[TN - 1]), "v"(g1.al[TM - 1]), "v"(g1.bh[0]));
         __builtin_amdgcn_sched_barrier(0);
         if (late && !DBG_ABL(1)) {
           if (kt + 2 < nk) fill_a(as);
           if (kt + 3 < nk) fill_w(ws);
         }
-        if (!DBG_ABL(2)) mma(g1, (TM * TN) / 2, TM * TN);
+        if (!DBG_ABL(2)) mma(g1, (TM * TN) / 2, TM * TN, 1);
         __builtin_amdgcn_sched_barrier(0);
         as = as_n; ws = ws_n;
       }
@@ -1080,6 +1131,7 @@ static bool planes_out_ok(const ddpo_gemm_desc& d) {
   if ((reinterpret_cast<uintptr_t>(d.out_hi) | reinterpret_cast<uintptr_t>(d.out_lo)) & 7) return false;
   const int ncols = d.epilogue == 1 ? d.N / 2 : d.N;
   if (d.ld_planes == 0 ? (ncols & 31) != 0 : d.ld_planes < ncols) return false;      // 0: k-blocked (ncols / 32, M, 32)
+  if (d.planes_fmt != 0 && (d.planes_fmt != 1 || (ncols & 31) || (d.ld_planes & 31))) return false;      // f16mx planes: whole 32-column blocks
   if (d.N & 3) return false;
   if (d.out && ((d.ld_out & 3) || (reinterpret_cast<uintptr_t>(d.out) & 15))) return false;
   if (d.residual && ((d.ld_res & 3) || (reinterpret_cast<uintptr_t>(d.residual) & 15))) return false;
@@ -1127,28 +1179,35 @@ static int launch_bf16(const ddpo_gemm_desc& d, const uint16_t* w_hi, const uint
   ktps = (ktps + 1) & ~1;                                  // the pipelined loop consumes k-tiles in pairs
   splits = (nk_total + ktps - 1) / ktps;
   float* part = splits > 1 ? ws : nullptr;
-  constexpr int NPL = (NPASS == 3) ? 2 : 1;
+  constexpr int NPL = (NPASS >= 3) ? 2 : 1;
   size_t lds = (APL == 3) ? NPL * (size_t)(2 * BM + 3 * BN) * 64 : 2 * NPL * (size_t)(BM + BN) * 64;     // APL 3: three weight stages
   if (lds < (size_t)BM * BN * 4) lds = (size_t)BM * BN * 4;     // the epilogue transposes the C tile through LDS
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_bf16_kernel<BM, BN, NPASS, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_bf16_kernel<BM, BN, NPASS, false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if constexpr (APL == 0) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_bf16_kernel<BM, BN, NPASS, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_bf16_kernel<BM, BN, NPASS, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_bf16_buf_kernel<BM, BN, NPASS, 0, WM, WN, true, APL>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  if (APL || buf_path_ok(d, ldw))       // the plane-fed entry point has already checked buf_path_ok
+  if constexpr (APL != 0) {                // the plane-fed entry points have already checked buf_path_ok
     hipLaunchKernelGGL((gemm_conv_bf16_buf_kernel<BM, BN, NPASS, 0, WM, WN, true, APL>), dim3(nblk, splits), dim3(64 * WM * WN), lds, st, d, w_hi,
                        w_lo, ldw, tiles_m, tiles_n, nblk, ktps, part);
-  else if (d.upsample == 0)
-    hipLaunchKernelGGL((gemm_conv_bf16_kernel<BM, BN, NPASS, true>), dim3(nblk, splits), dim3(BF_THREADS), lds, st, d, w_hi, w_lo, ldw,
-                       tiles_m, tiles_n, nblk, ktps, part);
-  else
-    hipLaunchKernelGGL((gemm_conv_bf16_kernel<BM, BN, NPASS, false>), dim3(nblk, splits), dim3(BF_THREADS), lds, st, d, w_hi, w_lo, ldw,
-                       tiles_m, tiles_n, nblk, ktps, part);
+  } else {
+    if (buf_path_ok(d, ldw))
+      hipLaunchKernelGGL((gemm_conv_bf16_buf_kernel<BM, BN, NPASS, 0, WM, WN, true, APL>), dim3(nblk, splits), dim3(64 * WM * WN), lds, st, d, w_hi,
+                         w_lo, ldw, tiles_m, tiles_n, nblk, ktps, part);
+    else if (d.upsample == 0)
+      hipLaunchKernelGGL((gemm_conv_bf16_kernel<BM, BN, NPASS, true>), dim3(nblk, splits), dim3(BF_THREADS), lds, st, d, w_hi, w_lo, ldw,
+                         tiles_m, tiles_n, nblk, ktps, part);
+    else
+      hipLaunchKernelGGL((gemm_conv_bf16_kernel<BM, BN, NPASS, false>), dim3(nblk, splits), dim3(BF_THREADS), lds, st, d, w_hi, w_lo, ldw,
+                         tiles_m, tiles_n, nblk, ktps, part);
+  }
   DDPO_LAUNCH_CHECK();
   if (splits > 1) {
     int64_t blocks = ((int64_t)d.M * (d.N >> 2) + 255) / 256;
@@ -1237,6 +1296,7 @@ static int dispatch_bf16(const ddpo_gemm_desc& d, const uint16_t* w_hi, const ui
   if (d.epilogue != 0) {       // GEGLU output stage: 128-wide tiles of the buffer-addressed kernel, vector epilogue only
     if (d.epilogue != 1 || (d.N & 127) || !buf_path_ok(d, ldw) || d.rowbias || d.residual || d.alpha != 1.0f || d.w_dgrad) return DDPO_EINVAL;
     if ((d.ld_out & 3) || (reinterpret_cast<uintptr_t>(d.out) & 15) || (d.bias && (reinterpret_cast<uintptr_t>(d.bias) & 15))) return DDPO_EINVAL;
+    if constexpr (APL == 3) { if (npass == 4) return launch_bf16<128, 128, 4, 2, 2, 3>(d, w_hi, w_lo, ldw, nullptr, 0, st); }
     return npass == 3 ? launch_bf16<128, 128, 3, 2, 2, APL>(d, w_hi, w_lo, ldw, nullptr, 0, st) : launch_bf16<128, 128, 1>(d, w_hi, w_lo, ldw, nullptr, 0, st);
   }
   float* wsf = (ws && !(reinterpret_cast<uintptr_t>(ws) & 15)) ? reinterpret_cast<float*>(ws) : nullptr;
@@ -1251,13 +1311,17 @@ static int dispatch_bf16(const ddpo_gemm_desc& d, const uint16_t* w_hi, const ui
     // are exactly one round; 576 (SD-2.1, 96x96) are 2.25 rounds = 3 rounds of time, where 1152 wide tiles waste half a round of five
     const long ntall = (long)((d.M + 255) / 256) * (d.N / 320), nwide = (long)((d.M + 127) / 128) * (d.N / 320);
     const double eff_tall = (double)ntall / (double)(((ntall + 255) / 256) * 256), eff_wide = (double)nwide / (double)(((nwide + 255) / 256) * 256);
-    if (tall_mode && d.N % 320 == 0 && d.epilogue == 0 && ntall >= 200 && eff_tall * 1.08 >= eff_wide)
+    // (bf16x3 only.  An f16mx tall loop — 8-bit weight fragments streamed per column block beside the 160 accumulators — was built and
+    // measured in round 3: correct, and no faster than either the bf16x3 tall tile or the f16mx 128x320 tile (conv 320->320 @64^2:
+    // 0.326 vs 0.321 / 0.317 ms): at this level the tile is bound by the operand stream, not by the matrix pipe.  profiles/r03_probe_mx_tall.log)
+    if (tall_mode && npass == 3 && d.N % 320 == 0 && d.epilogue == 0 && ntall >= 200 && eff_tall * 1.08 >= eff_wide)
       return launch_bf16_tall<5>(d, w_hi, w_lo, ldw, st);
   }
   const int wsplits = wide_splits(d, wsf != nullptr, ws_bytes);
   if (wide_mode && d.N % 320 == 0 && d.M >= 512 && buf_path_ok(d, ldw) && !(d.K / BF_BK < 16 && d.N > 1280) &&
       (long)((d.M + 127) / 128) * (d.N / 320) * wsplits >= 200 &&
       !(wsplits > 1 && d.K / BF_BK < 64)) {     // a split short reduction only adds the reduce pass (measured equal to 128x128 unsplit)
+    if constexpr (APL == 3) { if (npass == 4) return launch_bf16_wide<4, 3>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st); }
     return npass == 3 ? launch_bf16_wide<3, APL>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st) : launch_bf16_wide<1>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st);
   }
   const long t128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128);
@@ -1268,6 +1332,10 @@ static int dispatch_bf16(const ddpo_gemm_desc& d, const uint16_t* w_hi, const ui
   constexpr int mid64 = 1;
   const bool mid_short = mid64 && t128 < 512 && d.K / BF_BK <= 64;
   const bool big = (d.N % 128 == 0) && t128 >= big_min && !mid_short;
+  if constexpr (APL == 3) {
+    if (npass == 4)
+      return big ? launch_bf16<128, 128, 4, 2, 2, 3>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st) : launch_bf16<128, 64, 4, 2, 2, 3>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st);
+  }
   if (npass == 3)
     return big ? launch_bf16<128, 128, 3, 2, 2, APL>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st) : launch_bf16<128, 64, 3, 2, 2, APL>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st);
   return big ? launch_bf16<128, 128, 1>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st) : launch_bf16<128, 64, 1>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st);
@@ -1328,6 +1396,28 @@ extern "C" int ddpo_gemm_conv_fwd_bf16_planes(const ddpo_gemm_desc* dp, const ui
   { const char* e = getenv("DDPO_DBG_ABL"); if (e) d.splits |= atoi(e) << 4; }
 #endif
   return dispatch_bf16<3>(d, w_hi, w_lo, ldw, 3, ws, ws_bytes, as_stream(stream));
+}
+
+/* f16mx plane-fed variant (include/ddpo_hip.h): same kernel family, NPASS = 4 */
+extern "C" int ddpo_gemm_conv_fwd_f16mx_planes(const ddpo_gemm_desc* dp, const uint16_t* a16, const uint16_t* a8, int lda,
+                                               const uint16_t* w16, const uint16_t* w8, void* ws, size_t ws_bytes, void* stream) {
+  if (!dp || !a16 || !a8 || !w16 || !w8 || !dp->w_scale) return DDPO_EINVAL;
+  ddpo_gemm_desc d = *dp;
+  if (d.M <= 0 || d.N <= 0 || d.K <= 0 || lda < 0 || (lda & 31) || d.w_dgrad || d.w_layout != 1 || !planes_out_ok(d)) return DDPO_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(a16) | reinterpret_cast<uintptr_t>(a8) | reinterpret_cast<uintptr_t>(w16) | reinterpret_cast<uintptr_t>(w8)) & 15)
+    return DDPO_EINVAL;
+  if (d.ksize > 0) {
+    if (d.ksize != 1 && d.ksize != 3) return DDPO_EINVAL;
+    if (d.K != d.ksize * d.ksize * d.Cin || d.M != d.B * d.OH * d.OW || d.upsample < 0 || d.upsample > 2 || (lda && lda < d.Cin)) return DDPO_EINVAL;
+  } else if (lda && lda < d.K) {
+    return DDPO_EINVAL;
+  }
+  d.src = reinterpret_cast<const float*>(a16);
+  d.w = reinterpret_cast<const float*>(a8);
+  d.ld_src = lda;
+  if (!buf_path_ok(d, 0)) return DDPO_EINVAL;
+  d.splits = 1;
+  return dispatch_bf16<3>(d, w16, w8, 0, 4, ws, ws_bytes, as_stream(stream));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1436,6 +1526,77 @@ extern "C" int ddpo_split_planes_bf16(const float* x, int ldx, uint16_t* hi, uin
   int64_t blocks = (rows * (cols >> 2) + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(split_planes_kernel, dim3((int)blocks), dim3(256), 0, as_stream(stream), x, ldx, hi, lo, ld_out, rows, cols >> 2);
+  DDPO_LAUNCH_CHECK();
+  return DDPO_OK;
+}
+
+__global__ void __launch_bounds__(256) split_planes_mx_kernel(const float* __restrict__ x, int ldx, uint16_t* __restrict__ p16,
+                                                              uint16_t* __restrict__ p8, int ld_out, int64_t rows, int cols4) {
+  const int64_t total = rows * cols4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cols4;
+    const int c = (int)(i - r * cols4) << 2;
+    mx_store4(p16, p8, r, c, ld_out, rows, *reinterpret_cast<const float4*>(x + r * ldx + c));
+  }
+}
+
+extern "C" int ddpo_split_planes_f16mx(const float* x, int ldx, uint16_t* p16, uint16_t* p8, int ld_out, int64_t rows, int cols, void* stream) {
+  if (!x || !p16 || !p8 || rows <= 0 || cols <= 0 || (cols & 31) || (ldx & 3) || (ld_out & 31) || ldx < cols) return DDPO_EINVAL;
+  if (ld_out != 0 && ld_out < cols) return DDPO_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(x) & 15) || ((reinterpret_cast<uintptr_t>(p16) | reinterpret_cast<uintptr_t>(p8)) & 7)) return DDPO_EINVAL;
+  int64_t blocks = (rows * (cols >> 2) + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(split_planes_mx_kernel, dim3((int)blocks), dim3(256), 0, as_stream(stream), x, ldx, p16, p8, ld_out, rows, cols >> 2);
+  DDPO_LAUNCH_CHECK();
+  return DDPO_OK;
+}
+
+// f16mx weight planes (include/ddpo_hip.h).  Pass 1: biased exponent of every column's largest |w| -> scale byte; pass 2: the 32x32
+// tile transpose of the k-blocked packer, writing the f16 plane and the [l8 | h8] byte plane.
+__global__ void __launch_bounds__(256) mx_colscale_kernel(const float* __restrict__ w, int K, int N, uint8_t* __restrict__ scale) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  uint32_t m = 0;
+  for (int k = 0; k < K; ++k) m = max(m, __float_as_uint(w[(int64_t)k * N + n]) & 0x7FFFFFFFu);
+  int e = (int)(m >> 23);                 // 2^(e - 127) <= max|w| < 2^(e - 126)
+  e = min(max(e, 32), 240);               // all-zero / denormal columns: any valid scale; keeps (byte - 11) and 2^(261 - e) in range
+  scale[n] = (uint8_t)(e - 7);            // max|w| / 2^(e - 7 - 127) in [128, 256) <= 448 (e4m3 range)
+}
+__global__ void __launch_bounds__(256) pack_weights_mx_kernel(const float* __restrict__ w, int K, int N, const uint8_t* __restrict__ scale,
+                                                              uint16_t* __restrict__ w16, uint8_t* __restrict__ w8) {
+  __shared__ uint32_t tile[32][33];       // f16 bits | h8 << 16 | l8 << 24
+  const int kb = blockIdx.y, k0 = kb * 32, n0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    const int k = k0 + r, n = n0 + tx;
+    uint32_t packed = 0;
+    if (k < K && n < N) {
+      const float x = fminf(fmaxf(w[(int64_t)k * N + n], -65504.f), 65504.f);
+      const _Float16 h = (_Float16)x;
+      const float hf = (float)h, inv = __uint_as_float((uint32_t)(254 - (int)scale[n]) << 23);       // 2^-(byte - 127)
+      const int p = __builtin_amdgcn_cvt_pk_fp8_f32(hf * inv, (x - hf) * 2048.f * inv, 0, false);
+      packed = (uint32_t)__builtin_bit_cast(uint16_t, h) | ((uint32_t)p << 16);
+    }
+    tile[r][tx] = packed;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int n = n0 + r;
+    if (n < N) {
+      const uint32_t p = tile[tx][r];
+      const int64_t row = (int64_t)kb * N + n;
+      w16[row * 32 + tx] = (uint16_t)(p & 0xFFFFu);
+      w8[row * 64 + tx] = (uint8_t)(p >> 24);               // l8 first: lanes 0-31 of the MFMA pair it with the activations' h8
+      w8[row * 64 + 32 + tx] = (uint8_t)((p >> 16) & 0xFFu);
+    }
+  }
+}
+extern "C" int ddpo_pack_weights_f16mx(const float* w, int K, int N, uint16_t* w16, uint16_t* w8, uint8_t* scale, void* stream) {
+  if (!w || !w16 || !w8 || !scale || K <= 0 || N <= 0) return DDPO_EINVAL;
+  hipLaunchKernelGGL(mx_colscale_kernel, dim3((N + 255) / 256), dim3(256), 0, as_stream(stream), w, K, N, scale);
+  DDPO_LAUNCH_CHECK();
+  hipLaunchKernelGGL(pack_weights_mx_kernel, dim3((N + 31) / 32, (K + 31) / 32), dim3(256), 0, as_stream(stream), w, K, N, scale, w16,
+                     reinterpret_cast<uint8_t*>(w8));
   DDPO_LAUNCH_CHECK();
   return DDPO_OK;
 }

@@ -35,10 +35,11 @@ class GemmDesc(ctypes.Structure):
                 ("B", c_int), ("H", c_int), ("W", c_int), ("Cin", c_int),
                 ("OH", c_int), ("OW", c_int),
                 ("w_dgrad", c_int), ("ld_w", c_int), ("splits", c_int), ("accumulate", c_int), ("epilogue", c_int),
-                ("out_hi", c_void_p), ("out_lo", c_void_p), ("ld_planes", c_int), ("w_layout", c_int)]
+                ("out_hi", c_void_p), ("out_lo", c_void_p), ("ld_planes", c_int), ("w_layout", c_int),
+                ("w_scale", c_void_p), ("planes_fmt", c_int)]
 
 
-ABI_VERSION = 6          # must equal ddpo_abi_version() of the loaded library (include/ddpo_hip.h)
+ABI_VERSION = 7          # must equal ddpo_abi_version() of the loaded library (include/ddpo_hip.h)
 
 _SIGS = {
     "ddpo_abi_version": (c_int, []),
@@ -78,6 +79,9 @@ _SIGS = {
     "ddpo_layernorm_fwd_planes": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p]),
     "ddpo_pack_weights_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ddpo_pack_weights_bf16_kblocked": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "ddpo_pack_weights_f16mx": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ddpo_split_planes_f16mx": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p]),
+    "ddpo_gemm_conv_fwd_f16mx_planes": (c_int, [POINTER(GemmDesc), c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "ddpo_attention_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int,
                                    c_int, c_int, c_int, c_float, c_void_p]),
     "ddpo_attention_kv_images_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
@@ -269,6 +273,60 @@ def split_planes(x):
     pl = Planes(rows, C, x.device)
     _check(load().ddpo_split_planes_bf16(_p(x), C, _p(pl.hi), _p(pl.lo), pl.ld, rows, C, _stream()), "ddpo_split_planes_bf16")
     return pl
+
+
+# ---- f16mx forward operator (ABI v7): a*b ~= a_h*b_h (f16 MFMA) + a_h8*b_l8 + a_l8*b_h8 (one block-scaled 8-bit MFMA) on the plane-fed
+# kernels.  EXPERIMENTAL: validated operator by operator (tests/test_gpu_f16mx.py, tools/native/kernel_probe mx) and measured — 1.2-1.4x
+# on the long-reduction convolutions of the 32x32 / 16x16 levels, ~1.0x at the 64x64 level, whose tiles are bound by the operand stream
+# (profiles/r03_probe_mx.log) — but NOT routed by the models: they run bf16x3.
+def pack_weights_f16mx(w):
+    """fp32 weight (..., N) viewed as (K, N) -> dict(w16, w8, scale, K, N): the f16mx weight planes of ddpo_pack_weights_f16mx."""
+    N = w.shape[-1]
+    K = w.numel() // N
+    Kb = (K + 31) // 32
+    ent = dict(K=K, N=N, w16=torch.zeros(Kb, N, 32, dtype=torch.int16, device=w.device), w8=torch.zeros(Kb, N, 64, dtype=torch.uint8, device=w.device),
+               scale=torch.zeros(N, dtype=torch.uint8, device=w.device))
+    _check(load().ddpo_pack_weights_f16mx(_p(w), K, N, _p(ent["w16"]), _p(ent["w8"]), _p(ent["scale"]), _stream()), "ddpo_pack_weights_f16mx")
+    return ent
+
+
+def split_planes_f16mx(x):
+    """fp32 (rows, C), C % 32 == 0 -> (p16, p8): the f16 plane (rows, C) int16 and the 8-bit plane (rows, C / 32, 64) uint8
+    [e5m2(h) x 32 | e5m2(l * 2^11) x 32] per 32-channel block (row-major storage)."""
+    rows, C = x.shape
+    p16 = torch.empty(rows, C, dtype=torch.int16, device=x.device)
+    p8 = torch.empty(rows, C // 32, 64, dtype=torch.uint8, device=x.device)
+    _check(load().ddpo_split_planes_f16mx(_p(x), C, _p(p16), _p(p8), C, rows, C, _stream()), "ddpo_split_planes_f16mx")
+    return p16, p8
+
+
+def gemm_conv_f16mx(planes, wp, *, M, bias=None, residual=None, conv=None, out=None, planes_out=False):
+    """Plane-fed f16mx GEMM / convolution: planes = split_planes_f16mx(x), wp = pack_weights_f16mx(w); conv as in gemm_conv.
+    planes_out: also return the result as f16mx planes (p16, p8) written by the output stage."""
+    p16, p8 = planes
+    N, K = wp["N"], wp["K"]
+    d = GemmDesc()
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=p16.device)
+    d.out = out.data_ptr(); d.ld_out = N
+    d.bias = bias.data_ptr() if bias is not None else None
+    if residual is not None:
+        d.residual = residual.data_ptr(); d.ld_res = N
+    d.alpha = 1.0
+    d.M, d.N, d.K = int(M), int(N), int(K)
+    d.w_layout = 1
+    d.w_scale = wp["scale"].data_ptr()
+    if conv:
+        for k in ("ksize", "stride", "pad", "upsample", "B", "H", "W", "Cin", "OH", "OW"):
+            setattr(d, k, int(conv[k]))
+    opl = None
+    if planes_out:
+        opl = (torch.empty(M, N, dtype=torch.int16, device=p16.device), torch.empty(M, N // 32, 64, dtype=torch.uint8, device=p16.device))
+        d.out_hi, d.out_lo, d.ld_planes, d.planes_fmt = opl[0].data_ptr(), opl[1].data_ptr(), N, 1
+    ws = _scratch(SPLITK_WS_BYTES, p16.device, "splitk")
+    _check(load().ddpo_gemm_conv_fwd_f16mx_planes(byref(d), _p(p16), _p(p8), int(p16.shape[1]), _p(wp["w16"]), _p(wp["w8"]), _p(ws), SPLITK_WS_BYTES,
+                                                  _stream()), "ddpo_gemm_conv_fwd_f16mx_planes")
+    return (out, opl) if planes_out else out
 
 
 # When set to a list, every ddpo_gemm_conv_fwd launch appends (start_event, end_event, algorithmic_flops);

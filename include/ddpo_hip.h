@@ -187,6 +187,12 @@ typedef struct {
    *      8 full 128-byte cache lines instead of 16 half lines at the row stride — the weight stream of the k-loop measured
    *      1.25-1.4x faster per CU (tools/native/dma_bench, profiles/r03_dma_bench.log).  `ldw` is ignored.  Not with w_dgrad. */
   int w_layout;
+  /* f16mx datapath (ABI v7; ddpo_gemm_conv_fwd_f16mx_planes only, zero elsewhere): one E8M0 scale byte per output column of the
+   * 8-bit weight plane (ddpo_pack_weights_f16mx), and the FORMAT of the planes the output stage emits into out_hi / out_lo:
+   *   0: bf16 hi / lo (above);  1: f16mx — out_hi = f16 plane, out_lo = per 32-column block [e5m2(h) x 32 | e5m2(l * 2^11) x 32]
+   *      (needs the emitted column count % 32 == 0).  Same geometry and ld_planes convention as the bf16 planes. */
+  const uint8_t* w_scale;
+  int planes_fmt;
 } ddpo_gemm_desc;
 int ddpo_gemm_conv_fwd(const ddpo_gemm_desc* d, void* stream);
 /* Data gradients reuse ddpo_gemm_conv_fwd: src = dY, w = forward kernel with w_trans=1, w_dgrad=1, and for the
@@ -214,6 +220,27 @@ int ddpo_gemm_conv_fwd_bf16(const ddpo_gemm_desc* d, const uint16_t* w_hi, const
 int ddpo_gemm_conv_fwd_bf16_planes(const ddpo_gemm_desc* d, const uint16_t* a_hi, const uint16_t* a_lo, int lda,
                                    const uint16_t* w_hi, const uint16_t* w_lo, int ldw, void* ws, size_t ws_bytes,
                                    void* stream);
+/* f16mx forward datapath (plane-fed, ABI v7).  a*b ~= a_h*b_h + a_h8*b_l8 + a_l8*b_h8: per 32x32 accumulator block and 32-wide
+ * k-tile two v_mfma_f32_32x32x16_f16 (the f16 x f16 term) and ONE v_mfma_scale_f32_32x32x64_f8f6f4 carrying both cross terms,
+ * against six bf16 MFMAs of the bf16x3 datapath — 2/3 of its matrix-pipe time on the same LDS-DMA operand stream (the planes have
+ * the geometry of the bf16 hi / lo planes; profiles/r03_ktime_mx_ablation.log).  The dropped term is a_l*b_l (~2^-22 relative) and
+ * the 8-bit rounding of the factors of the cross terms (~2^-15): ~7e-5 relative on a whole SD-1.5 U-Net forward against
+ * 2e-5 for bf16x3 and ~2e-3 for single-pass bf16.  Operands:
+ *   a16 / a8  activation planes written by ddpo_split_planes_f16mx or a plane-emitting producer (planes_fmt = 1), (rows, lda) or
+ *             k-blocked (lda == 0) like the bf16 planes;
+ *   w16 / w8 / d->w_scale  weight planes of ddpo_pack_weights_f16mx (k-blocked only: d->w_layout must be 1).
+ * Tiles, split-K, output stage (incl. epilogue = 1 and plane emission in either format) as ddpo_gemm_conv_fwd_bf16_planes;
+ * every tile class accumulates in the same order (bit-identical results for one layer whatever the batch).  Forward only:
+ * data / weight gradients stay on bf16x3. */
+int ddpo_gemm_conv_fwd_f16mx_planes(const ddpo_gemm_desc* d, const uint16_t* a16, const uint16_t* a8, int lda,
+                                    const uint16_t* w16, const uint16_t* w8, void* ws, size_t ws_bytes, void* stream);
+/* fp32 W (K, N) -> f16mx weight planes, k-blocked: w16 (ceil(K/32), N, 32) f16 = f16(w); w8 (ceil(K/32), N, 64) bytes =
+ * [e4m3(l * 2^11 / s_n) x 32 | e4m3(h / s_n) x 32] with h = f16(w), l = w - h and s_n = 2^(scale[n] - 127) the power of two that
+ * puts the column's largest |w| in [128, 256); scale (N) bytes.  Zero padded in k. */
+int ddpo_pack_weights_f16mx(const float* w, int K, int N, uint16_t* w16, uint16_t* w8, uint8_t* scale, void* stream);
+/* fp32 activations (rows, cols), row stride ldx -> f16mx activation planes (what the plane-emitting producers write); ld_out as
+ * ddpo_split_planes_bf16 (0 = k-blocked); cols % 32 == 0. */
+int ddpo_split_planes_f16mx(const float* x, int ldx, uint16_t* p16, uint16_t* p8, int ld_out, int64_t rows, int cols, void* stream);
 /* fp32 W (K, N) -> bf16 hi / lo planes in the k-blocked forward layout (ceil(K / 32), N, 32), zero padded in k (w_layout = 1). */
 int ddpo_pack_weights_bf16_kblocked(const float* w, int K, int N, uint16_t* fwd_hi, uint16_t* fwd_lo, void* stream);
 /* x:(rows, cols) fp32, row stride ldx -> hi / lo bf16 planes (rows, ld_out): hi = bf16(x), lo = bf16(x - hi). */

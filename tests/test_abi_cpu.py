@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in ddpo_hip.h but not exported"
     assert declared == set(L.EXPORTED_SYMBOLS)
-    assert L.load().ddpo_abi_version() == L.ABI_VERSION == 6
+    assert L.load().ddpo_abi_version() == L.ABI_VERSION == 7
 
 
 def test_struct_mirrors():
@@ -75,7 +75,7 @@ def test_gemm_desc_field_order_matches_header():
         stmt = stmt.strip()
         if not stmt:
             continue
-        decl = re.sub(r"^(const\s+)?(float|int|int32_t|int64_t|size_t|void|uint16_t)\s*\*?\s*", "", stmt)
+        decl = re.sub(r"^(const\s+)?(float|int|int32_t|int64_t|size_t|void|uint16_t|uint8_t)\s*\*?\s*", "", stmt)
         names += [n.strip().lstrip("*") for n in decl.split(",")]
     assert names == [f[0] for f in L.GemmDesc._fields_]
 

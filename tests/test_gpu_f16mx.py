@@ -1,0 +1,123 @@
+"""f16mx forward operator (ABI v7: ddpo_pack_weights_f16mx / ddpo_split_planes_f16mx / ddpo_gemm_conv_fwd_f16mx_planes) against a host
+emulation built from torch's float8 / float16 conversions: (1) the plane encodings bit for bit, (2) the GEMM against the exact
+product of the DECODED planes (layouts, lane pairing, block scales: only fp32 accumulation error left), (3) the datapath's accuracy
+against float64 next to bf16x3.  The operator is not routed by the models (ddpo_amd/lib.py); tools/native/kernel_probe mx times it."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as TF
+
+from ddpo_amd import lib as L
+
+pytestmark = pytest.mark.gpu
+
+
+def _dec_planes(p16, p8):
+    """(h, h8, l8) as float64 (rows, C) from the activation planes."""
+    rows, C = p16.shape
+    h = p16.view(torch.float16).double()
+    b = p8.view(torch.float8_e5m2).double()                      # (rows, C/32, 64)
+    return h, b[:, :, :32].reshape(rows, C), b[:, :, 32:].reshape(rows, C) / 2048.0
+
+
+def _dec_weights(wp):
+    """(h, h8, l8) as float64 (K, N) from the weight planes (zero padded rows dropped)."""
+    K, N = wp["K"], wp["N"]
+    s = torch.pow(2.0, wp["scale"].double() - 127.0)                      # (N,)
+    h = wp["w16"].view(torch.float16).double().permute(0, 2, 1).reshape(-1, N)[:K]      # (Kb, N, 32) -> (Kb*32, N)
+    b = wp["w8"].view(torch.float8_e4m3fn).double()                      # (Kb, N, 64): [l8 | h8]
+    l8 = (b[:, :, :32] * s[None, :, None] / 2048.0).permute(0, 2, 1).reshape(-1, N)[:K]
+    h8 = (b[:, :, 32:] * s[None, :, None]).permute(0, 2, 1).reshape(-1, N)[:K]
+    return h, h8, l8
+
+
+def test_activation_planes_are_f16_and_e5m2_of_the_split():
+    torch.manual_seed(0)
+    x = (torch.randn(77, 96, device="cuda") * torch.logspace(-6, 3, 96, device="cuda")).contiguous()
+    p16, p8 = L.split_planes_f16mx(x)
+    h = x.half()
+    assert torch.equal(p16.view(torch.float16), h)                       # round to nearest even, like torch
+    l = (x - h.float()) * 2048.0
+    b = p8.view(torch.float8_e5m2)
+    assert torch.equal(b[:, :, :32].reshape(77, 96).float(), h.float().to(torch.float8_e5m2).float())
+    assert torch.equal(b[:, :, 32:].reshape(77, 96).float(), l.to(torch.float8_e5m2).float())
+    hh, h8, l8 = _dec_planes(p16, p8)
+    xd = x.double()
+    assert float(((hh + l8) - xd).abs().max() / xd.abs().max()) < 2.0 ** -13          # h + l8: 11 + 3 bits
+    big = xd.abs() >= 2.0 ** -14                                          # e5m2's normal range (smaller values lose bits, then flush)
+    assert float((h8 - xd).abs().div(xd.abs())[big].max()) < 2.0 ** -2.5  # e5m2 of h: 3 significant bits
+
+
+def test_weight_planes_are_f16_and_column_scaled_e4m3():
+    torch.manual_seed(1)
+    K, N = 100, 72                                                        # ragged K (zero padded to 128), N % 32 != 0
+    w = (torch.randn(K, N, device="cuda") * torch.logspace(-3, 1, N, device="cuda")[None, :]).contiguous()
+    w[:, 5] = 0.0                                                         # an all-zero column keeps a valid scale
+    wp = L.pack_weights_f16mx(w)
+    h, h8, l8 = _dec_weights(wp)
+    assert torch.equal(h.float(), w.half().float())
+    e = torch.floor(torch.log2(w.abs().amax(0).clamp_min(2.0 ** -95))) - 7            # scale exponent: max|w| / 2^e in [128, 256)
+    assert torch.equal(wp["scale"].double()[w.abs().amax(0) > 0] - 127.0, e.double()[w.abs().amax(0) > 0])
+    s = torch.pow(2.0, wp["scale"].float() - 127.0)
+    q = lambda v: (v / s).to(torch.float8_e4m3fn).float() * s
+    assert torch.equal(h8.float(), q(w.half().float()))
+    assert torch.equal((l8 * 2048.0).float(), q((w - w.half().float()) * 2048.0))
+    assert float(wp["w16"][3, :, 4:].abs().max()) == 0 and float(wp["w8"][3, :, 4:32].abs().max()) == 0      # k >= K: zeros
+
+
+CASES = [  # (B, H, Cin, Cout, ksize, stride, upsample)  ksize 0: dense with M = B * H rows
+    (2, 16, 64, 96, 3, 1, 0),        # 128x64 tiles, ragged N tile
+    (2, 32, 320, 320, 3, 1, 0),      # 128x320 tiles
+    (2, 16, 640, 640, 3, 1, 0),      # split-K
+    (2, 16, 128, 128, 3, 2, 0),      # stride 2
+    (2, 8, 64, 64, 3, 1, 1),         # nearest-neighbour upsample in the gather
+    (2, 16, 96, 160, 1, 1, 0),       # 1x1
+    (3, 77, 768, 320, 0, 1, 0),      # dense, ragged M
+    (1, 640, 320, 1280, 0, 1, 0),    # dense, 128x128 tiles
+]
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout,ks,stride,ups", CASES)
+def test_gemm_equals_the_product_of_the_decoded_planes(B, H, Cin, Cout, ks, stride, ups):
+    torch.manual_seed(2)
+    conv = ks > 0
+    rows = B * H * H if conv else B * H
+    K = ks * ks * Cin if conv else Cin
+    x = torch.randn(rows, Cin, device="cuda")
+    w = torch.randn(K, Cout, device="cuda") / K ** 0.5
+    bias = torch.randn(Cout, device="cuda")
+    planes, wp = L.split_planes_f16mx(x), L.pack_weights_f16mx(w)
+    ah, ah8, al8 = _dec_planes(*planes)
+    wh, wh8, wl8 = _dec_weights(wp)
+    if conv:
+        pad = ks // 2
+        VH = 2 * H if ups else H
+        OH = (VH + 2 * pad - ks) // stride + 1
+        M = B * OH * OH
+        geom = dict(ksize=ks, stride=stride, pad=pad, upsample=ups, B=B, H=H, W=H, Cin=Cin, OH=OH, OW=OH)
+
+        def cv(a, b_):
+            a = a.view(B, H, H, Cin).permute(0, 3, 1, 2)
+            if ups:
+                a = a.repeat_interleave(2, 2).repeat_interleave(2, 3)
+            return TF.conv2d(a, b_.view(ks, ks, Cin, Cout).permute(3, 2, 0, 1), None, stride=stride, padding=pad).permute(0, 2, 3, 1).reshape(M, Cout)
+    else:
+        M, geom = rows, None
+        cv = lambda a, b_: a @ b_
+    res = torch.randn(M, Cout, device="cuda")
+    out = L.gemm_conv_f16mx(planes, wp, M=M, bias=bias, residual=res, conv=geom)
+    ref_planes = cv(ah, wh) + cv(ah8, wl8) + cv(al8, wh8) + bias.double() + res.double()
+    ref_true = cv(x.double(), w.double()) + bias.double() + res.double()
+    scale = float(ref_true.abs().max())
+    assert float((out.double() - ref_planes).abs().max()) < 3e-6 * scale            # the operator's contract (fp32 accumulation only)
+    err = float((out.double() - ref_true).pow(2).mean().sqrt() / (ref_true - bias.double() - res.double()).pow(2).mean().sqrt())
+    assert err < 3e-5                                                     # the datapath: ~1e-5 rms on Gaussian operands (bf16x3: ~3e-6)
+
+
+def test_output_stage_emits_f16mx_planes_of_the_result():
+    torch.manual_seed(3)
+    M, K, N = 300, 256, 320
+    x, w = torch.randn(M, K, device="cuda"), torch.randn(K, N, device="cuda") / 16
+    out, (p16, p8) = L.gemm_conv_f16mx(L.split_planes_f16mx(x), L.pack_weights_f16mx(w), M=M, planes_out=True)
+    q16, q8 = L.split_planes_f16mx(out)
+    assert torch.equal(p16, q16) and torch.equal(p8, q8)

@@ -8,6 +8,8 @@
 //   kernel_probe gemm2 [batch=16] [iters=10]    plane-fed (LDS-DMA) kernel vs the fp32-fed one: timing + bitwise comparison
 //                                               PROBE_COLD=1: flush the caches before every timed launch and re-read only the
 //                                               activations (weights cold, as in the model)
+//   kernel_probe mx [batch=16] [iters=10]       f16mx plane-fed datapath vs bf16x3 plane-fed: timing, contract check against the decoded
+//                                               planes, accuracy against fp64
 //   kernel_probe attn [batch=16] [iters=10]     bf16x3 / fp32 flash-attention shapes of the same forward
 //   kernel_probe ppo                            scoring-mode log-prob + PPO-clip + grouped micro-batches vs a host loop
 //
@@ -308,6 +310,127 @@ static int probe_gemm2(int B, int iters) {
   return g_fail;
 }
 
+
+// ------------------------------------------------------------------------------------------------ f16mx plane-fed datapath
+static double dec_f16(uint16_t b) {
+  const int s = b >> 15, e = (b >> 10) & 31, m = b & 1023;
+  double v = e == 0 ? ldexp((double)m, -24) : (e == 31 ? INFINITY : ldexp((double)(m | 1024), e - 25));
+  return s ? -v : v;
+}
+static double dec_e5m2(uint8_t b) { return dec_f16((uint16_t)b << 8); }
+static double dec_e4m3(uint8_t b) {
+  const int s = b >> 7, e = (b >> 3) & 15, m = b & 7;
+  double v = e == 0 ? ldexp((double)m, -9) : ldexp((double)(m | 8), e - 10);
+  return s ? -v : v;
+}
+// bf16x3 plane-fed kernel vs f16mx plane-fed kernel on the same layer: timing of both; f16mx spot-checked (a) against the exact product
+// of the DECODED planes (the kernel's contract: layouts, lane pairing, block scales — fp32-accumulation error only) and (b) against the
+// double-precision product of the fp32 inputs (the datapath's accuracy)
+static void run_mx(int B, int H, int Cin, int Cout, int ks, int stride, int ups, int iters, void* ws, size_t ws_bytes) {
+  const bool conv = ks > 0;
+  const int pad = ks / 2;
+  const int VH = ups ? 2 * H : H;
+  const int OH = conv ? (VH + 2 * pad - ks) / stride + 1 : 0;
+  const int64_t M = conv ? (int64_t)B * OH * OH : (int64_t)B * H;
+  const int K = conv ? ks * ks * Cin : Cin, N = Cout, Kb = (K + 31) / 32;
+  const int64_t arows = conv ? (int64_t)B * H * H : M;
+  const int acols = conv ? Cin : K;
+  Dev src(arows * acols, 11, 1.0f), w((int64_t)K * N, 12, 1.0f / sqrtf((float)K)), bias(N, 13, 0.5f), res(M * N, 14, 1.0f);
+  float* out1 = (float*)dalloc((size_t)M * N * 4);
+  float* out2 = (float*)dalloc((size_t)M * N * 4);
+  const size_t wpl = (size_t)Kb * N * 64, apl = (size_t)arows * acols * 2;
+  uint16_t *hi = (uint16_t*)dalloc(wpl), *lo = (uint16_t*)dalloc(wpl), *w16 = (uint16_t*)dalloc(wpl), *w8 = (uint16_t*)dalloc(wpl);
+  uint8_t* wsc = (uint8_t*)dalloc(N);
+  uint16_t *ah = (uint16_t*)dalloc(apl), *al = (uint16_t*)dalloc(apl), *a16 = (uint16_t*)dalloc(apl), *a8 = (uint16_t*)dalloc(apl);
+  ABI_OK(ddpo_split_planes_bf16(src.p, acols, ah, al, acols, arows, acols, nullptr));
+  ABI_OK(ddpo_split_planes_f16mx(src.p, acols, a16, a8, acols, arows, acols, nullptr));
+  ABI_OK(ddpo_pack_weights_bf16_kblocked(w.p, K, N, hi, lo, nullptr));
+  ABI_OK(ddpo_pack_weights_f16mx(w.p, K, N, w16, w8, wsc, nullptr));
+  ddpo_gemm_desc d;
+  memset(&d, 0, sizeof(d));
+  d.w_layout = 1;
+  d.bias = bias.p; d.residual = res.p; d.ld_res = N; d.ld_out = N; d.alpha = 1.f;
+  d.M = (int)M; d.N = N; d.K = K;
+  if (conv) { d.ksize = ks; d.stride = stride; d.pad = pad; d.upsample = ups; d.B = B; d.H = H; d.W = H; d.Cin = Cin; d.OH = OH; d.OW = OH; }
+  ddpo_gemm_desc d1 = d, d2 = d;
+  d1.out = out1; d2.out = out2; d2.w_scale = wsc;
+  auto f1 = [&] { ABI_OK(ddpo_gemm_conv_fwd_bf16_planes(&d1, ah, al, acols, hi, lo, 0, ws, ws_bytes, nullptr)); };
+  auto f2 = [&] { ABI_OK(ddpo_gemm_conv_fwd_f16mx_planes(&d2, a16, a8, acols, w16, w8, ws, ws_bytes, nullptr)); };
+  const float ms1 = time_ms(iters, f1), ms2 = time_ms(iters, f2);
+  std::vector<uint16_t> h_a16(apl / 2), h_a8(apl / 2), h_w16(wpl / 2), h_w8(wpl / 2);
+  std::vector<uint8_t> h_sc(N);
+  HIP_OK(hipMemcpy(h_a16.data(), a16, apl, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(h_a8.data(), a8, apl, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(h_w16.data(), w16, wpl, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(h_w8.data(), w8, wpl, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(h_sc.data(), wsc, N, hipMemcpyDeviceToHost));
+  const uint8_t* a8b = reinterpret_cast<const uint8_t*>(h_a8.data());
+  const uint8_t* w8b = reinterpret_cast<const uint8_t*>(h_w8.data());
+  const int NS = 64;
+  double err_planes = 0.0, err_true = 0.0, err_b3 = 0.0, ref_sq = 0.0;
+  for (int s = 0; s < NS; ++s) {
+    const int64_t m = (s < 8) ? (s < 4 ? s : M - 1 - (s - 4)) : (int64_t)((hval(77, s) * 0.5 + 0.5) * (double)M) % M;
+    const int n = (s < 8) ? (s & 1 ? N - 1 - s : s) % N : (int)((hval(78, s) * 0.5 + 0.5) * N) % N;
+    float got = 0.f, got3 = 0.f;
+    HIP_OK(hipMemcpy(&got, out2 + m * N + n, 4, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(&got3, out1 + m * N + n, 4, hipMemcpyDeviceToHost));
+    double acc_p = 0.0, acc_t = 0.0;
+    const double sn = ldexp(1.0, (int)h_sc[n] - 127);
+    auto term = [&](int64_t arow, int ci, int k) {            // activation (arow, ci) x weight (k, n)
+      const int64_t ao = arow * acols + ci, wo = ((int64_t)(k >> 5) * N + n);
+      const double a_h = dec_f16(h_a16[ao]), w_h = dec_f16(h_w16[wo * 32 + (k & 31)]);
+      const int64_t ab = (arow * acols + (ci & ~31)) * 2 + (ci & 31);
+      const double a_h8 = dec_e5m2(a8b[ab]), a_l8 = dec_e5m2(a8b[ab + 32]) / 2048.0;
+      const double w_l8 = dec_e4m3(w8b[wo * 64 + (k & 31)]) * sn / 2048.0, w_h8 = dec_e4m3(w8b[wo * 64 + 32 + (k & 31)]) * sn;
+      acc_p += a_h * w_h + a_h8 * w_l8 + a_l8 * w_h8;
+      acc_t += (double)src.at(ao) * (double)w.at((int64_t)k * N + n);
+    };
+    if (conv) {
+      const int64_t b = m / ((int64_t)OH * OH), rem = m % ((int64_t)OH * OH);
+      const int oy = (int)(rem / OH), ox = (int)(rem % OH);
+      for (int ky = 0; ky < ks; ++ky)
+        for (int kx = 0; kx < ks; ++kx) {
+          const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
+          if (iy < 0 || iy >= VH || ix < 0 || ix >= VH) continue;
+          const int sy = ups ? iy >> 1 : iy, sx = ups ? ix >> 1 : ix;
+          const int64_t pix = (b * H + sy) * H + sx;
+          for (int ci = 0; ci < Cin; ++ci) term(pix, ci, (ky * ks + kx) * Cin + ci);
+        }
+    } else {
+      for (int k = 0; k < K; ++k) term(m, k, k);
+    }
+    const double add = (double)bias.at(n) + (double)res.at(m * N + n);
+    err_planes = std::max(err_planes, fabs(acc_p + add - (double)got));
+    err_true = std::max(err_true, fabs(acc_t + add - (double)got));
+    err_b3 = std::max(err_b3, fabs(acc_t + add - (double)got3));
+    ref_sq += acc_t * acc_t;
+  }
+  const double rms = sqrt(ref_sq / NS);
+  const double fl = 2.0 * (double)M * N * K;
+  const bool ok = err_planes / rms < 1e-5 && err_true / rms < 3e-4;      // fp32 accumulation over up to 17280 terms; the datapath's ~5e-5
+  if (!ok) ++g_fail;
+  if (conv) printf("conv %dx%d s%d up%d %5d->%5d @%3d^2 B%-3d:", ks, ks, stride, ups, Cin, Cout, H, B);
+  else printf("gemm M=%7lld K=%5d N=%5d       :", (long long)M, K, N);
+  printf(" bf16x3 %7.3f ms %6.1f TF | f16mx %7.3f ms %6.1f TF (x%.2f) | f16mx vs decoded planes %.1e, vs fp64 %.1e (bf16x3 %.1e) of rms %s\n", ms1,
+         fl / ms1 / 1e9, ms2, fl / ms2 / 1e9, ms1 / ms2, err_planes / rms, err_true / rms, err_b3 / rms, ok ? "" : "FAIL");
+  fflush(stdout);
+  src.release(); w.release(); bias.release(); res.release();
+  for (void* q : {(void*)out1, (void*)out2, (void*)hi, (void*)lo, (void*)w16, (void*)w8, (void*)wsc, (void*)ah, (void*)al, (void*)a16, (void*)a8}) HIP_OK(hipFree(q));
+}
+
+static int probe_mx(int B, int iters) {
+  const size_t ws_bytes = 64u << 20;
+  void* ws = dalloc(ws_bytes);
+  const ConvCase convs[] = {{64, 320, 320, 3, 1, 0}, {32, 640, 640, 3, 1, 0}, {16, 1280, 1280, 3, 1, 0}, {8, 1280, 1280, 3, 1, 0},
+                            {64, 960, 320, 3, 1, 0}, {32, 1920, 640, 3, 1, 0}, {16, 2560, 1280, 3, 1, 0}, {32, 320, 640, 3, 1, 0},
+                            {32, 640, 640, 3, 1, 1}, {64, 320, 320, 3, 2, 0},  {64, 320, 320, 1, 1, 0},   {20, 64, 96, 3, 1, 0}};
+  for (const ConvCase& c : convs) run_mx(B, c.H, c.Cin, c.Cout, c.ks, c.stride, c.ups, iters, ws, ws_bytes);
+  const int dense[][3] = {{4096, 320, 320}, {4096, 320, 2560}, {4096, 1280, 320}, {1024, 640, 5120}, {1024, 2560, 640},
+                          {256, 1280, 10240}, {256, 5120, 1280}, {64, 1280, 1280}, {77, 768, 320}, {1, 1280, 1280}, {37, 96, 72},
+                          {1024, 640, 640}, {256, 1280, 1280}, {4096, 320, 960}};
+  for (auto& g : dense) run_mx(B, g[0], g[1], g[2], 0, 1, 0, iters, ws, ws_bytes);
+  HIP_OK(hipFree(ws));
+  return g_fail;
+}
+
 // ------------------------------------------------------------------------------------------------ phase timing (kernel_probe_timing)
 #ifdef PROBE_TIMING
 extern "C" int ddpo_debug_kloop_times(unsigned long long* host, int n_wg);
@@ -549,6 +672,7 @@ int main(int argc, char** argv) {
   int rc;
   if (mode == "gemm") rc = probe_gemm(B, iters);
   else if (mode == "gemm2") rc = probe_gemm2(B, iters);
+  else if (mode == "mx") rc = probe_mx(B, iters);
   else if (mode == "attn") rc = probe_attn(B, iters);
   else if (mode == "ppo") rc = probe_ppo();
 #ifdef PROBE_TIMING
