@@ -1878,6 +1878,214 @@ __global__ void __launch_bounds__(BF_THREADS) gemm_wgrad_bf16_kernel(const ddpo_
     }
 }
 
+// WIDE weight-gradient tile (round 3): 128 (k) x 320 (n) per workgroup, 8 waves of 32 x 160, one workgroup per CU.  The 128 x 128 kernel above
+// moves 32 KB of operands per 0.52 M multiply-adds (61 B / kMAC) and sits at the CU's ~20 B / clk fetch rate with the matrix pipe 42 % busy
+// (236 TF); this tile moves 56 KB per 1.31 M (43 B / kMAC) — the forward 128x320 tile's ratio.  Row loader only (the regular layers: dense, and
+// stride-1 "same" convolutions whose rows tile into the 32-pixel k-tiles), N % 320 == 0; same staging (pixel pairs of a channel packed into one
+// dword of the [row][m] LDS image), same MFMA order per element as the 128 x 128 kernel.
+//   loader tasks (4 channels x 2 pixels, 8 quads x 8 pixel pairs per wave): A = 128 rows x 16 pairs = 8 wave tasks, one per wave;
+//   dY = 320 rows x 16 pairs = 20 wave tasks: waves 0-3 take three, waves 4-7 two.
+template <bool APLN, bool BPLN>
+__global__ void __launch_bounds__(512) gemm_wgrad_bf16_wide_kernel(const ddpo_gemm_desc d, int tiles_n, int m_per_split,
+                                                                   const uint16_t* __restrict__ a_hi, const uint16_t* __restrict__ a_lo,
+                                                                   const uint16_t* __restrict__ b_hi, const uint16_t* __restrict__ b_lo) {
+  constexpr int BM = 128, BN = 320, BK = 32, TN = 5, NBT = 3;
+  constexpr int PA = BM * WG_PITCH, PB = BN * WG_PITCH;          // dwords per plane
+  constexpr int STAGE = 2 * PA + 2 * PB;                         // A_hi | A_lo | B_hi | B_lo
+  extern __shared__ __attribute__((aligned(16))) uint32_t wsm[];
+  const int t = threadIdx.x, lane = t & 63, wid = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wid >> 1, wn = wid & 1;
+  const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
+  const int k0 = tile_m * BM, n0 = tile_n * BN;
+  const int m_begin = blockIdx.y * m_per_split;
+  const int m_end = min(m_begin + m_per_split, d.M);
+  if (m_begin >= m_end) return;
+  const bool conv = d.ksize > 0;
+  const int q = lane & 7, pp = lane >> 3;
+  // ---- this thread's A task: 4 channel rows, one pixel pair
+  const int a_row = 32 * (wid & 3) + 4 * q, a_dw = 8 * (wid >> 2) + pp;
+  const int kg = k0 + a_row;
+  const bool kvalid = kg < d.K;
+  int dky = 0, dkx = 0, ci = kg;
+  if (conv) {
+    const int tap = kg / d.Cin;
+    ci = kg - tap * d.Cin;
+    const int ky = tap / d.ksize;
+    dky = ky - d.pad;
+    dkx = tap - ky * d.ksize - d.pad;
+  }
+  const bool kbA = APLN && d.ld_src == 0, kbB = BPLN && d.ld_w == 0;
+  const int64_t rowsA = conv ? (int64_t)d.B * d.H * d.W : (int64_t)d.M;
+  const int lda_e = kbA ? 32 : d.ld_src, ldb_e = kbB ? 32 : d.ld_w;
+  const int64_t a_c0 = kbA ? (int64_t)(ci >> 5) * rowsA * 32 + (ci & 31) : (int64_t)ci;
+  const int64_t tap_off = conv ? ((int64_t)dky * d.W + dkx) * lda_e + a_c0 : a_c0;
+  constexpr uint32_t ESA = APLN ? 2u : 4u, ESB = BPLN ? 2u : 4u;
+  const int64_t rl_guard = conv ? (int64_t)(d.W + 1) * lda_e * (int64_t)ESA : 0;
+  const __amdgpu_buffer_rsrc_t rs_a0 = make_rsrc(reinterpret_cast<const char*>(APLN ? (const void*)a_hi : (const void*)d.src) - rl_guard),
+                               rs_a1 = make_rsrc(reinterpret_cast<const char*>(APLN ? (const void*)a_lo : (const void*)d.src) - rl_guard);
+  const __amdgpu_buffer_rsrc_t rs_b0 = make_rsrc(BPLN ? (const void*)b_hi : (const void*)d.w), rs_b1 = make_rsrc(BPLN ? (const void*)b_lo : (const void*)d.w);
+  uint32_t va[2], vb[NBT][2];
+  int cy[2], cx[2];
+  const int rem0 = conv ? m_begin % (d.OH * d.OW) : 0;
+  int t_oy = conv ? rem0 / d.OW : 0, t_ox = conv ? rem0 - (rem0 / d.OW) * d.OW : 0;      // image position of the current k-tile's first pixel (uniform)
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int eoff = 2 * a_dw + e;
+    const int dy_e = (conv && d.OW < BK) ? eoff / d.OW : 0;
+    const int x_e = (conv && d.OW < BK) ? eoff - dy_e * d.OW : eoff;
+    cy[e] = dy_e + dky;
+    cx[e] = x_e + dkx;
+    const int64_t ao = ((int64_t)(m_begin + eoff) * lda_e + tap_off) * (int64_t)ESA + rl_guard;
+    va[e] = (kvalid && ao >= 0 && ao < 0x7FFFFFF0ll) ? (uint32_t)ao : BUF_OOB;
+  }
+  int b_row[NBT], b_dw[NBT];
+#pragma unroll
+  for (int i = 0; i < NBT; ++i) {
+    const int T = wid + 8 * i;                         // wave task: channel block T >> 1 (of 10), pixel-pair half T & 1
+    b_row[i] = 32 * (T >> 1) + 4 * q;
+    b_dw[i] = 8 * (T & 1) + pp;
+    const int ng = n0 + b_row[i];
+    const int64_t b_c0 = kbB ? (int64_t)(ng >> 5) * (int64_t)d.M * 32 + (ng & 31) : (int64_t)ng;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int64_t bo = ((int64_t)(m_begin + 2 * b_dw[i] + e) * ldb_e + b_c0) * (int64_t)ESB;
+      vb[i][e] = (T < 20 && ng < d.N && bo >= 0 && bo < 0x7FFFFFF0ll) ? (uint32_t)bo : BUF_OOB;
+    }
+  }
+  const bool third = wid < 4;                          // wave-uniform: this wave stages a third dY task
+  // TWO register sets: tile T travels in set T & 1 and is requested two k-tiles before it is written to LDS (one workgroup per CU: nothing else
+  // covers the fetch latency; with one set the loop measured no faster than the 128 x 128 kernel's two workgroups per CU)
+  float4 ra[2][2], rb[2][NBT][2];
+  auto ld4 = [&](const __amdgpu_buffer_rsrc_t r0, const __amdgpu_buffer_rsrc_t r1, uint32_t vo, uint32_t so, bool pl) {
+    if (pl) {
+      const u32x2 h2 = __builtin_amdgcn_raw_buffer_load_b64(r0, vo, so, 0), l2 = __builtin_amdgcn_raw_buffer_load_b64(r1, vo, so, 0);
+      return make_float4(__uint_as_float(h2.x), __uint_as_float(h2.y), __uint_as_float(l2.x), __uint_as_float(l2.y));
+    }
+    const u32x4 v4 = __builtin_amdgcn_raw_buffer_load_b128(r0, vo, so, 0);
+    return make_float4(__uint_as_float(v4.x), __uint_as_float(v4.y), __uint_as_float(v4.z), __uint_as_float(v4.w));
+  };
+  const int nk = (m_end - m_begin + BK - 1) / BK;
+  auto load_tile = [&](int kt, auto sc) {              // requests past the last k-tile re-fetch it (unconditional loads: counted waits stay exact)
+    constexpr int S = decltype(sc)::value;
+    const int ktc = min(kt, nk - 1);
+    const uint32_t so_a = (uint32_t)ktc * (uint32_t)(BK * lda_e) * ESA, so_b = (uint32_t)ktc * (uint32_t)(BK * ldb_e) * ESB;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      uint32_t vo = va[e];
+      if (conv) vo = ((unsigned)(t_oy + cy[e]) < (unsigned)d.H && (unsigned)(t_ox + cx[e]) < (unsigned)d.W) ? vo : BUF_OOB;
+      ra[S][e] = ld4(rs_a0, rs_a1, vo, so_a, APLN);
+    }
+#pragma unroll
+    for (int i = 0; i < NBT; ++i) {
+      if (i == 2 && !third) continue;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) rb[S][i][e] = ld4(rs_b0, rs_b1, vb[i][e], so_b, BPLN);
+    }
+    if (conv && kt < nk - 1) {            // next k-tile: 32 pixels on (uniform)
+      if (d.OW >= BK) {
+        t_ox += BK;
+        if (t_ox >= d.OW) { t_ox = 0; t_oy = t_oy + 1 >= d.OH ? 0 : t_oy + 1; }
+      } else {
+        t_oy += BK / d.OW;
+        if (t_oy >= d.OH) t_oy -= d.OH;
+      }
+    }
+  };
+  auto pair = [](const float* p0, const float* p1, int j, int plane) {
+    const uint32_t w0 = __float_as_uint(p0[2 * plane + (j >> 1)]), w1 = __float_as_uint(p1[2 * plane + (j >> 1)]);
+    return __builtin_amdgcn_perm(w1, w0, (j & 1) ? 0x07060302u : 0x05040100u);
+  };
+  auto store_tile = [&](int buf, auto sc) {
+    constexpr int S = decltype(sc)::value;
+    uint32_t* st = wsm + buf * STAGE;
+    {
+      const float* a0 = &ra[S][0].x; const float* a1 = &ra[S][1].x;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        uint32_t hi, lo;
+        if (APLN) { hi = pair(a0, a1, j, 0); lo = pair(a0, a1, j, 1); }
+        else split2(a0[j], a1[j], hi, lo);
+        st[(a_row + j) * WG_PITCH + a_dw] = hi;
+        st[PA + (a_row + j) * WG_PITCH + a_dw] = lo;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NBT; ++i) {
+      if (i == 2 && !third) continue;
+      const float* b0 = &rb[S][i][0].x; const float* b1 = &rb[S][i][1].x;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        uint32_t hi, lo;
+        if (BPLN) { hi = pair(b0, b1, j, 0); lo = pair(b0, b1, j, 1); }
+        else split2(b0[j], b1[j], hi, lo);
+        st[2 * PA + (b_row[i] + j) * WG_PITCH + b_dw[i]] = hi;
+        st[2 * PA + PB + (b_row[i] + j) * WG_PITCH + b_dw[i]] = lo;
+      }
+    }
+  };
+
+  f32x16 acc[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  const int li = lane & 31, h = lane >> 5;
+  auto compute = [&](int cur) {
+    const uint32_t* st = wsm + cur * STAGE;
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms) {
+      const int dw = 8 * ms + 4 * h;
+      const bf16x8 ah = lds_frag(st, wm * 32 + li, dw), al = lds_frag(st + PA, wm * 32 + li, dw);
+      bf16x8 bh[TN], bl[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bh[j] = lds_frag(st + 2 * PA, wn * 160 + j * 32 + li, dw);
+        bl[j] = lds_frag(st + 2 * PA + PB, wn * 160 + j * 32 + li, dw);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[j], 0, 0, 0);
+      }
+    }
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  load_tile(0, S0{});
+  store_tile(0, S0{});
+  load_tile(1, S1{});
+  load_tile(2, S0{});
+  __syncthreads();
+  // iteration kt: tile kt + 1 (requested two iterations ago) -> the LDS stage everybody left at the last barrier; request tile kt + 3 into
+  // the registers just freed; multiply tile kt
+  auto step = [&](int kt, auto sc) {
+    constexpr int S = decltype(sc)::value;             // == (kt + 1) & 1
+    if (kt + 1 < nk) store_tile(S, sc);
+    load_tile(kt + 3, sc);
+    compute(S ^ 1);
+    __syncthreads();
+  };
+  int kt = 0;
+#pragma unroll 1
+  for (; kt + 1 < nk; kt += 2) {
+    step(kt, S1{});
+    step(kt + 1, S0{});
+  }
+  if (kt < nk) step(kt, S1{});
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + wn * 160 + j * 32 + li;
+    if (col >= d.N) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = k0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (row >= d.K) continue;
+      atomicAdd(d.out + (int64_t)row * d.ld_out + col, d.alpha * acc[j][r]);
+    }
+  }
+}
+
 static int wgrad_bf16x3(const ddpo_gemm_desc* dp, const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* b_hi, const uint16_t* b_lo,
                        void* stream) {
   if (!dp) return DDPO_EINVAL;
@@ -1932,6 +2140,47 @@ static int wgrad_bf16x3(const ddpo_gemm_desc* dp, const uint16_t* a_hi, const ui
   const int64_t a_bytes = (int64_t)d.M * lda_b * (a_hi ? 2 : 4), b_bytes = (int64_t)d.M * ldb_b * (b_hi ? 2 : 4);
   const bool rows_ok = rows_mode && simple_ && (d.M % 32) == 0 && a_bytes + (conv_ ? (int64_t)(d.W + 1) * lda_b * 4 : 0) < 0x7FFFFFF0ll && b_bytes < 0x7FFFFFF0ll &&
                        (!conv_ || (((d.OW % 32) == 0 || (32 % d.OW) == 0) && ((d.OH * d.OW) % 32) == 0));
+  // wide 128 x 320 tile (one workgroup per CU) where it measured faster (tools/native/kernel_probe wgrad, profiles/r03_probe_wgrad.log): the
+  // 320-column layers with a long k and many pixels — the 3x3 convolutions of the 64x64 level: 320->320 0.67 -> 0.48 ms (181 -> 254 TF) from
+  // fp32 operands, 0.57 -> 0.45 from planes; 960->320 1.62 -> 1.23 / 1.44 -> 1.29; train step +0.6 % (profiles/r03_ab_wgrad_wide.log).  With two or more 320-column tiles, short reductions or
+  // few pixels it ties or loses against two 128 x 128 workgroups per CU (LDS read bytes per MFMA of a 32 x 160 wave tile), so those stay there.
+  const bool wide_ok = rows_ok && d.N == 320 && d.K >= 2560 && d.M >= 16384 && dp->splits <= 0;
+  if (wide_ok) {
+    const int wt = ((d.K + 127) / 128) * (d.N / 320);
+    const int max_splits = (d.M + 255) / 256;
+    int ws_ = 1;                                         // split of the pixel reduction whose tiles x splits fills whole rounds of the 256 CUs best
+    double best_eff = 0.0;
+    for (int r = 1; r <= 3; ++r) {
+      int cand = (256 * r) / wt;
+      if (cand > max_splits) cand = max_splits;
+      if (cand < 1) cand = 1;
+      const long wgs = (long)wt * cand;
+      const double eff = (double)wgs / (double)(((wgs + 255) / 256) * 256);
+      if (eff > best_eff + 0.04 || best_eff == 0.0) { best_eff = eff; ws_ = cand; }
+    }
+    int wmps = (d.M + ws_ - 1) / ws_;
+    wmps = (wmps + 31) / 32 * 32;
+    ws_ = (d.M + wmps - 1) / wmps;
+    const size_t lds = (size_t)2 * (2 * 128 + 2 * 320) * WG_PITCH * 4;
+    const dim3 wgrid(wt, ws_), wblk(512);
+#define WGW_LAUNCH(A, B)                                                                                                           \
+  do {                                                                                                                             \
+    static bool attr_ = false;                                                                                                     \
+    if (!attr_) {                                                                                                                  \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wgrad_bf16_wide_kernel<A, B>),                                 \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                             \
+      attr_ = true;                                                                                                                \
+    }                                                                                                                              \
+    hipLaunchKernelGGL((gemm_wgrad_bf16_wide_kernel<A, B>), wgrid, wblk, lds, st, d, d.N / 320, wmps, a_hi, a_lo, b_hi, b_lo);     \
+  } while (0)
+    if (a_hi && b_hi) WGW_LAUNCH(true, true);
+    else if (a_hi) WGW_LAUNCH(true, false);
+    else if (b_hi) WGW_LAUNCH(false, true);
+    else WGW_LAUNCH(false, false);
+#undef WGW_LAUNCH
+    DDPO_LAUNCH_CHECK();
+    return DDPO_OK;
+  }
 #define WG_LAUNCH(A, B)                                                                                                                        \
   do {                                                                                                                                         \
     if (rows_ok) hipLaunchKernelGGL((gemm_wgrad_bf16_kernel<A, B, true>), grid, blk, 0, st, d, tiles_n, mps, a_hi, a_lo, b_hi, b_lo);          \

@@ -10,6 +10,7 @@
 //                                               activations (weights cold, as in the model)
 //   kernel_probe mx [batch=16] [iters=10]       f16mx plane-fed datapath vs bf16x3 plane-fed: timing, contract check against the decoded
 //                                               planes, accuracy against fp64
+//   kernel_probe wgrad [batch=16] [iters=10]    bf16x3 weight gradients: wide 128x320 tile vs the 128x128 kernel, fp32 and plane operands
 //   kernel_probe attn [batch=16] [iters=10]     bf16x3 / fp32 flash-attention shapes of the same forward
 //   kernel_probe ppo                            scoring-mode log-prob + PPO-clip + grouped micro-batches vs a host loop
 //
@@ -431,6 +432,95 @@ static int probe_mx(int B, int iters) {
   return g_fail;
 }
 
+
+// ------------------------------------------------------------------------------------------------ weight gradient (bf16x3)
+// dW[k][n] = sum_m A(m, k) dY[m][n]: the wide 128x320 tile (splits = 0: the library chooses) against the 128x128 kernel (explicit split count of
+// its own heuristic), fp32 operands and plane operands; spot check against a double-precision host sum
+static int old_wgrad_splits(int M, int K, int N) {
+  const int tiles = ((K + 127) / 128) * ((N + 127) / 128), max_splits = (M + 255) / 256;
+  int best = 1;
+  double best_eff = 0.0;
+  for (int r = 1; r <= 4; ++r) {
+    int cand = std::max(1, std::min((512 * r) / tiles, max_splits));
+    const long wgs = (long)tiles * cand;
+    const double eff = (double)wgs / (double)(((wgs + 511) / 512) * 512);
+    if (eff > best_eff + 0.03 || best_eff == 0.0) { best_eff = eff; best = cand; }
+  }
+  return best;
+}
+static void run_wgrad(int B, int H, int Cin, int Cout, int ks, int iters) {
+  const bool conv = ks > 0;
+  const int pad = ks / 2;
+  const int64_t M = conv ? (int64_t)B * H * H : (int64_t)B * H;
+  const int K = conv ? ks * ks * Cin : Cin, N = Cout;
+  const int acols = conv ? Cin : K;
+  Dev src(M * acols, 21, 1.0f), dy(M * N, 22, 1.0f);
+  float* dw = (float*)dalloc((size_t)K * N * 4);
+  uint16_t *ah = (uint16_t*)dalloc((size_t)M * acols * 2), *al = (uint16_t*)dalloc((size_t)M * acols * 2);
+  uint16_t *bh = (uint16_t*)dalloc((size_t)M * N * 2), *bl = (uint16_t*)dalloc((size_t)M * N * 2);
+  ABI_OK(ddpo_split_planes_bf16(src.p, acols, ah, al, acols, M, acols, nullptr));
+  ABI_OK(ddpo_split_planes_bf16(dy.p, N, bh, bl, N, M, N, nullptr));
+  ddpo_gemm_desc d;
+  memset(&d, 0, sizeof(d));
+  d.src = src.p; d.ld_src = acols; d.w = dy.p; d.ld_w = N; d.out = dw; d.ld_out = N; d.alpha = 1.f;
+  d.M = (int)M; d.N = N; d.K = K;
+  if (conv) { d.ksize = ks; d.stride = 1; d.pad = pad; d.B = B; d.H = H; d.W = H; d.Cin = Cin; d.OH = H; d.OW = H; }
+  ddpo_gemm_desc d_old = d;
+  d_old.splits = old_wgrad_splits((int)M, K, N);
+  const double fl = 2.0 * (double)M * N * K;
+  float ms[4];
+  ms[0] = time_ms(iters, [&] { ABI_OK(ddpo_gemm_conv_wgrad_bf16x3(&d_old, nullptr)); });
+  ms[1] = time_ms(iters, [&] { ABI_OK(ddpo_gemm_conv_wgrad_bf16x3(&d, nullptr)); });
+  ms[2] = time_ms(iters, [&] { ABI_OK(ddpo_gemm_conv_wgrad_bf16x3_planes(&d_old, ah, al, bh, bl, nullptr)); });
+  ms[3] = time_ms(iters, [&] { ABI_OK(ddpo_gemm_conv_wgrad_bf16x3_planes(&d, ah, al, bh, bl, nullptr)); });
+  double rel[2] = {0, 0};
+  for (int v = 0; v < 2; ++v) {              // one clean accumulation each: fp32-fed, plane-fed (library's choice of kernel)
+    HIP_OK(hipMemset(dw, 0, (size_t)K * N * 4));
+    if (v == 0) ABI_OK(ddpo_gemm_conv_wgrad_bf16x3(&d, nullptr));
+    else ABI_OK(ddpo_gemm_conv_wgrad_bf16x3_planes(&d, ah, al, bh, bl, nullptr));
+    const int NS = 24;
+    double max_err = 0.0, ref_sq = 0.0;
+    for (int s = 0; s < NS; ++s) {
+      const int k = (s < 4) ? (s & 1 ? K - 1 - s : s) : (int)((hval(87, s) * 0.5 + 0.5) * K) % K;
+      const int n = (s < 4) ? (s & 2 ? N - 1 - s : s) : (int)((hval(88, s) * 0.5 + 0.5) * N) % N;
+      float got;
+      HIP_OK(hipMemcpy(&got, dw + (int64_t)k * N + n, 4, hipMemcpyDeviceToHost));
+      double acc = 0.0;
+      const int tap = conv ? k / Cin : 0, ci = conv ? k % Cin : k;
+      const int dky = conv ? tap / ks - pad : 0, dkx = conv ? tap % ks - pad : 0;
+      for (int64_t m = 0; m < M; ++m) {
+        int64_t am = m;
+        if (conv) {
+          const int x = (int)(m % H), y = (int)((m / H) % H);
+          if (y + dky < 0 || y + dky >= H || x + dkx < 0 || x + dkx >= H) continue;
+          am = m + (int64_t)dky * H + dkx;
+        }
+        acc += (double)src.at(am * acols + ci) * (double)dy.at(m * N + n);
+      }
+      max_err = std::max(max_err, fabs(acc - (double)got));
+      ref_sq += acc * acc;
+    }
+    rel[v] = max_err / (sqrt(ref_sq / NS) + 1e-30);
+  }
+  const bool ok = rel[0] < 2e-4 && rel[1] < 2e-4;
+  if (!ok) ++g_fail;
+  if (conv) printf("wgrad conv %dx%d %5d->%5d @%3d^2 B%-3d:", ks, ks, Cin, Cout, H, B);
+  else printf("wgrad gemm M=%7lld K=%5d N=%5d  :", (long long)M, K, N);
+  printf(" fp32 128x128 %7.3f ms %6.1f TF -> auto %7.3f ms %6.1f TF (x%.2f) | planes %7.3f ms %6.1f TF -> auto %7.3f ms %6.1f TF (x%.2f) | err/rms %.1e %.1e %s\n",
+         ms[0], fl / ms[0] / 1e9, ms[1], fl / ms[1] / 1e9, ms[0] / ms[1], ms[2], fl / ms[2] / 1e9, ms[3], fl / ms[3] / 1e9, ms[2] / ms[3], rel[0], rel[1], ok ? "" : "FAIL");
+  fflush(stdout);
+  src.release(); dy.release();
+  for (void* q : {(void*)dw, (void*)ah, (void*)al, (void*)bh, (void*)bl}) HIP_OK(hipFree(q));
+}
+static int probe_wgrad(int B, int iters) {
+  const int convs[][4] = {{64, 320, 320, 3}, {32, 640, 640, 3}, {16, 1280, 1280, 3}, {8, 1280, 1280, 3}, {64, 960, 320, 3}, {32, 1920, 640, 3},
+                          {16, 2560, 1280, 3}, {32, 320, 640, 3}, {64, 320, 320, 1}, {32, 960, 640, 1}};
+  for (auto& c : convs) run_wgrad(B, c[0], c[1], c[2], c[3], iters);
+  const int dense[][3] = {{4096, 320, 320}, {4096, 320, 2560}, {4096, 1280, 320}, {1024, 640, 640}, {1024, 2560, 640}, {256, 1280, 1280}, {256, 5120, 1280}};
+  for (auto& g : dense) run_wgrad(B, g[0], g[1], g[2], 0, iters);
+  return g_fail;
+}
+
 // ------------------------------------------------------------------------------------------------ phase timing (kernel_probe_timing)
 #ifdef PROBE_TIMING
 extern "C" int ddpo_debug_kloop_times(unsigned long long* host, int n_wg);
@@ -673,6 +763,7 @@ int main(int argc, char** argv) {
   if (mode == "gemm") rc = probe_gemm(B, iters);
   else if (mode == "gemm2") rc = probe_gemm2(B, iters);
   else if (mode == "mx") rc = probe_mx(B, iters);
+  else if (mode == "wgrad") rc = probe_wgrad(B, iters);
   else if (mode == "attn") rc = probe_attn(B, iters);
   else if (mode == "ppo") rc = probe_ppo();
 #ifdef PROBE_TIMING
