@@ -75,7 +75,9 @@ __host__ __device__ __forceinline__ int64_t plane_off(int64_t row, int c, int ld
 // lanes 0-31 carrying the first pair and lanes 32-63 the second).  ACTIVATIONS: e5m2 at a FIXED scale — h8 = e5m2(h) (the f16 value
 // rounded to two mantissa bits; same exponent range, so no block scale has to be computed, stored or fetched), l8 = e5m2(l * 2^11)
 // (|l| <= 2^-11 |x|).  Two planes of the geometry of the bf16 hi / lo planes: `p16` holds h, `p8` holds per 32-channel block the
-// 64 bytes [h8 x 32 | l8 x 32].  WEIGHTS: e4m3 with one power-of-two scale per output column (ddpo_pack_weights_f16mx).
+// 64 bytes [h8 c0-15 | l8 c0-15 | h8 c16-31 | l8 c16-31] — 16-byte chunk q of a row is what lane half (q & 1) of the 8-bit MFMA reads for
+// its k half (q >> 1), i.e. the fragment reads use the SAME LDS offsets as the 16-bit plane's.  WEIGHTS: e4m3 with one power-of-two
+// scale per output column, chunks [l8 | h8 | l8 | h8] (ddpo_pack_weights_f16mx).
 typedef _Float16 mx_half2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void mx_split4(const float4 v, uint2& h16, uint32_t& h8, uint32_t& l8) {
   const float lim = 65504.f;              // f16 range: larger magnitudes saturate (Stable Diffusion runs in f16 end to end)
@@ -96,9 +98,9 @@ __device__ __forceinline__ void mx_store4(uint16_t* __restrict__ p16, uint16_t* 
   uint32_t h8, l8;
   mx_split4(v, h16, h8, l8);
   *reinterpret_cast<uint2*>(p16 + plane_off(row, c, ld, rows)) = h16;
-  char* b = reinterpret_cast<char*>(p8 + plane_off(row, c & ~31, ld, rows)) + (c & 31);
+  char* b = reinterpret_cast<char*>(p8 + plane_off(row, c & ~31, ld, rows)) + 2 * (c & 16) + (c & 15);
   *reinterpret_cast<uint32_t*>(b) = h8;
-  *reinterpret_cast<uint32_t*>(b + 32) = l8;
+  *reinterpret_cast<uint32_t*>(b + 16) = l8;
 }
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }

@@ -467,10 +467,9 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
   // right after the barrier that publishes it and the second half of the current tile's ks=1 MFMAs is issued behind them,
   // so the LDS latency is covered by matrix work instead of stalling the wave at the top of every k-tile.
   // f16mx: the 16-bit fragments are f16 (same bytes, same offsets), and at ks = 1 each operand's 32 bytes of the 8-bit plane are read as
-  // one fragment: lanes 0-31 the chunks 0, 1 of the row (A: h8, W: l8), lanes 32-63 the chunks 2, 3 (A: l8, W: h8) — the two cross terms
-  // of the k-tile ride in the two lane halves of ONE 32x32x64 MFMA.  Chunk c sits at a_ld0 ^ (16 * (c ^ khalf)) (swz_off is an XOR).
+  // one fragment from the SAME two offsets (the plane's chunks are [h8 | l8 | h8 | l8] for activations, [l8 | h8 | l8 | h8] for weights: lane half
+  // 0 gets a_h8 and w_l8 of k 0..31, lane half 1 a_l8 and w_h8) — the two cross terms of the k-tile ride in the two lane halves of ONE 32x32x64 MFMA.
   struct Frag { bf16x8 ah[TM], al[TM], bh[TN], bl[TN]; i32x8 a8[TM], b8[TN]; };
-  const int a_x0 = a_ld0 ^ (khalf * 48), a_x1 = a_ld0 ^ (16 + khalf * 16), b_x0 = b_ld0 ^ (khalf * 48), b_x1 = b_ld0 ^ (16 + khalf * 16);
   auto ldfrag_at = [&](const char* sa, const char* sb, int ks, Frag& f) {
     const char* pa = sa + (ks ? a_ld1 : a_ld0);
     const char* pb = sb + (ks ? b_ld1 : b_ld0);
@@ -479,7 +478,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
       f.ah[i] = *reinterpret_cast<const bf16x8*>(pa + i * 2048);
       if (NPASS == 3) f.al[i] = *reinterpret_cast<const bf16x8*>(pa + A_BYTES + i * 2048);
       if (MX && ks) {
-        const i32x4 x = *reinterpret_cast<const i32x4*>(sa + a_x0 + A_BYTES + i * 2048), y = *reinterpret_cast<const i32x4*>(sa + a_x1 + A_BYTES + i * 2048);
+        const i32x4 x = *reinterpret_cast<const i32x4*>(sa + a_ld0 + A_BYTES + i * 2048), y = *reinterpret_cast<const i32x4*>(sa + a_ld1 + A_BYTES + i * 2048);
         f.a8[i] = i32x8{x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
       }
     }
@@ -488,7 +487,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
       f.bh[j] = *reinterpret_cast<const bf16x8*>(pb + j * 2048);
       if (NPASS == 3) f.bl[j] = *reinterpret_cast<const bf16x8*>(pb + B_BYTES + j * 2048);
       if (MX && ks) {
-        const i32x4 x = *reinterpret_cast<const i32x4*>(sb + b_x0 + B_BYTES + j * 2048), y = *reinterpret_cast<const i32x4*>(sb + b_x1 + B_BYTES + j * 2048);
+        const i32x4 x = *reinterpret_cast<const i32x4*>(sb + b_ld0 + B_BYTES + j * 2048), y = *reinterpret_cast<const i32x4*>(sb + b_ld1 + B_BYTES + j * 2048);
         f.b8[j] = i32x8{x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
       }
     }
@@ -1311,9 +1310,10 @@ static int dispatch_bf16(const ddpo_gemm_desc& d, const uint16_t* w_hi, const ui
     // are exactly one round; 576 (SD-2.1, 96x96) are 2.25 rounds = 3 rounds of time, where 1152 wide tiles waste half a round of five
     const long ntall = (long)((d.M + 255) / 256) * (d.N / 320), nwide = (long)((d.M + 127) / 128) * (d.N / 320);
     const double eff_tall = (double)ntall / (double)(((ntall + 255) / 256) * 256), eff_wide = (double)nwide / (double)(((nwide + 255) / 256) * 256);
-    // (bf16x3 only.  An f16mx tall loop — 8-bit weight fragments streamed per column block beside the 160 accumulators — was built and
-    // measured in round 3: correct, and no faster than either the bf16x3 tall tile or the f16mx 128x320 tile (conv 320->320 @64^2:
-    // 0.326 vs 0.321 / 0.317 ms): at this level the tile is bound by the operand stream, not by the matrix pipe.  profiles/r03_probe_mx_tall.log)
+    // (bf16x3 only.  An f16mx tall loop — the weight operand's ks = 1 fragments streamed per column block beside the 160 accumulators — was
+    // built twice in round 3: correct, but the compiler spills ~60 registers of the convolution bookkeeping around it, and their reloads sit
+    // behind the LDS-DMA requests on the in-order vmcnt counter, so every k-tile waits for its own prefetch: 0.326 ms against 0.321 (bf16x3
+    // tall) / 0.317 (f16mx 128x320) on conv 320->320 @64^2, profiles/r03_probe_mx_tall.log.  It needs the tap bookkeeping out of VGPRs first.)
     if (tall_mode && npass == 3 && d.N % 320 == 0 && d.epilogue == 0 && ntall >= 200 && eff_tall * 1.08 >= eff_wide)
       return launch_bf16_tall<5>(d, w_hi, w_lo, ldw, st);
   }
@@ -1586,8 +1586,9 @@ __global__ void __launch_bounds__(256) pack_weights_mx_kernel(const float* __res
       const uint32_t p = tile[tx][r];
       const int64_t row = (int64_t)kb * N + n;
       w16[row * 32 + tx] = (uint16_t)(p & 0xFFFFu);
-      w8[row * 64 + tx] = (uint8_t)(p >> 24);               // l8 first: lanes 0-31 of the MFMA pair it with the activations' h8
-      w8[row * 64 + 32 + tx] = (uint8_t)((p >> 16) & 0xFFu);
+      const int o = 2 * (tx & 16) + (tx & 15);              // chunks [l8 k0-15 | h8 k0-15 | l8 k16-31 | h8 k16-31]
+      w8[row * 64 + o] = (uint8_t)(p >> 24);                // l8 first: lane half 0 of the MFMA pairs it with the activations' h8
+      w8[row * 64 + o + 16] = (uint8_t)((p >> 16) & 0xFFu);
     }
   }
 }

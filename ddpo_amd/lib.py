@@ -292,7 +292,7 @@ def pack_weights_f16mx(w):
 
 def split_planes_f16mx(x):
     """fp32 (rows, C), C % 32 == 0 -> (p16, p8): the f16 plane (rows, C) int16 and the 8-bit plane (rows, C / 32, 64) uint8
-    [e5m2(h) x 32 | e5m2(l * 2^11) x 32] per 32-channel block (row-major storage)."""
+    per 32-channel block: chunks of 16 bytes [h8 c0-15 | l8 c0-15 | h8 c16-31 | l8 c16-31], h8 = e5m2(h), l8 = e5m2(l * 2^11) (row-major storage)."""
     rows, C = x.shape
     p16 = torch.empty(rows, C, dtype=torch.int16, device=x.device)
     p8 = torch.empty(rows, C // 32, 64, dtype=torch.uint8, device=x.device)

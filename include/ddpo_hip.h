@@ -189,8 +189,8 @@ typedef struct {
   int w_layout;
   /* f16mx datapath (ABI v7; ddpo_gemm_conv_fwd_f16mx_planes only, zero elsewhere): one E8M0 scale byte per output column of the
    * 8-bit weight plane (ddpo_pack_weights_f16mx), and the FORMAT of the planes the output stage emits into out_hi / out_lo:
-   *   0: bf16 hi / lo (above);  1: f16mx — out_hi = f16 plane, out_lo = per 32-column block [e5m2(h) x 32 | e5m2(l * 2^11) x 32]
-   *      (needs the emitted column count % 32 == 0).  Same geometry and ld_planes convention as the bf16 planes. */
+   *   0: bf16 hi / lo (above);  1: f16mx — out_hi = f16 plane, out_lo = per 32-column block the 64 bytes
+   *      [h8 c0-15 | l8 c0-15 | h8 c16-31 | l8 c16-31], h8 = e5m2(h), l8 = e5m2(l * 2^11) (needs the emitted column count % 32 == 0).  Same geometry and ld_planes convention as the bf16 planes. */
   const uint8_t* w_scale;
   int planes_fmt;
 } ddpo_gemm_desc;

@@ -16,8 +16,8 @@ def _dec_planes(p16, p8):
     """(h, h8, l8) as float64 (rows, C) from the activation planes."""
     rows, C = p16.shape
     h = p16.view(torch.float16).double()
-    b = p8.view(torch.float8_e5m2).double()                      # (rows, C/32, 64)
-    return h, b[:, :, :32].reshape(rows, C), b[:, :, 32:].reshape(rows, C) / 2048.0
+    b = p8.view(torch.float8_e5m2).double().view(rows, C // 32, 2, 2, 16)      # per block: [k half][h8 | l8][16]
+    return h, b[:, :, :, 0].reshape(rows, C), b[:, :, :, 1].reshape(rows, C) / 2048.0
 
 
 def _dec_weights(wp):
@@ -25,9 +25,9 @@ def _dec_weights(wp):
     K, N = wp["K"], wp["N"]
     s = torch.pow(2.0, wp["scale"].double() - 127.0)                      # (N,)
     h = wp["w16"].view(torch.float16).double().permute(0, 2, 1).reshape(-1, N)[:K]      # (Kb, N, 32) -> (Kb*32, N)
-    b = wp["w8"].view(torch.float8_e4m3fn).double()                      # (Kb, N, 64): [l8 | h8]
-    l8 = (b[:, :, :32] * s[None, :, None] / 2048.0).permute(0, 2, 1).reshape(-1, N)[:K]
-    h8 = (b[:, :, 32:] * s[None, :, None]).permute(0, 2, 1).reshape(-1, N)[:K]
+    b = wp["w8"].view(torch.float8_e4m3fn).double().view(-1, N, 2, 2, 16)      # (Kb, N, k half, [l8 | h8], 16)
+    l8 = (b[:, :, :, 0].reshape(-1, N, 32) * s[None, :, None] / 2048.0).permute(0, 2, 1).reshape(-1, N)[:K]
+    h8 = (b[:, :, :, 1].reshape(-1, N, 32) * s[None, :, None]).permute(0, 2, 1).reshape(-1, N)[:K]
     return h, h8, l8
 
 
@@ -38,9 +38,9 @@ def test_activation_planes_are_f16_and_e5m2_of_the_split():
     h = x.half()
     assert torch.equal(p16.view(torch.float16), h)                       # round to nearest even, like torch
     l = (x - h.float()) * 2048.0
-    b = p8.view(torch.float8_e5m2)
-    assert torch.equal(b[:, :, :32].reshape(77, 96).float(), h.float().to(torch.float8_e5m2).float())
-    assert torch.equal(b[:, :, 32:].reshape(77, 96).float(), l.to(torch.float8_e5m2).float())
+    b = p8.view(torch.float8_e5m2).view(77, 3, 2, 2, 16)
+    assert torch.equal(b[:, :, :, 0].reshape(77, 96).float(), h.float().to(torch.float8_e5m2).float())
+    assert torch.equal(b[:, :, :, 1].reshape(77, 96).float(), l.to(torch.float8_e5m2).float())
     hh, h8, l8 = _dec_planes(p16, p8)
     xd = x.double()
     assert float(((hh + l8) - xd).abs().max() / xd.abs().max()) < 2.0 ** -13          # h + l8: 11 + 3 bits
@@ -62,7 +62,7 @@ def test_weight_planes_are_f16_and_column_scaled_e4m3():
     q = lambda v: (v / s).to(torch.float8_e4m3fn).float() * s
     assert torch.equal(h8.float(), q(w.half().float()))
     assert torch.equal((l8 * 2048.0).float(), q((w - w.half().float()) * 2048.0))
-    assert float(wp["w16"][3, :, 4:].abs().max()) == 0 and float(wp["w8"][3, :, 4:32].abs().max()) == 0      # k >= K: zeros
+    assert float(wp["w16"][3, :, 4:].abs().max()) == 0 and float(wp["w8"].view(-1, N, 2, 2, 16)[3, :, 0, :, 4:].abs().max()) == 0      # k >= K: zeros
 
 
 CASES = [  # (B, H, Cin, Cout, ksize, stride, upsample)  ksize 0: dense with M = B * H rows

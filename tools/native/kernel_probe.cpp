@@ -8,6 +8,7 @@
 //   kernel_probe gemm2 [batch=16] [iters=10]    plane-fed (LDS-DMA) kernel vs the fp32-fed one: timing + bitwise comparison
 //                                               PROBE_COLD=1: flush the caches before every timed launch and re-read only the
 //                                               activations (weights cold, as in the model)
+//   kernel_probe vae [batch=8] [iters=5]        the VAE decoder's convolutions (512 x 512 output), fp32-fed vs plane-fed
 //   kernel_probe mx [batch=16] [iters=10]       f16mx plane-fed datapath vs bf16x3 plane-fed: timing, contract check against the decoded
 //                                               planes, accuracy against fp64
 //   kernel_probe wgrad [batch=16] [iters=10]    bf16x3 weight gradients: wide 128x320 tile vs the 128x128 kernel, fp32 and plane operands
@@ -285,6 +286,18 @@ static void run_gemm2(int B, int H, int Cin, int Cout, int ks, int stride, int u
   HIP_OK(hipFree(out1)); HIP_OK(hipFree(out2)); HIP_OK(hipFree(hi)); HIP_OK(hipFree(lo)); HIP_OK(hipFree(ah)); HIP_OK(hipFree(al));
 }
 
+// the VAE decoder's convolutions at 512 x 512 output (batch = images per decode call): few channels, millions of rows
+static int probe_vae(int B, int iters) {
+  const size_t ws_bytes = 64u << 20;
+  void* ws = dalloc(ws_bytes);
+  const ConvCase convs[] = {{64, 512, 512, 3, 1, 0},  {128, 512, 512, 3, 1, 0}, {64, 512, 512, 3, 1, 1},  {256, 512, 256, 3, 1, 0},
+                            {256, 256, 256, 3, 1, 0}, {128, 512, 512, 3, 1, 1}, {512, 256, 128, 3, 1, 0}, {512, 128, 128, 3, 1, 0},
+                            {256, 256, 256, 3, 1, 1}, {256, 512, 256, 1, 1, 0}, {512, 256, 128, 1, 1, 0}};
+  for (const ConvCase& c : convs) run_gemm2(B, c.H, c.Cin, c.Cout, c.ks, c.stride, c.ups, iters, ws, ws_bytes);
+  HIP_OK(hipFree(ws));
+  return 0;
+}
+
 static int probe_gemm2(int B, int iters) {
   const size_t ws_bytes = 64u << 20;
   void* ws = dalloc(ws_bytes);
@@ -378,9 +391,10 @@ static void run_mx(int B, int H, int Cin, int Cout, int ks, int stride, int ups,
     auto term = [&](int64_t arow, int ci, int k) {            // activation (arow, ci) x weight (k, n)
       const int64_t ao = arow * acols + ci, wo = ((int64_t)(k >> 5) * N + n);
       const double a_h = dec_f16(h_a16[ao]), w_h = dec_f16(h_w16[wo * 32 + (k & 31)]);
-      const int64_t ab = (arow * acols + (ci & ~31)) * 2 + (ci & 31);
-      const double a_h8 = dec_e5m2(a8b[ab]), a_l8 = dec_e5m2(a8b[ab + 32]) / 2048.0;
-      const double w_l8 = dec_e4m3(w8b[wo * 64 + (k & 31)]) * sn / 2048.0, w_h8 = dec_e4m3(w8b[wo * 64 + 32 + (k & 31)]) * sn;
+      const int64_t ab = (arow * acols + (ci & ~31)) * 2 + 2 * (ci & 16) + (ci & 15);       // chunks [h8 | l8 | h8 | l8]
+      const double a_h8 = dec_e5m2(a8b[ab]), a_l8 = dec_e5m2(a8b[ab + 16]) / 2048.0;
+      const int wq = 2 * (k & 16) + (k & 15);                                              // chunks [l8 | h8 | l8 | h8]
+      const double w_l8 = dec_e4m3(w8b[wo * 64 + wq]) * sn / 2048.0, w_h8 = dec_e4m3(w8b[wo * 64 + wq + 16]) * sn;
       acc_p += a_h * w_h + a_h8 * w_l8 + a_l8 * w_h8;
       acc_t += (double)src.at(ao) * (double)w.at((int64_t)k * N + n);
     };
@@ -763,6 +777,7 @@ int main(int argc, char** argv) {
   if (mode == "gemm") rc = probe_gemm(B, iters);
   else if (mode == "gemm2") rc = probe_gemm2(B, iters);
   else if (mode == "mx") rc = probe_mx(B, iters);
+  else if (mode == "vae") rc = probe_vae(B, iters);
   else if (mode == "wgrad") rc = probe_wgrad(B, iters);
   else if (mode == "attn") rc = probe_attn(B, iters);
   else if (mode == "ppo") rc = probe_ppo();

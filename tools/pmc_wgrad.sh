@@ -1,5 +1,5 @@
 #!/bin/bash
-# SQ-level PMC counters of gemm_wgrad_bf16_kernel on one layer (separate passes, --kernel-trace only).
+# SQ-level PMC counters of the bf16x3 weight-gradient kernels (128x128 and wide 128x320 tile) on two layers (separate passes, --kernel-trace only).
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/pmc_wgrad
@@ -24,8 +24,8 @@ for d in sorted(glob.glob("g*")):
     acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
     for row in csv.DictReader(open(files[0])):
         k = row["Kernel_Name"]
-        if "gemm_wgrad_bf16_kernel" not in k: continue
-        tag = k[5:48]
+        if "gemm_wgrad_bf16" not in k: continue
+        tag = k[5:60]
         acc[tag][row["Counter_Name"]] += float(row["Counter_Value"]); n[(tag, row["Counter_Name"])] += 1
     for k, v in acc.items():
         print(d, k, {c: f"{x / max(n[(k, c)], 1):.4g}" for c, x in v.items()})

@@ -18,6 +18,8 @@ for d in prof_s3 prof_t3; do f=$(find gpurun_out/$d -name "*.db" | head -1); [ -
 head -16 gpurun_out/r03_final_prof_s3_kernel_stats.md | cut -c1-170
 timeout 400 python bench.py --mode train --steps 12 --warmup 2 --no-cpu-baseline --no-roofline > gpurun_out/r03_bench_train_final.log 2>&1; tail -1 gpurun_out/r03_bench_train_final.log | cut -c1-400
 timeout 400 python bench.py --mode epoch --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > gpurun_out/r03_bench_epoch.log 2>&1; tail -1 gpurun_out/r03_bench_epoch.log | cut -c1-400
+timeout 500 bash tools/pmc_wgrad.sh > gpurun_out/r03_pmc_wgrad.log 2>&1; tail -8 gpurun_out/r03_pmc_wgrad.log | cut -c1-300
+(cd tools/native && for m in gemm2 mx wgrad; do PROBE_WKBLK=1 timeout 200 ./kernel_probe $m 16 10 > ../../gpurun_out/r03_final_probe_$m.log 2>&1; tail -1 ../../gpurun_out/r03_final_probe_$m.log; done)
 # BASELINE configs[4] (C5): SD-2.1 768^2 on the fp32-class datapath and on the config's named dtype (bfloat16 -> single-pass bf16 MFMA)
 timeout 500 python bench.py --model sd21 --resolution 768 --no-cpu-baseline --no-train-extra > gpurun_out/r03_bench_c5_sd21_768_bf16x3.log 2>&1; tail -1 gpurun_out/r03_bench_c5_sd21_768_bf16x3.log | cut -c1-300
 timeout 500 python bench.py --model sd21 --resolution 768 --datapath bf16 --no-cpu-baseline --no-train-extra > gpurun_out/r03_bench_c5_sd21_768_bf16.log 2>&1; tail -1 gpurun_out/r03_bench_c5_sd21_768_bf16.log | cut -c1-300

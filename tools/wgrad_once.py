@@ -23,3 +23,11 @@ for _ in range(5):
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 5
 print(f"wgrad conv3x3 {C}->{C} @{H}^2 B{B}: {ms:.3f} ms  {2.0 * B * H * H * 9 * C * C / ms / 1e9:.1f} TF (A from planes)")
+
+# a second layer that stays on the 128x128 kernel (conv 3x3 640->640 @ 32^2): the counters of both tiles come from one process
+C2, H2 = 640, 32
+x2 = torch.randn(B * H2 * H2, C2, device="cuda"); dy2 = torch.randn(B * H2 * H2, C2, device="cuda"); dw2 = torch.zeros(3, 3, C2, C2, device="cuda")
+xp2 = L.split_planes(x2)
+for _ in range(3):
+    L.conv2d_wgrad(xp2, dy2, dw2, B, H2, H2, C2, C2, 3)
+torch.cuda.synchronize()
