@@ -1022,6 +1022,11 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
         float4 o;
         o.x = (a.x + ba.x) * gelu_tanh_f(g.x + bg.x); o.y = (a.y + ba.y) * gelu_tanh_f(g.y + bg.y);
         o.z = (a.z + ba.z) * gelu_tanh_f(g.z + bg.z); o.w = (a.w + ba.w) * gelu_tanh_f(g.w + bg.w);
+        if (d.aux_out) {                          // pre-activation in the original [a | gate] column order (training forward)
+          float* pa = d.aux_out + (int64_t)row * d.N + q * 32 + gc;
+          *reinterpret_cast<float4*>(pa) = make_float4(a.x + ba.x, a.y + ba.y, a.z + ba.z, a.w + ba.w);
+          *reinterpret_cast<float4*>(pa + (d.N >> 1)) = make_float4(g.x + bg.x, g.y + bg.y, g.z + bg.z, g.w + bg.w);
+        }
         if (d.out) *reinterpret_cast<float4*>(d.out + (int64_t)row * d.ld_out + q * 32 + gc) = o;
         if (d.out_hi) store_planes4(d, row, q * 32 + gc, o);
       }
@@ -1295,6 +1300,7 @@ static int dispatch_bf16(const ddpo_gemm_desc& d, const uint16_t* w_hi, const ui
   if (d.epilogue != 0) {       // GEGLU output stage: 128-wide tiles of the buffer-addressed kernel, vector epilogue only
     if (d.epilogue != 1 || (d.N & 127) || !buf_path_ok(d, ldw) || d.rowbias || d.residual || d.alpha != 1.0f || d.w_dgrad) return DDPO_EINVAL;
     if ((d.ld_out & 3) || (reinterpret_cast<uintptr_t>(d.out) & 15) || (d.bias && (reinterpret_cast<uintptr_t>(d.bias) & 15))) return DDPO_EINVAL;
+    if (reinterpret_cast<uintptr_t>(d.aux_out) & 15) return DDPO_EINVAL;
     if constexpr (APL == 3) { if (npass == 4) return launch_bf16<128, 128, 4, 2, 2, 3>(d, w_hi, w_lo, ldw, nullptr, 0, st); }
     return npass == 3 ? launch_bf16<128, 128, 3, 2, 2, APL>(d, w_hi, w_lo, ldw, nullptr, 0, st) : launch_bf16<128, 128, 1>(d, w_hi, w_lo, ldw, nullptr, 0, st);
   }
@@ -1797,8 +1803,15 @@ __global__ void __launch_bounds__(BF_THREADS) gemm_wgrad_bf16_kernel(const ddpo_
   auto load_tile = [&](int kt) {
     if constexpr (ROWL) load_tile_rows(kt); else load_tile_px(kt);
   };
+  // bias gradient (d.colsum, fp32 dY only): the k = 0 row of workgroups also sums the dY values it stages, per channel
+  const bool do_cs = !BPLN && d.colsum != nullptr && tile_m == 0;
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
   auto store_tile = [&](int buf) {
     uint32_t* st = smem[buf];
+    if (do_cs) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) cs[j] += ((&rb[0][0].x)[j] + (&rb[0][1].x)[j]) + ((&rb[1][0].x)[j] + (&rb[1][1].x)[j]);
+    }
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       const int dw = pp + 8 * p;                        // dword (= pixel pair) index within the row
@@ -1877,6 +1890,14 @@ __global__ void __launch_bounds__(BF_THREADS) gemm_wgrad_bf16_kernel(const ddpo_
         atomicAdd(d.out + (int64_t)row * d.ld_out + col, d.alpha * acc[i][j][r]);
       }
     }
+  if (do_cs) {                                  // lanes q + 8 * pp of a wave hold the same 4 channels: fold the 8 pixel-pair lanes, lane pp == 0 adds
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v = cs[j];
+      v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+      if (pp == 0 && ng + j < d.N) atomicAdd(d.colsum + ng + j, v);
+    }
+  }
 }
 
 // WIDE weight-gradient tile (round 3): 128 (k) x 320 (n) per workgroup, 8 waves of 32 x 160, one workgroup per CU.  The 128 x 128 kernel above
@@ -1996,9 +2017,23 @@ __global__ void __launch_bounds__(512) gemm_wgrad_bf16_wide_kernel(const ddpo_ge
     const uint32_t w0 = __float_as_uint(p0[2 * plane + (j >> 1)]), w1 = __float_as_uint(p1[2 * plane + (j >> 1)]);
     return __builtin_amdgcn_perm(w1, w0, (j & 1) ? 0x07060302u : 0x05040100u);
   };
+  const bool do_cs = !BPLN && d.colsum != nullptr && tile_m == 0;      // bias gradient: see the 128 x 128 kernel
+  float cs[NBT][4];
+#pragma unroll
+  for (int i = 0; i < NBT; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cs[i][j] = 0.f;
   auto store_tile = [&](int buf, auto sc) {
     constexpr int S = decltype(sc)::value;
     uint32_t* st = wsm + buf * STAGE;
+    if (do_cs) {
+#pragma unroll
+      for (int i = 0; i < NBT; ++i) {
+        if (i == 2 && !third) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cs[i][j] += (&rb[S][i][0].x)[j] + (&rb[S][i][1].x)[j];
+      }
+    }
     {
       const float* a0 = &ra[S][0].x; const float* a1 = &ra[S][1].x;
 #pragma unroll
@@ -2085,6 +2120,19 @@ __global__ void __launch_bounds__(512) gemm_wgrad_bf16_wide_kernel(const ddpo_ge
       atomicAdd(d.out + (int64_t)row * d.ld_out + col, d.alpha * acc[j][r]);
     }
   }
+  if (do_cs) {
+#pragma unroll
+    for (int i = 0; i < NBT; ++i) {
+      if (i == 2 && !third) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v = cs[i][j];
+        v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+        const int n = n0 + b_row[i] + j;
+        if (pp == 0 && vb[i][0] != BUF_OOB && n < d.N) atomicAdd(d.colsum + n, v);
+      }
+    }
+  }
 }
 
 static int wgrad_bf16x3(const ddpo_gemm_desc* dp, const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* b_hi, const uint16_t* b_lo,
@@ -2093,6 +2141,7 @@ static int wgrad_bf16x3(const ddpo_gemm_desc* dp, const uint16_t* a_hi, const ui
   ddpo_gemm_desc d = *dp;
   if ((!d.src && !a_hi) || (!d.w && !b_hi) || !d.out || d.M <= 0 || d.N <= 0 || d.K <= 0) return DDPO_EINVAL;
   if ((a_hi && !a_lo) || (b_hi && !b_lo)) return DDPO_EINVAL;
+  if (d.colsum && b_hi) return DDPO_EINVAL;          // the fused bias gradient sums the fp32 dY registers
   if ((d.ld_src & 3) || (d.ld_w & 3) || (d.N & 3) || (d.K & 3)) return DDPO_EINVAL;
   if (!a_hi && (reinterpret_cast<uintptr_t>(d.src) & 15)) return DDPO_EINVAL;
   if (!b_hi && (reinterpret_cast<uintptr_t>(d.w) & 15)) return DDPO_EINVAL;

@@ -36,10 +36,10 @@ class GemmDesc(ctypes.Structure):
                 ("OH", c_int), ("OW", c_int),
                 ("w_dgrad", c_int), ("ld_w", c_int), ("splits", c_int), ("accumulate", c_int), ("epilogue", c_int),
                 ("out_hi", c_void_p), ("out_lo", c_void_p), ("ld_planes", c_int), ("w_layout", c_int),
-                ("w_scale", c_void_p), ("planes_fmt", c_int)]
+                ("w_scale", c_void_p), ("planes_fmt", c_int), ("colsum", c_void_p), ("aux_out", c_void_p)]
 
 
-ABI_VERSION = 7          # must equal ddpo_abi_version() of the loaded library (include/ddpo_hip.h)
+ABI_VERSION = 8          # must equal ddpo_abi_version() of the loaded library (include/ddpo_hip.h)
 
 _SIGS = {
     "ddpo_abi_version": (c_int, []),
@@ -615,10 +615,11 @@ def pack_weights_geglu(w, bias):
     return True
 
 
-def linear_geglu(x, w, out=None, planes_out=False):
+def linear_geglu(x, w, out=None, planes_out=False, pre_out=False):
     """(x @ w + b)[:, :F] * gelu_tanh((x @ w + b)[:, F:]) in one launch; w must have been registered by pack_weights_geglu.
     Returns None when it was not (caller falls back to linear + geglu).  planes_out: the result comes back as `Planes` only
-    (for a plane-fed second feed-forward GEMM)."""
+    (for a plane-fed second feed-forward GEMM).  pre_out: returns (result, pre) with pre = x @ w + b, (M, 2F) fp32 in w's column order —
+    the tensor the GEGLU backward needs (training forward; ddpo_gemm_desc.aux_out)."""
     ent = PACKED.get(w.data_ptr())
     if current_datapath() == "fp32" or ent is None or "geglu" not in ent or ent["geglu"]["stale"]:
         return None
@@ -647,6 +648,10 @@ def linear_geglu(x, w, out=None, planes_out=False):
     d.M, d.N, d.K = int(M), int(N), int(K)
     d.epilogue = 1
     d.w_layout = g["w_layout"]
+    pre = None
+    if pre_out:
+        pre = torch.empty(M, N, dtype=torch.float32, device=x.device)
+        d.aux_out = pre.data_ptr()
     npass = 3 if current_datapath() == "bf16x3" else 1
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -659,7 +664,8 @@ def linear_geglu(x, w, out=None, planes_out=False):
     if PROFILE is not None:
         e1.record()
         PROFILE.append((e0, e1, 2.0 * M * N * K, current_datapath(), 4.0 * (M * K + K * N + M * N // 2)))
-    return opl if planes_out else out
+    res = opl if planes_out else out
+    return (res, pre) if pre_out else res
 
 
 def _bf16_route(w, K, N, conv, dgrad):
@@ -888,16 +894,18 @@ def linear_dgrad(dy, w, residual=None):
     return gemm_conv(dy, w, M=M, N=K, K=N, w_trans=True, residual=residual)
 
 
-def linear_wgrad(x, dy, dw):
-    """dw (K,N) += x^T @ dy."""
+def linear_wgrad(x, dy, dw, dbias=None):
+    """dw (K,N) += x^T @ dy  [and dbias (N,) += column sums of dy]."""
     M, K = x.shape
     N = dy.shape[1]
-    return gemm_wgrad(x, dy, dw, M=M, N=N, K=K)
+    return gemm_wgrad(x, dy, dw, M=M, N=N, K=K, dbias=dbias)
 
 
-def gemm_wgrad(src, dy, dw, *, M, N, K, conv=None, ld_src=None, ld_dy=None, accumulate=True, splits=0, alpha=1.0):
+def gemm_wgrad(src, dy, dw, *, M, N, K, conv=None, ld_src=None, ld_dy=None, accumulate=True, splits=0, alpha=1.0, dbias=None):
     """dw += A^T dY.  `src` / `dy` may be `Planes` (the forward input as a plane-emitting norm wrote it, dY from a plane-emitting
-    output stage): the bf16x3 kernel then skips the fp32 -> bf16 split of that operand."""
+    output stage): the bf16x3 kernel then skips the fp32 -> bf16 split of that operand.
+    dbias: the layer's bias gradient (N,), += sum_m dY[m, :] — folded into the bf16x3 weight-gradient launch (ddpo_gemm_desc.colsum: the kernel
+    sums the dY values it stages anyway) when dY is fp32; a separate ddpo_colsum_accum launch otherwise."""
     fast = current_datapath() != "fp32" and accumulate and (conv is None or (conv["stride"] in (1, 2) and conv["upsample"] in (0, 1) and
                                                                       conv["pad"] == conv["ksize"] // 2)) and K >= 64 and N >= 32
     spl = src if isinstance(src, Planes) else None
@@ -929,6 +937,11 @@ def gemm_wgrad(src, dy, dw, *, M, N, K, conv=None, ld_src=None, ld_dy=None, accu
     if conv:
         for k in ("ksize", "stride", "pad", "upsample", "B", "H", "W", "Cin", "OH", "OW"):
             setattr(d, k, int(conv[k]))
+    fused_bias = dbias is not None and fast and dpl is None
+    if fused_bias:
+        d.colsum = dbias.data_ptr()
+    elif dbias is not None:
+        colsum_accum(dy if dpl is None else dpl.float(), dbias, ld_x=ld_dy)
     if fast and (spl is not None or dpl is not None):
         _check(load().ddpo_gemm_conv_wgrad_bf16x3_planes(byref(d), _p(spl.hi) if spl else None, _p(spl.lo) if spl else None,
                                                          _p(dpl.hi) if dpl else None, _p(dpl.lo) if dpl else None, _stream()),
@@ -949,10 +962,10 @@ def _conv_geom(B, H, W, Cin, ksize, stride, pad, upsample):
     return dict(ksize=ksize, stride=stride, pad=pad, upsample=int(bool(upsample)), B=B, H=H, W=W, Cin=Cin, OH=OH, OW=OW)
 
 
-def conv2d_wgrad(x, dy, dw, B, H, W, Cin, Cout, ksize, stride=1, pad=None, upsample=False, ld_src=None):
-    """dw (ksize,ksize,Cin,Cout) += im2col(x)^T @ dy, x: forward input (B*H*W, Cin), dy: (B*OH*OW, Cout)."""
+def conv2d_wgrad(x, dy, dw, B, H, W, Cin, Cout, ksize, stride=1, pad=None, upsample=False, ld_src=None, dbias=None):
+    """dw (ksize,ksize,Cin,Cout) += im2col(x)^T @ dy, x: forward input (B*H*W, Cin), dy: (B*OH*OW, Cout)  [dbias (Cout,) += column sums of dy]."""
     conv = _conv_geom(B, H, W, Cin, ksize, stride, pad, upsample)
-    return gemm_wgrad(x, dy, dw, M=B * conv["OH"] * conv["OW"], N=Cout, K=ksize * ksize * Cin, conv=conv, ld_src=ld_src)
+    return gemm_wgrad(x, dy, dw, M=B * conv["OH"] * conv["OW"], N=Cout, K=ksize * ksize * Cin, conv=conv, ld_src=ld_src, dbias=dbias)
 
 
 def conv2d_dgrad(dy, w, B, H, W, Cin, Cout, ksize, stride=1, residual=None):

@@ -239,12 +239,10 @@ def resnet_backward(P, G, r, d_out, tctx):
     name, x, cout = r["name"], r["x"], r["cout"]
     B, H, W, HW = x.B, x.H, x.W, x.HW
     # out = conv2(h2) + res
-    L.conv2d_wgrad(r["h2"], d_out, G[name + ".conv2.kernel"], B, H, W, cout, cout, 3)
-    L.colsum_accum(d_out, G[name + ".conv2.bias"])
+    L.conv2d_wgrad(r["h2"], d_out, G[name + ".conv2.kernel"], B, H, W, cout, cout, 3, dbias=G[name + ".conv2.bias"])
     d_h2 = L.conv2d_dgrad(d_out, P[name + ".conv2.kernel"], B, H, W, cout, cout, 3)
     if r["shortcut"]:
-        L.conv2d_wgrad(x.t, d_out, G[name + ".conv_shortcut.kernel"], B, H, W, x.C, cout, 1)
-        L.colsum_accum(d_out, G[name + ".conv_shortcut.bias"])
+        L.conv2d_wgrad(x.t, d_out, G[name + ".conv_shortcut.kernel"], B, H, W, x.C, cout, 1, dbias=G[name + ".conv_shortcut.bias"])
         d_res = L.conv2d_dgrad(d_out, P[name + ".conv_shortcut.kernel"], B, H, W, x.C, cout, 1)
     else:
         d_res = d_out
@@ -255,8 +253,7 @@ def resnet_backward(P, G, r, d_out, tctx):
         d_tproj = torch.zeros(B, cout, dtype=torch.float32, device=d_c1.device)
         L.colsum_accum(d_c1, d_tproj, rows_per_seg=HW)                      # d(time_emb_proj output)[b] = sum over pixels of b
         L.colsum_accum(d_tproj, G[name + ".conv1.bias"])                    # conv1 bias sees the same sums
-        L.linear_wgrad(tctx["temb_act"], d_tproj, G[name + ".time_emb_proj.kernel"])
-        L.colsum_accum(d_tproj, G[name + ".time_emb_proj.bias"])
+        L.linear_wgrad(tctx["temb_act"], d_tproj, G[name + ".time_emb_proj.kernel"], dbias=G[name + ".time_emb_proj.bias"])
         tctx["d_temb_act"] = L.linear_dgrad(d_tproj, P[name + ".time_emb_proj.kernel"], residual=tctx["d_temb_act"])
     else:
         L.colsum_accum(d_c1, G[name + ".conv1.bias"])
@@ -347,7 +344,11 @@ class UNet2DCondition:
         l3 = ln("norm3", h2, pl_3)
         f = None
         # sampling: GEGLU fused into the GEMM epilogue, written as planes when FF2 can take them
-        gg = L.linear_geglu(l3, P[tb + ".ff.net_0.proj.kernel"], planes_out=pl_ff2) if tape is None else None
+        if tape is None:
+            gg = L.linear_geglu(l3, P[tb + ".ff.net_0.proj.kernel"], planes_out=pl_ff2)
+        else:                                      # training: the same fused launch also stores the pre-activation the GEGLU backward reads
+            r_ = L.linear_geglu(l3, P[tb + ".ff.net_0.proj.kernel"], pre_out=True)
+            gg, f = r_ if r_ is not None else (None, None)
         if gg is None:
             f = L.linear(l3, P[tb + ".ff.net_0.proj.kernel"], P[tb + ".ff.net_0.proj.bias"])
             gg = L.geglu(f)
@@ -370,41 +371,35 @@ class UNet2DCondition:
         tb = name + ".transformer_blocks_0"
         gw = lambda n: G[n + ".kernel"]
         # out = proj_out(h3) + x
-        L.colsum_accum(d_out, G[name + ".proj_out.bias"])
         if cfg.use_linear_projection:
-            L.linear_wgrad(r["h3"], d_out, gw(name + ".proj_out"))
+            L.linear_wgrad(r["h3"], d_out, gw(name + ".proj_out"), dbias=G[name + ".proj_out.bias"])
             d_h3 = L.linear_dgrad(d_out, P[name + ".proj_out.kernel"])
         else:
-            L.conv2d_wgrad(r["h3"], d_out, gw(name + ".proj_out"), B, H, W, C, C, 1)
+            L.conv2d_wgrad(r["h3"], d_out, gw(name + ".proj_out"), B, H, W, C, C, 1, dbias=G[name + ".proj_out.bias"])
             d_h3 = L.conv2d_dgrad(d_out, P[name + ".proj_out.kernel"], B, H, W, C, C, 1)
         # h3 = ff2(geglu(ff1(LN3(h2)))) + h2
-        L.linear_wgrad(r["gg"], d_h3, gw(tb + ".ff.net_2"))
-        L.colsum_accum(d_h3, G[tb + ".ff.net_2.bias"])
+        L.linear_wgrad(r["gg"], d_h3, gw(tb + ".ff.net_2"), dbias=G[tb + ".ff.net_2.bias"])
         d_gg = L.linear_dgrad(d_h3, P[tb + ".ff.net_2.kernel"])
         d_f = L.geglu_bwd(r["f"], d_gg)
-        L.linear_wgrad(r["l3"], d_f, gw(tb + ".ff.net_0.proj"))
-        L.colsum_accum(d_f, G[tb + ".ff.net_0.proj.bias"])
+        L.linear_wgrad(r["l3"], d_f, gw(tb + ".ff.net_0.proj"), dbias=G[tb + ".ff.net_0.proj.bias"])
         d_l3 = L.linear_dgrad(d_f, P[tb + ".ff.net_0.proj.kernel"])
         d_h2 = L.layernorm_bwd(r["h2"], d_l3, P[tb + ".norm3.scale"], G[tb + ".norm3.scale"], G[tb + ".norm3.bias"], 1e-5, dx_add=d_h3)
         # h2 = to_out(attn2(LN2(h1), ctx)) + h1
-        L.linear_wgrad(r["a2r"]["o"], d_h2, gw(tb + ".attn2.to_out_0"))
-        L.colsum_accum(d_h2, G[tb + ".attn2.to_out_0.bias"])
+        L.linear_wgrad(r["a2r"]["o"], d_h2, gw(tb + ".attn2.to_out_0"), dbias=G[tb + ".attn2.to_out_0.bias"])
         d_a2 = L.linear_dgrad(d_h2, P[tb + ".attn2.to_out_0.kernel"])
         d_l2 = self._attention_backward(tb + ".attn2", r["a2r"], r["l2"], r["ctx"], d_a2, B, N, C, heads, False)
         d_h1 = L.layernorm_bwd(r["h1"], d_l2, P[tb + ".norm2.scale"], G[tb + ".norm2.scale"], G[tb + ".norm2.bias"], 1e-5, dx_add=d_h2)
         # h1 = to_out(attn1(LN1(h0))) + h0
-        L.linear_wgrad(r["a1r"]["o"], d_h1, gw(tb + ".attn1.to_out_0"))
-        L.colsum_accum(d_h1, G[tb + ".attn1.to_out_0.bias"])
+        L.linear_wgrad(r["a1r"]["o"], d_h1, gw(tb + ".attn1.to_out_0"), dbias=G[tb + ".attn1.to_out_0.bias"])
         d_a1 = L.linear_dgrad(d_h1, P[tb + ".attn1.to_out_0.kernel"])
         d_l1 = self._attention_backward(tb + ".attn1", r["a1r"], r["l1"], r["l1"], d_a1, B, N, C, heads, True)
         d_h0 = L.layernorm_bwd(r["h0"], d_l1, P[tb + ".norm1.scale"], G[tb + ".norm1.scale"], G[tb + ".norm1.bias"], 1e-5, dx_add=d_h1)
         # h0 = proj_in(GN(x))
-        L.colsum_accum(d_h0, G[name + ".proj_in.bias"])
         if cfg.use_linear_projection:
-            L.linear_wgrad(r["hn"], d_h0, gw(name + ".proj_in"))
+            L.linear_wgrad(r["hn"], d_h0, gw(name + ".proj_in"), dbias=G[name + ".proj_in.bias"])
             d_hn = L.linear_dgrad(d_h0, P[name + ".proj_in.kernel"])
         else:
-            L.conv2d_wgrad(r["hn"], d_h0, gw(name + ".proj_in"), B, H, W, C, C, 1)
+            L.conv2d_wgrad(r["hn"], d_h0, gw(name + ".proj_in"), B, H, W, C, C, 1, dbias=G[name + ".proj_in.bias"])
             d_hn = L.conv2d_dgrad(d_h0, P[name + ".proj_in.kernel"], B, H, W, C, C, 1)
         return L.groupnorm_bwd(x.t, d_hn, r["st"], P[name + ".norm.scale"], B, N, cfg.norm_groups, False,
                                G[name + ".norm.scale"], G[name + ".norm.bias"], dx_add=d_out)
@@ -686,8 +681,7 @@ class UNet2DCondition:
         x = tail["x"]
         B, H, W = x.B, x.H, x.W
         d = L.nchw_to_nhwc(d_out.contiguous())                                 # (B*H*W, C_out)
-        L.conv2d_wgrad(tail["hn"], d, G["conv_out.kernel"], B, H, W, x.C, cfg.out_channels, 3)
-        L.colsum_accum(d, G["conv_out.bias"])
+        L.conv2d_wgrad(tail["hn"], d, G["conv_out.kernel"], B, H, W, x.C, cfg.out_channels, 3, dbias=G["conv_out.bias"])
         d = L.conv2d_dgrad(d, P["conv_out.kernel"], B, H, W, x.C, cfg.out_channels, 3)
         d = L.groupnorm_bwd(x.t, d, tail["st"], P["conv_norm_out.scale"], B, x.HW, cfg.norm_groups, True,
                             G["conv_norm_out.scale"], G["conv_norm_out.bias"])
@@ -711,15 +705,13 @@ class UNet2DCondition:
                 d = d_h
             elif kind == "up":
                 xx, name = r["x"], r["name"]
-                L.conv2d_wgrad(xx.t, d, G[name + ".kernel"], xx.B, xx.H, xx.W, xx.C, xx.C, 3, upsample=True)
-                L.colsum_accum(d, G[name + ".bias"])
+                L.conv2d_wgrad(xx.t, d, G[name + ".kernel"], xx.B, xx.H, xx.W, xx.C, xx.C, 3, upsample=True, dbias=G[name + ".bias"])
                 d_up = L.conv2d_dgrad(d, P[name + ".kernel"], xx.B, 2 * xx.H, 2 * xx.W, xx.C, xx.C, 3)
                 d = L.sumpool2x2(d_up, xx.B, xx.H, xx.W, xx.C)
                 done(name)
             elif kind == "down":
                 xx, name = r["x"], r["name"]
-                L.conv2d_wgrad(xx.t, d, G[name + ".kernel"], xx.B, xx.H, xx.W, xx.C, xx.C, 3, stride=2, pad=1)
-                L.colsum_accum(d, G[name + ".bias"])
+                L.conv2d_wgrad(xx.t, d, G[name + ".kernel"], xx.B, xx.H, xx.W, xx.C, xx.C, 3, stride=2, pad=1, dbias=G[name + ".bias"])
                 d = L.conv2d_dgrad(d, P[name + ".kernel"], xx.B, xx.H, xx.W, xx.C, xx.C, 3, stride=2)
                 done(name)
             elif kind == "skip_push":
@@ -731,13 +723,10 @@ class UNet2DCondition:
         d = L.add(d, skip_grads.pop())
         assert not skip_grads
         xin = head["x"]
-        L.conv2d_wgrad(xin.t, d, G["conv_in.kernel"], xin.B, xin.H, xin.W, xin.C, cfg.block_out_channels[0], 3)
-        L.colsum_accum(d, G["conv_in.bias"])
+        L.conv2d_wgrad(xin.t, d, G["conv_in.kernel"], xin.B, xin.H, xin.W, xin.C, cfg.block_out_channels[0], 3, dbias=G["conv_in.bias"])
         # time embedding MLP
         d_temb = L.silu_bwd(head["temb"], tctx["d_temb_act"])
-        L.linear_wgrad(head["s1"], d_temb, G["time_embedding.linear_2.kernel"])
-        L.colsum_accum(d_temb, G["time_embedding.linear_2.bias"])
+        L.linear_wgrad(head["s1"], d_temb, G["time_embedding.linear_2.kernel"], dbias=G["time_embedding.linear_2.bias"])
         d_s1 = L.linear_dgrad(d_temb, P["time_embedding.linear_2.kernel"])
         d_t1 = L.silu_bwd(head["t1"], d_s1)
-        L.linear_wgrad(head["emb"], d_t1, G["time_embedding.linear_1.kernel"])
-        L.colsum_accum(d_t1, G["time_embedding.linear_1.bias"])
+        L.linear_wgrad(head["emb"], d_t1, G["time_embedding.linear_1.kernel"], dbias=G["time_embedding.linear_1.bias"])

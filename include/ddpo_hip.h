@@ -193,6 +193,14 @@ typedef struct {
    *      [h8 c0-15 | l8 c0-15 | h8 c16-31 | l8 c16-31], h8 = e5m2(h), l8 = e5m2(l * 2^11) (needs the emitted column count % 32 == 0).  Same geometry and ld_planes convention as the bf16 planes. */
   const uint8_t* w_scale;
   int planes_fmt;
+  /* weight gradients on the bf16x3 kernels (ABI v8; NULL elsewhere): when set and dY (`w`) is fp32, the kernel also accumulates the column sums of
+   * dY — the BIAS gradient of the layer, sum_m dY[m][n] — into colsum[n] (fp32 atomic adds, like dW) from the registers that stage dY anyway,
+   * instead of a separate ddpo_colsum_accum launch re-reading dY.  Ignored (returns DDPO_EINVAL) with a plane dY operand. */
+  float* colsum;
+  /* epilogue == 1 (GEGLU) only (ABI v8; NULL elsewhere): also store the PRE-activation x W + b, (M, N) fp32 with row stride N in the ORIGINAL
+   * column order [a (N/2) | gate (N/2)] (the interleaving of the packed weights undone) — what the GEGLU backward needs, so the training forward
+   * can use the fused launch too. */
+  float* aux_out;
 } ddpo_gemm_desc;
 int ddpo_gemm_conv_fwd(const ddpo_gemm_desc* d, void* stream);
 /* Data gradients reuse ddpo_gemm_conv_fwd: src = dY, w = forward kernel with w_trans=1, w_dgrad=1, and for the

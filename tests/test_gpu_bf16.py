@@ -100,6 +100,11 @@ def test_linear_geglu_fused_epilogue(datapath, mode, M, K, F):
     f64 = x.cpu().double() @ w.cpu().double() + b.cpu().double()
     ref = f64[:, :F] * TF.gelu(f64[:, F:], approximate="tanh")
     assert _rel(fused, ref) < TOL[mode]
+    # training forward: the same launch also stores the pre-activation (ddpo_gemm_desc.aux_out) in w's column order
+    fused2, pre = L.linear_geglu(x, w, pre_out=True)
+    assert torch.equal(fused2, fused) and pre.shape == (M, 2 * F)
+    assert torch.equal(L.geglu(pre), fused)                  # exactly the values the output stage gated
+    assert _rel(pre, f64) < TOL[mode]
     L.pack_weights(w)                                        # weights "changed": fused planes are stale until re-packed
     assert L.linear_geglu(x, w) is None
 
@@ -170,7 +175,8 @@ def test_attention_bf16x3(datapath, B, heads, Nq, Nk, d):
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,ks", [(2, 8, 8, 64, 64, 3), (2, 8, 8, 96, 128, 3), (2, 8, 8, 64, 128, 1), (1, 32, 32, 320, 320, 3),
-                                               (3, 6, 10, 64, 64, 3), (2, 16, 16, 640, 320, 3)])
+                                               (3, 6, 10, 64, 64, 3), (2, 16, 16, 640, 320, 3),
+                                               (4, 64, 64, 320, 320, 3)])          # last: 16384 pixels, N = 320, K = 2880 -> the wide 128x320 tile
 def test_conv_wgrad_bf16x3(datapath, B, H, W, Cin, Cout, ks):
     L.DATAPATH = "bf16x3"
     g = torch.Generator().manual_seed(H + Cin + Cout + ks)
@@ -180,10 +186,13 @@ def test_conv_wgrad_bf16x3(datapath, B, H, W, Cin, Cout, ks):
     TF.conv2d(x.permute(0, 3, 1, 2).double(), wd, None, padding=ks // 2).backward(dy.permute(0, 3, 1, 2).double())
     ref = wd.grad.permute(2, 3, 1, 0)
     dw = torch.zeros(ks, ks, Cin, Cout, device=DEV)
-    L.conv2d_wgrad(x.reshape(-1, Cin).to(DEV), dy.reshape(-1, Cout).to(DEV), dw, B, H, W, Cin, Cout, ks)
+    db = torch.zeros(Cout, device=DEV)                     # the bias gradient rides in the same launch (ddpo_gemm_desc.colsum)
+    L.conv2d_wgrad(x.reshape(-1, Cin).to(DEV), dy.reshape(-1, Cout).to(DEV), dw, B, H, W, Cin, Cout, ks, dbias=db)
     assert _rel(dw, ref) < 5e-5
-    L.conv2d_wgrad(x.reshape(-1, Cin).to(DEV), dy.reshape(-1, Cout).to(DEV), dw, B, H, W, Cin, Cout, ks)
+    assert _rel(db, dy.double().sum((0, 1, 2))) < 2e-6
+    L.conv2d_wgrad(x.reshape(-1, Cin).to(DEV), dy.reshape(-1, Cout).to(DEV), dw, B, H, W, Cin, Cout, ks, dbias=db)
     assert _rel(dw, 2 * ref) < 5e-5
+    assert _rel(db, 2 * dy.double().sum((0, 1, 2))) < 2e-6
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,stride,ups", [(2, 16, 16, 64, 64, 2, False), (3, 12, 20, 96, 128, 2, False), (2, 8, 8, 64, 96, 1, True),
@@ -204,8 +213,10 @@ def test_conv_wgrad_bf16x3_strided_and_upsampled(datapath, B, H, W, Cin, Cout, s
     y.backward(dy.permute(0, 3, 1, 2).double())
     ref = wd.grad.permute(2, 3, 1, 0)
     dw = torch.zeros(3, 3, Cin, Cout, device=DEV)
-    L.conv2d_wgrad(x.reshape(-1, Cin).to(DEV), dy.reshape(-1, Cout).to(DEV), dw, B, H, W, Cin, Cout, 3, stride=stride, upsample=ups)
+    db = torch.zeros(Cout, device=DEV)
+    L.conv2d_wgrad(x.reshape(-1, Cin).to(DEV), dy.reshape(-1, Cout).to(DEV), dw, B, H, W, Cin, Cout, 3, stride=stride, upsample=ups, dbias=db)
     assert _rel(dw, ref) < 5e-5
+    assert _rel(db, dy.double().sum((0, 1, 2))) < 2e-6
 
 
 @pytest.mark.parametrize("M,K,N", [(300, 320, 640), (4096, 64, 128), (2048, 640, 5120), (154, 768, 320), (4, 1280, 320)])
@@ -214,8 +225,10 @@ def test_linear_wgrad_bf16x3(datapath, M, K, N):
     g = torch.Generator().manual_seed(M + K)
     x, dy = torch.randn(M, K, generator=g), torch.randn(M, N, generator=g)
     dw = torch.zeros(K, N, device=DEV)
-    L.linear_wgrad(x.to(DEV), dy.to(DEV), dw)
+    db = torch.zeros(N, device=DEV)
+    L.linear_wgrad(x.to(DEV), dy.to(DEV), dw, dbias=db)
     assert _rel(dw, x.double().t() @ dy.double()) < 5e-5
+    assert _rel(db, dy.double().sum(0)) < 2e-6
 
 
 @pytest.mark.parametrize("B,heads,Nq,Nk,d", [(2, 8, 64, 64, 8), (1, 8, 200, 77, 16), (2, 8, 256, 256, 40), (2, 8, 1024, 77, 40),
