@@ -52,8 +52,9 @@ def parse(argv=None):
     ap.add_argument("--resolution", type=int, default=None, help="default: 512 (sd15), 768 (sd21), 64 (tiny)")
     ap.add_argument("--n-inference-steps", type=int, default=50)
     ap.add_argument("--sample-batch-size", type=int, default=8)
-    ap.add_argument("--datapath", default=os.environ.get("DDPO_DATAPATH", "bf16x3"), choices=["fp32", "bf16x3", "bf16"],
-                    help="contraction datapath: exact-fp32 MFMA, bf16-split MFMA x3 (fp32-accurate to ~1e-5, default), single-pass bf16")
+    ap.add_argument("--datapath", default=os.environ.get("DDPO_DATAPATH", "bf16x3"), choices=["fp32", "bf16x3", "bf16", "f16mx"],
+                    help="contraction datapath: exact-fp32 MFMA, bf16-split MFMA x3 (fp32-accurate to ~1e-5, default), single-pass bf16, "
+                         "f16mx (opt-in: f16 MFMA + one MX-scaled 8-bit MFMA for the cross terms on every plane-eligible forward layer, ~7e-5)")
     ap.add_argument("--mode", default="sample", choices=["sample", "train", "epoch", "comm"],
                     help="sample (headline): images/sec of the sampling hot path; train: PPO sample-timesteps/sec of train_step; "
                          "epoch: one sample batch + its PPO micro-steps + optimizer updates (gradient all-reduce included); "
@@ -564,7 +565,7 @@ def main(argv=None):
         flops = sum(r[2] for r in recs)
         ms = sum(r[0].elapsed_time(r[1]) for r in recs)
         achieved = flops / (ms * 1e-3) / 1e12
-        passes = {"fp32": 1, "bf16": 1, "bf16x3": 3}[dom]
+        passes = {"fp32": 1, "bf16": 1, "bf16x3": 3, "f16mx": 2}[dom]          # f16mx: 2 f16 + 1 fp8 (double rate) per block and k-tile = 2 pass-equivalents
         peak = FP32_MFMA_PEAK_TFLOPS if dom == "fp32" else BF16_MFMA_PEAK_TFLOPS
         kname = "gemm_conv_kernel (v_mfma_f32_32x32x2_f32)" if dom == "fp32" else \
             f"gemm_conv_bf16_buf_kernel<128x320 | 128x128 | 128x64, NPASS={passes}> (v_mfma_f32_32x32x16_bf16)"
@@ -599,7 +600,8 @@ def main(argv=None):
     out = {
         "metric": f"sampled images/sec ({args.resolution}^2, {args.n_inference_steps} DDIM steps)", "value": value, "unit": "images/sec", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": {"fp32": "f32", "bf16x3": "f32 (bf16x3-split MFMA)", "bf16": "bf16 products, f32 accumulate"}[args.datapath],
+        "scaling": "weak", "vs_baseline": None, "dtype": {"fp32": "f32", "bf16x3": "f32 (bf16x3-split MFMA)", "bf16": "bf16 products, f32 accumulate",
+                                                                 "f16mx": "f32 (f16 MFMA + MX-fp8 cross terms on plane-eligible forward layers, bf16x3 elsewhere)"}[args.datapath],
         "data": "synthetic",
         "config": {"workload": f"BASELINE configs[{1 if args.model == 'sd15' else 4}]: {'compressed-animals' if args.model == 'sd15' else 'neg_jpeg'} geometry, "
                                f"{args.model} U-Net+VAE (random init), "
@@ -608,7 +610,9 @@ def main(argv=None):
                    "datapath": {"fp32": "exact-fp32 MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4_f32)",
                                 "bf16x3": "conv/GEMM: bf16x3-split MFMA (a_lo*b_hi + a_hi*b_lo + a_hi*b_hi, fp32 accumulate, ~1e-5 rel; "
                                           "= XLA HIGH, the reference ran TPU DEFAULT = 1 pass); attention (d in 40/64/80): same split; d=160 attention and norms: exact fp32",
-                                "bf16": "conv/GEMM: single-pass bf16 MFMA, fp32 accumulate (= XLA TPU DEFAULT precision)"}[args.datapath],
+                                "bf16": "conv/GEMM: single-pass bf16 MFMA, fp32 accumulate (= XLA TPU DEFAULT precision)",
+                                "f16mx": "plane-eligible forward conv/GEMM: f16 MFMA + ONE MX-scaled 8-bit MFMA carrying both cross terms (a_h*b_h + a_h8*b_l8 + a_l8*b_h8, "
+                                         "~7e-5 rel on a U-Net forward); every other contraction as under bf16x3 (opt-in datapath, DESIGN.md section 6a)"}[args.datapath],
                    "parallelism": f"dp{world}",
                    "global_batch": world * B},
         "end_to_end_tflops": None if tflop_per_image is None else value * tflop_per_image,

@@ -130,6 +130,10 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__
     o.x = v.x * k0.x + k0.y; o.y = v.y * k0.z + k0.w; o.z = v.z * k1.x + k1.y; o.w = v.w * k1.z + k1.w;
     if (SILU) { o.x = silu_f(o.x); o.y = silu_f(o.y); o.z = silu_f(o.z); o.w = silu_f(o.w); }
     if (PL) {
+      if (pair == 2) {                    // f16mx planes (common.h): y_hi = f16 plane, y_lo = interleaved e5m2 [h8 | l8] chunks
+        mx_store4(y_hi, y_lo, row, c, ldy, (int64_t)B * HW, o);
+        continue;
+      }
       uint2 h, l;
       split4(o, h, l);
       if (pair) {
@@ -167,6 +171,9 @@ static int groupnorm_fwd_impl(const float* x, int ldx, float* y, uint16_t* y_hi,
                               const float* beta, int B, int HW, int C, int G, float eps, int fuse_silu, void* ws, float* stats,
                               void* stream) {
   const bool planes = y == nullptr;
+  const bool mx = (fuse_silu & 2) != 0;               // planes entry only: bit 1 of the flag selects the f16mx plane format (ABI v9)
+  fuse_silu &= 1;
+  if (mx && (!planes || (C & 31) || (ldy & 31))) return DDPO_EINVAL;
   if (!x || !gamma || !beta || !ws || !stats || B <= 0 || HW <= 0 || C <= 0 || G <= 0 || G > GN_MAXG) return DDPO_EINVAL;
   if (planes ? (!y_hi || !y_lo) : false) return DDPO_EINVAL;
   if ((C & 3) || (C % G) || (ldx & 3) || (ldy & 3) || C > GN_MAXC || B > 65535) return DDPO_EINVAL;
@@ -190,8 +197,8 @@ static int groupnorm_fwd_impl(const float* x, int ldx, float* y, uint16_t* y_hi,
   uint16_t* const no = nullptr;
   if (planes) {
     // lane-paired 16-byte stores need 8-channel granularity and 16-byte aligned plane rows
-    const int pair = ((C & 7) == 0 && (ldy & 7) == 0 &&
-                      ((reinterpret_cast<uintptr_t>(y_hi) | reinterpret_cast<uintptr_t>(y_lo)) & 15) == 0) ? 1 : 0;
+    const int pair = mx ? 2 : ((C & 7) == 0 && (ldy & 7) == 0 &&
+                                ((reinterpret_cast<uintptr_t>(y_hi) | reinterpret_cast<uintptr_t>(y_lo)) & 15) == 0) ? 1 : 0;
     if (fuse_silu)
       hipLaunchKernelGGL((gn_apply_kernel<true, true>), dim3((int)blocks), dim3(256), 0, st, x, ldx, y, ldy, ab, B, HW, C, y_hi, y_lo, pair);
     else
@@ -265,7 +272,9 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
       o.y = (v[j].y - mean) * rstd * g.y + bt.y;
       o.z = (v[j].z - mean) * rstd * g.z + bt.z;
       o.w = (v[j].w - mean) * rstd * g.w + bt.w;
-      if (PL) {             // bf16 hi / lo planes (rows, C) instead of the fp32 tensor (see gn_apply_kernel)
+      if (PL && pair == 2) {             // f16mx planes
+        mx_store4(y_hi, y_lo, row, c4 << 2, ldy, rows, o);
+      } else if (PL) {             // bf16 hi / lo planes (rows, C) instead of the fp32 tensor (see gn_apply_kernel)
         uint2 h, l;
         split4(o, h, l);
         if (pair) {           // lane-paired 16-byte stores (see gn_apply_kernel); C % 8 == 0 keeps both lanes of a pair inside the row
@@ -296,10 +305,12 @@ extern "C" int ddpo_layernorm_fwd(const float* x, float* y, const float* gamma, 
 extern "C" int ddpo_layernorm_fwd_planes(const float* x, uint16_t* y_hi, uint16_t* y_lo, const float* gamma, const float* beta,
                                          int rows, int C, float eps, int kblocked, void* stream) {
   if (!x || !y_hi || !y_lo || !gamma || !beta || rows <= 0 || C <= 0 || (C & 3) || C > 256 * LN_MAXV) return DDPO_EINVAL;
-  if (kblocked && (C & 31)) return DDPO_EINVAL;
+  const bool mx = (kblocked & 2) != 0;                // bit 1 of the layout flag: f16mx plane format (ABI v9); bit 0: k-blocked storage
+  kblocked &= 1;
+  if ((kblocked || mx) && (C & 31)) return DDPO_EINVAL;
   if ((reinterpret_cast<uintptr_t>(y_hi) | reinterpret_cast<uintptr_t>(y_lo)) & 7) return DDPO_EINVAL;
   float* const nof = nullptr;
-  const int pair = ((C & 7) == 0 && ((reinterpret_cast<uintptr_t>(y_hi) | reinterpret_cast<uintptr_t>(y_lo)) & 15) == 0) ? 1 : 0;
+  const int pair = mx ? 2 : ((C & 7) == 0 && ((reinterpret_cast<uintptr_t>(y_hi) | reinterpret_cast<uintptr_t>(y_lo)) & 15) == 0) ? 1 : 0;
   hipLaunchKernelGGL(layernorm_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, as_stream(stream), x, nof, gamma, beta, rows, C, eps, y_hi,
                      y_lo, pair, kblocked ? 0 : C);
   DDPO_LAUNCH_CHECK();

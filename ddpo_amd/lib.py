@@ -39,7 +39,7 @@ class GemmDesc(ctypes.Structure):
                 ("w_scale", c_void_p), ("planes_fmt", c_int), ("colsum", c_void_p), ("aux_out", c_void_p)]
 
 
-ABI_VERSION = 8          # must equal ddpo_abi_version() of the loaded library (include/ddpo_hip.h)
+ABI_VERSION = 9          # must equal ddpo_abi_version() of the loaded library (include/ddpo_hip.h)
 
 _SIGS = {
     "ddpo_abi_version": (c_int, []),
@@ -126,6 +126,12 @@ _lib = None
 DATAPATH = os.environ.get("DDPO_DATAPATH", "fp32")
 
 
+DATAPATHS = ("fp32", "bf16x3", "bf16", "f16mx")
+# "f16mx" (round 3, opt-in): every PLANE-ELIGIBLE forward contraction (registered weights, 32-channel k-tiles, 31-bit offsets — a function of
+# the layer, never of the batch) runs on the f16 + MX-fp8 cross-term kernel (ddpo_gemm_conv_fwd_f16mx_planes); its activation planes come from
+# the producing kernel (GroupNorm / LayerNorm / GEMM output stages) or, when the producer wrote fp32 (training forward: the weight gradients read
+# the fp32 tensor), from ddpo_split_planes_f16mx on the way in — the same bits either way, so the sampler and the training forward of a layer
+# always take the same arithmetic.  Everything else (non-eligible layers, data / weight gradients, attention) runs as under bf16x3.
 _TLS = threading.local()
 
 
@@ -139,7 +145,7 @@ class datapath:
     and stream next to the sampler), restored on exit."""
 
     def __init__(self, name):
-        if name not in ("fp32", "bf16x3", "bf16"):
+        if name not in DATAPATHS:
             raise ValueError(f"unknown datapath {name!r}")
         self.name = name
 
@@ -158,7 +164,22 @@ def fp32_class_datapath():
     /root/reference/ddpo/utils/serialization.py:343-350 casts text_encoder / vae / unet only): the current one, except that the
     single-pass `bf16` selected by `load_unet(dtype=bfloat16)` is replaced by `bf16x3`."""
     cur = current_datapath()
-    return datapath("bf16x3" if cur == "bf16" else cur)
+    return datapath("bf16x3" if cur in ("bf16", "f16mx") else cur)
+
+
+def _x3():
+    """Three-pass class (fp32-equivalent) MFMA datapaths: bf16x3, and f16mx whose non-plane-fed layers and gradients ARE bf16x3."""
+    return current_datapath() in ("bf16x3", "f16mx")
+
+
+def _mx():
+    return current_datapath() == "f16mx"
+
+
+def train_planes():
+    """Norm outputs as planes on the TRAINING forward (consumed by the layer's GEMM and its weight gradient): bf16x3 only — under f16mx the
+    weight gradients read the fp32 tensor and the forward GEMM splits it on the way in."""
+    return TRAIN_PLANES and not _mx()
 
 
 SPLITK_WS_BYTES = 64 << 20       # scratch for the deterministic split-K of under-filled launches
@@ -193,10 +214,14 @@ A_KBLOCKED = os.environ.get("DDPO_A_KBLOCKED", "0") == "1"
 class Planes:
     """An activation (rows, C) stored as bf16 hi / lo planes (two int16 buffers): x ~= hi + lo.  Storage is row-major (rows, C), or —
     when A_KBLOCKED and C % 32 == 0 — k-blocked (C / 32, rows, 32); `ld` is the plane row stride handed to the C ABI (0 = k-blocked)."""
-    __slots__ = ("hi", "lo", "rows", "C", "kblocked")
+    __slots__ = ("hi", "lo", "rows", "C", "kblocked", "fmt")
 
-    def __init__(self, rows, C, device):
+    def __init__(self, rows, C, device, fmt=None):
         self.rows, self.C = int(rows), int(C)
+        # fmt 0: bf16 hi / lo; 1: f16mx (hi = the f16 plane, lo = the interleaved e5m2 chunks; same geometry, same byte counts)
+        self.fmt = int((1 if _mx() else 0) if fmt is None else fmt)
+        if self.fmt == 1 and C % 32:
+            raise DdpoHipError("f16mx planes need whole 32-channel blocks")
         self.kblocked = bool(A_KBLOCKED and C % 32 == 0)
         shp = (C // 32, rows, 32) if self.kblocked else (rows, C)
         self.hi = torch.empty(shp, dtype=torch.int16, device=device)
@@ -223,7 +248,10 @@ class Planes:
         return t.permute(1, 0, 2).reshape(self.rows, self.C) if self.kblocked else t
 
     def float(self):
-        """hi + lo as fp32 (rows, C) (tests / debugging)."""
+        """hi + lo as fp32 (rows, C) (tests / debugging).  f16mx planes: h + l8 / 2^11 (the exact value up to the e5m2 rounding of l)."""
+        if self.fmt == 1:
+            b = self.plane("lo").contiguous().view(torch.float8_e5m2).view(self.rows, self.C // 32, 2, 2, 16)
+            return self.plane("hi").contiguous().view(torch.float16).float() + b[:, :, :, 1].reshape(self.rows, self.C).float() / 2048.0
         f = lambda t: (t.to(torch.int32) << 16).view(torch.float32)
         return f(self.plane("hi")) + f(self.plane("lo"))
 
@@ -233,10 +261,10 @@ def planes_ok(w, cin, rows):
     of a convolution's input, M of a dense layer) can take a plane-fed activation: bf16x3 datapath, weight planes registered
     (pack_weights), 32-channel k-tiles that never straddle a tap, and 31-bit byte offsets (the conditions of the
     buffer-addressed kernel, buf_path_ok() in csrc/gemm_bf16.hip — the VAE's 512x512 levels at batch 8 exceed them)."""
-    if not (PLANES and current_datapath() == "bf16x3" and cin % 32 == 0):
+    if not (PLANES and _x3() and cin % 32 == 0):
         return False
     ent = PACKED.get(w.data_ptr())
-    if ent is None:
+    if ent is None or (_mx() and "mx" not in ent):
         return False
     lim = 0x7FFFFFFF
     return rows * cin * 4 < lim and ent["N"] * ent["fwd"][2] * 2 < lim
@@ -249,7 +277,7 @@ def planes_pay(w, cin, rows):
     LDS-DMA loop's fill latency, so their norms keep writing fp32.  DDPO_PLANES_ALL=1 ignores the rule (tests of the kernels)."""
     if not planes_ok(w, cin, rows):
         return False
-    if PLANES_ALL:
+    if PLANES_ALL or _mx():              # f16mx: the routing must not depend on the batch — every eligible layer is plane-fed
         return True
     return PACKED[w.data_ptr()]["K"] >= 2560 or rows >= 32768
 
@@ -258,7 +286,7 @@ def planes_out_ok(w, cin, rows, N):
     """True when the GEMM / conv with weight `w` (reduction channels per tap `cin`, `rows` source rows, N output columns) runs on a
     buffer-addressed bf16x3 kernel, i.e. can emit its result as planes (ddpo_gemm_desc.out_hi): the conditions of planes_ok()
     except that the ACTIVATION may be fp32 (then only K % 32 and the 31-bit offsets matter), plus N % 4 == 0."""
-    if not (PLANES and PLANES_OUT and current_datapath() == "bf16x3" and cin % 32 == 0 and N % 4 == 0):
+    if not (PLANES and PLANES_OUT and _x3() and cin % 32 == 0 and N % 4 == 0 and (not _mx() or N % 32 == 0)):
         return False
     ent = PACKED.get(w.data_ptr())
     if ent is None:
@@ -271,7 +299,10 @@ def split_planes(x):
     """fp32 (rows, C) -> Planes (what a plane-emitting producer writes; used by tests and tools)."""
     rows, C = x.shape
     pl = Planes(rows, C, x.device)
-    _check(load().ddpo_split_planes_bf16(_p(x), C, _p(pl.hi), _p(pl.lo), pl.ld, rows, C, _stream()), "ddpo_split_planes_bf16")
+    if pl.fmt == 1:
+        _check(load().ddpo_split_planes_f16mx(_p(x), C, _p(pl.hi), _p(pl.lo), pl.ld, rows, C, _stream()), "ddpo_split_planes_f16mx")
+    else:
+        _check(load().ddpo_split_planes_bf16(_p(x), C, _p(pl.hi), _p(pl.lo), pl.ld, rows, C, _stream()), "ddpo_split_planes_bf16")
     return pl
 
 
@@ -526,7 +557,7 @@ def groupnorm(x, B, HW, gamma, beta, groups, eps, silu, out=None, ld_x=None, ld_
         ws = _scratch(load().ddpo_groupnorm_ws_bytes(B, HW, C, groups), x.device, "gn")
         stats = torch.empty(load().ddpo_groupnorm_stats_floats(B, C, groups), dtype=torch.float32, device=x.device)
         _check(load().ddpo_groupnorm_fwd_planes(_p(x), int(ld_x or C), _p(pl.hi), _p(pl.lo), pl.ld, _p(gamma), _p(beta), B, HW, C, groups,
-                                                float(eps), int(bool(silu)), _p(ws), _p(stats), _stream()), "ddpo_groupnorm_fwd_planes")
+                                                float(eps), int(bool(silu)) | (2 * pl.fmt), _p(ws), _p(stats), _stream()), "ddpo_groupnorm_fwd_planes")
         return (pl, stats) if return_stats else pl
     if out is None:
         out = torch.empty(B * HW, C, dtype=torch.float32, device=x.device)
@@ -551,7 +582,7 @@ def layernorm(x, gamma, beta, eps=1e-5, out=None, planes=False):
     rows, C = x.shape
     if planes:
         pl = Planes(rows, C, x.device)
-        _check(load().ddpo_layernorm_fwd_planes(_p(x), _p(pl.hi), _p(pl.lo), _p(gamma), _p(beta), rows, C, float(eps), int(pl.kblocked), _stream()),
+        _check(load().ddpo_layernorm_fwd_planes(_p(x), _p(pl.hi), _p(pl.lo), _p(gamma), _p(beta), rows, C, float(eps), int(pl.kblocked) | (2 * pl.fmt), _stream()),
                "ddpo_layernorm_fwd_planes")
         return pl
     if out is None:
@@ -579,6 +610,12 @@ def pack_weights(w, bwd=True):
         ent["geglu"]["stale"] = True          # re-ordered GEGLU planes (pack_weights_geglu) no longer match w
     fh, fl, _ = ent["fwd"]
     bh, bl = ent["bwd"] if ent["bwd"] is not None else (None, None)
+    if _mx() and K % 32 == 0:            # f16mx forward planes next to the bf16 ones (non-eligible shapes and the backward use those)
+        if "mx" not in ent:
+            ent["mx"] = dict(w16=torch.zeros(K // 32, N, 32, dtype=torch.int16, device=w.device), w8=torch.zeros(K // 32, N, 64, dtype=torch.uint8, device=w.device),
+                             scale=torch.zeros(N, dtype=torch.uint8, device=w.device))
+        m = ent["mx"]
+        _check(load().ddpo_pack_weights_f16mx(_p(w), K, N, _p(m["w16"]), _p(m["w8"]), _p(m["scale"]), _stream()), "ddpo_pack_weights_f16mx")
     if ent["w_layout"] == 1:
         _check(load().ddpo_pack_weights_bf16_kblocked(_p(w), K, N, _p(fh), _p(fl), _stream()), "ddpo_pack_weights_bf16_kblocked")
         if bh is not None:               # data-gradient planes keep the original (K, N) order: the plain split of w, no transpose
@@ -611,6 +648,12 @@ def pack_weights_geglu(w, bias):
         _check(load().ddpo_pack_weights_bf16_kblocked(_p(wp), K, N, _p(g["hi"]), _p(g["lo"]), _stream()), "ddpo_pack_weights_bf16_kblocked")
     else:
         _check(load().ddpo_pack_weights_bf16(_p(wp), K, N, K, _p(g["hi"]), _p(g["lo"]), None, None, _stream()), "ddpo_pack_weights_bf16")
+    if _mx():
+        if "mx" not in g:
+            g["mx"] = dict(w16=torch.zeros(K // 32, N, 32, dtype=torch.int16, device=w.device), w8=torch.zeros(K // 32, N, 64, dtype=torch.uint8, device=w.device),
+                           scale=torch.zeros(N, dtype=torch.uint8, device=w.device))
+        m = g["mx"]
+        _check(load().ddpo_pack_weights_f16mx(_p(wp), K, N, _p(m["w16"]), _p(m["w8"]), _p(m["scale"]), _stream()), "ddpo_pack_weights_f16mx")
     g["stale"] = False
     return True
 
@@ -629,15 +672,17 @@ def linear_geglu(x, w, out=None, planes_out=False, pre_out=False):
     if (M * K * 4) >= (1 << 31):
         return None
     pl = x if isinstance(x, Planes) else None
-    if pl is not None and (current_datapath() != "bf16x3" or K % 32):
-        raise DdpoHipError("plane-fed linear_geglu needs the bf16x3 datapath and K % 32 == 0 (check planes_ok before asking for planes)")
+    if pl is None and _mx() and "mx" in g and K % 32 == 0:          # f16mx: an eligible layer ALWAYS runs on the f16mx kernel (see DATAPATHS)
+        pl = x = split_planes(x)
+    if pl is not None and (not _x3() or K % 32 or (pl.fmt == 1 and "mx" not in g)):
+        raise DdpoHipError("plane-fed linear_geglu needs the bf16x3 / f16mx datapath and K % 32 == 0 (check planes_ok before asking for planes)")
     d = GemmDesc()
     opl = None
     if planes_out:
-        if current_datapath() != "bf16x3":
-            raise DdpoHipError("plane-emitting linear_geglu needs the bf16x3 datapath")
+        if not _x3():
+            raise DdpoHipError("plane-emitting linear_geglu needs the bf16x3 / f16mx datapath")
         opl = Planes(M, N // 2, x.device)
-        d.out_hi, d.out_lo, d.ld_planes = opl.hi.data_ptr(), opl.lo.data_ptr(), opl.ld
+        d.out_hi, d.out_lo, d.ld_planes, d.planes_fmt = opl.hi.data_ptr(), opl.lo.data_ptr(), opl.ld, opl.fmt
     else:
         if out is None:
             out = torch.empty(M, N // 2, dtype=torch.float32, device=x.device)
@@ -652,11 +697,17 @@ def linear_geglu(x, w, out=None, planes_out=False, pre_out=False):
     if pre_out:
         pre = torch.empty(M, N, dtype=torch.float32, device=x.device)
         d.aux_out = pre.data_ptr()
-    npass = 3 if current_datapath() == "bf16x3" else 1
+    npass = 3 if _x3() else 1
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    if pl is not None:
+    if pl is not None and pl.fmt == 1:
+        m = g["mx"]
+        d.w_layout = 1
+        d.w_scale = m["scale"].data_ptr()
+        _check(load().ddpo_gemm_conv_fwd_f16mx_planes(byref(d), _p(pl.hi), _p(pl.lo), pl.ld, _p(m["w16"]), _p(m["w8"]), None, 0, _stream()),
+               "ddpo_gemm_conv_fwd_f16mx_planes")
+    elif pl is not None:
         _check(load().ddpo_gemm_conv_fwd_bf16_planes(byref(d), _p(pl.hi), _p(pl.lo), pl.ld, _p(g["hi"]), _p(g["lo"]), K, None, 0, _stream()),
                "ddpo_gemm_conv_fwd_bf16_planes")
     else:
@@ -678,7 +729,7 @@ def _bf16_route(w, K, N, conv, dgrad):
     cin = conv["Cin"] if conv else K
     if cin % 8:
         return None
-    npass = 3 if current_datapath() == "bf16x3" else 1
+    npass = 3 if _x3() else 1
     if dgrad:
         if ent["bwd"] is None or not conv:
             return None
@@ -695,6 +746,13 @@ def gemm_conv(src, w, *, M, N, K, bias=None, rowbias=None, rows_per_batch=0, res
     bf16 hi / lo planes a plane-fed consumer reads); "only" -> Planes (no fp32 tensor is written).  Check
     planes_out_ok() first: only the buffer-addressed bf16x3 kernels have the plane-emitting output stage."""
     pl = src if isinstance(src, Planes) else None
+    if pl is None and _mx() and not w_trans and ld_src is None:
+        # f16mx: an eligible layer ALWAYS runs on the f16mx kernel; a producer that wrote fp32 (training forward, layers without a plane-emitting
+        # producer) is split on the way in — the same planes its plane-emitting form would have written
+        cin_ = conv["Cin"] if conv else K
+        rows_ = conv["B"] * conv["H"] * conv["W"] if conv else M
+        if planes_ok(w, cin_, rows_) and src.dim() == 2 and src.shape[0] == rows_ and src.shape[1] == cin_ and src.is_contiguous():
+            pl = src = split_planes(src)
     d = GemmDesc()
     d.src = src.data_ptr(); d.ld_src = int(ld_src if ld_src is not None else (conv["Cin"] if conv else K))
     d.w = w.data_ptr(); d.w_trans = int(bool(w_trans))
@@ -706,7 +764,7 @@ def gemm_conv(src, w, *, M, N, K, bias=None, rowbias=None, rows_per_batch=0, res
         if planes_out not in ("both", "only"):
             raise ValueError(planes_out)
         opl = Planes(M, N, src.device)
-        d.out_hi, d.out_lo, d.ld_planes = opl.hi.data_ptr(), opl.lo.data_ptr(), opl.ld
+        d.out_hi, d.out_lo, d.ld_planes, d.planes_fmt = opl.hi.data_ptr(), opl.lo.data_ptr(), opl.ld, opl.fmt
     if out is None and planes_out != "only":
         out = torch.empty(M, N, dtype=torch.float32, device=src.device)
     if residual is not None:
@@ -722,14 +780,22 @@ def gemm_conv(src, w, *, M, N, K, bias=None, rowbias=None, rows_per_batch=0, res
     if route is not None:
         d.w_layout = PACKED[w.data_ptr()].get("w_layout", 0)
     if opl is not None and (route is None or route[3] != 3):
-        raise DdpoHipError("a plane-emitting GEMM needs the bf16x3 datapath and registered weight planes (check planes_out_ok)")
-    if pl is not None and (route is None or route[3] != 3 or (conv["Cin"] if conv else K) % 32 or ld_src is not None):
-        raise DdpoHipError("a plane-fed GEMM needs the bf16x3 datapath, registered weight planes and 32-channel k-tiles "
-                           "(check planes_ok before asking a producer for planes)")
+        raise DdpoHipError("a plane-emitting GEMM needs the bf16x3 / f16mx datapath and registered weight planes (check planes_out_ok)")
+    if pl is not None and (route is None or route[3] != 3 or (conv["Cin"] if conv else K) % 32 or ld_src is not None or
+                           (pl.fmt == 1 and "mx" not in PACKED[w.data_ptr()])):
+        raise DdpoHipError("a plane-fed GEMM needs the bf16x3 / f16mx datapath, registered weight planes (of the planes' format) and 32-channel "
+                           "k-tiles (check planes_ok before asking a producer for planes)")
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    if pl is not None:
+    if pl is not None and pl.fmt == 1:
+        m = PACKED[w.data_ptr()]["mx"]
+        d.w_layout = 1
+        d.w_scale = m["scale"].data_ptr()
+        ws = _scratch(SPLITK_WS_BYTES, src.device, "splitk")
+        _check(load().ddpo_gemm_conv_fwd_f16mx_planes(byref(d), _p(pl.hi), _p(pl.lo), pl.ld, _p(m["w16"]), _p(m["w8"]), _p(ws), SPLITK_WS_BYTES,
+                                                      _stream()), "ddpo_gemm_conv_fwd_f16mx_planes")
+    elif pl is not None:
         hi, lo, ldw, npass = route
         ws = _scratch(SPLITK_WS_BYTES, src.device, "splitk")
         _check(load().ddpo_gemm_conv_fwd_bf16_planes(byref(d), _p(pl.hi), _p(pl.lo), pl.ld, _p(hi), _p(lo), ldw, _p(ws),
@@ -743,7 +809,7 @@ def gemm_conv(src, w, *, M, N, K, bias=None, rowbias=None, rows_per_batch=0, res
     if PROFILE is not None:
         e1.record()
         a_bytes = 4.0 * (conv["B"] * conv["H"] * conv["W"] * conv["Cin"] if conv else M * K)       # unique operand bytes
-        w_bytes = (4.0 if route is None else (4.0 if current_datapath() == "bf16x3" else 2.0)) * K * N
+        w_bytes = (4.0 if route is None else (4.0 if _x3() else 2.0)) * K * N
         io_bytes = a_bytes + w_bytes + 4.0 * M * N * (2 if residual is not None else 1)
         PROFILE.append((e0, e1, 2.0 * M * N * K, "fp32" if route is None else current_datapath(), io_bytes))
     if planes_out == "only":
@@ -888,7 +954,7 @@ def linear_dgrad(dy, w, residual=None):
         d.alpha = 1.0
         d.M, d.N, d.K = int(M), int(K), int(N)
         ws = _scratch(SPLITK_WS_BYTES, dy.device, "splitk")
-        _check(load().ddpo_gemm_conv_fwd_bf16(byref(d), _p(ent["bwd"][0]), _p(ent["bwd"][1]), int(N), 3 if current_datapath() == "bf16x3" else 1,
+        _check(load().ddpo_gemm_conv_fwd_bf16(byref(d), _p(ent["bwd"][0]), _p(ent["bwd"][1]), int(N), 3 if _x3() else 1,
                                               _p(ws), SPLITK_WS_BYTES, _stream()), "ddpo_gemm_conv_fwd_bf16(dgrad)")
         return out
     return gemm_conv(dy, w, M=M, N=K, K=N, w_trans=True, residual=residual)
@@ -910,11 +976,15 @@ def gemm_wgrad(src, dy, dw, *, M, N, K, conv=None, ld_src=None, ld_dy=None, accu
                                                                       conv["pad"] == conv["ksize"] // 2)) and K >= 64 and N >= 32
     spl = src if isinstance(src, Planes) else None
     dpl = dy if isinstance(dy, Planes) else None
-    if not fast or current_datapath() != "bf16x3":           # exact-fp32 / single-pass kernels take fp32 operands (small layers: conv_out, tests)
+    if not fast or not _x3():           # exact-fp32 / single-pass kernels take fp32 operands (small layers: conv_out, tests)
         if spl is not None:
             src, spl = spl.float(), None
         if dpl is not None:
             dy, dpl = dpl.float(), None
+    if spl is not None and spl.fmt == 1:          # the weight gradients run on bf16x3: f16mx planes are decoded (tests only — the models keep
+        src, spl = spl.float(), None              # fp32 activations for the backward under f16mx, lib.train_planes())
+    if dpl is not None and dpl.fmt == 1:
+        dy, dpl = dpl.float(), None
     d = GemmDesc()
     if spl is None:
         d.src = src.data_ptr()

@@ -205,8 +205,8 @@ def resnet_forward(P, name, x: Act, temb_act, groups, eps, tape=None, emit_plane
     # inference / sampling (no tape): the two GroupNorm+SiLU results feed only their convolution, so they are written as bf16
     # hi / lo planes and the convolutions run plane-fed (LDS-DMA operands; bit-identical to the fp32-fed kernels)
     # training (tape): the same, the planes are what the weight gradients of conv1 / conv2 read (lib.TRAIN_PLANES)
-    pl1 = (tape is None or L.TRAIN_PLANES) and L.planes_pay(P[name + ".conv1.kernel"], x.C, x.M)
-    pl2 = (tape is None or L.TRAIN_PLANES) and L.planes_pay(P[name + ".conv2.kernel"], cout, x.M)
+    pl1 = (tape is None or L.train_planes()) and L.planes_pay(P[name + ".conv1.kernel"], x.C, x.M)
+    pl2 = (tape is None or L.train_planes()) and L.planes_pay(P[name + ".conv2.kernel"], cout, x.M)
     h1, st1 = L.groupnorm(x.t, x.B, x.HW, P[name + ".norm1.scale"], P[name + ".norm1.bias"], groups, eps, True, return_stats=True,
                           planes=pl1)
     rowbias, rpb = None, x.HW
@@ -318,7 +318,7 @@ class UNet2DCondition:
         rec = None if tape is None else dict(name=name, x=x, heads=heads, ctx=ctx, ctx_len=ctx_len)
         tb = name + ".transformer_blocks_0"
         inf = tape is None                         # plane-fed GEMMs behind the norms (see resnet_forward)
-        npl = inf or L.TRAIN_PLANES                # norm outputs as planes: sampling, and training when the wgrads read planes
+        npl = inf or L.train_planes()              # norm outputs as planes: sampling, and training when the wgrads read planes
         pl_in = npl and L.planes_pay(P[name + ".proj_in.kernel"], C, B * N)
         pl_1 = npl and all(L.planes_pay(P[f"{tb}.attn1.{n}.kernel"], C, B * N) for n in ("to_q", "to_k", "to_v"))
         pl_2 = npl and L.planes_pay(P[tb + ".attn2.to_q.kernel"], C, B * N)

@@ -122,7 +122,10 @@ int ddpo_groupnorm_fwd(const float* x, int ldx, float* y, int ldy, const float* 
  * plane row stride ldy / ld_out / ld_planes / lda / ld_src / ld_w):  ld > 0: row-major (rows, ld);  ld == 0: k-blocked
  * (C / 32, rows, 32), C % 32 == 0 — the 32 channels of one k-tile of consecutive rows are consecutive memory, so every 1 KiB
  * LDS-DMA piece of the plane-fed GEMM (16 consecutive rows x 64 B) is 8 full cache lines instead of 16 half lines.  `rows` is the
- * row count of the tensor the planes describe: B*HW here, `rows` / M elsewhere, B*H*W source pixels for a convolution's input. */
+ * row count of the tensor the planes describe: B*HW here, `rows` / M elsewhere, B*H*W source pixels for a convolution's input.
+ * PLANE FORMAT (ABI v9): bit 1 of `fuse_silu` here (values 2 / 3) and bit 1 of `kblocked` in ddpo_layernorm_fwd_planes select the f16mx
+ * format instead of bf16 hi / lo: y_hi = f16(y), y_lo = the interleaved e5m2 chunks of ddpo_split_planes_f16mx (C, ldy % 32 == 0) —
+ * the operand of ddpo_gemm_conv_fwd_f16mx_planes, bit for bit what ddpo_split_planes_f16mx would make of the fp32 result. */
 int ddpo_groupnorm_fwd_planes(const float* x, int ldx, uint16_t* y_hi, uint16_t* y_lo, int ldy, const float* gamma,
                               const float* beta, int B, int HW, int C, int G, float eps, int fuse_silu, void* ws,
                               float* stats, void* stream);
