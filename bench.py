@@ -25,6 +25,7 @@ import json
 import os
 import socket
 import statistics
+import subprocess
 import sys
 import time
 
@@ -69,6 +70,7 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-train-extra", action="store_true", help="skip the short train-step measurement attached to the headline line")
+    ap.add_argument("--no-f16mx-extra", action="store_true", help="skip the opt-in f16mx datapath's sampling measurement attached to the headline line (extra.f16mx)")
     args = ap.parse_args(argv)
     if args.resolution is None:
         args.resolution = {"sd15": 512, "sd21": 768}.get(args.model, 64)
@@ -592,6 +594,21 @@ def main(argv=None):
     if rank != 0:
         comm.close()
         return
+    if world == 1 and args.datapath == "bf16x3" and not args.no_f16mx_extra and not args.no_train_extra and args.model == "sd15":
+        # the opt-in f16mx datapath (long reductions on the f16 + MX-fp8 kernel) on the same workload, in a fresh process: reported NEXT to the
+        # headline, never as it
+        try:
+            cmd = [sys.executable, os.path.abspath(__file__), "--datapath", "f16mx", "--steps", str(args.steps), "--warmup", str(args.warmup),
+                   "--no-cpu-baseline", "--no-train-extra", "--no-roofline", "--sample-batch-size", str(args.sample_batch_size)]
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+            pr = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+            line = [l for l in pr.stdout.splitlines() if l.startswith('{"metric"')][-1]
+            dj = json.loads(line)
+            extra["f16mx"] = {"value": dj["value"], "unit": dj["unit"], "ms_per_step": dj["ms_per_step"], "dtype": dj["dtype"],
+                              "note": "opt-in datapath (--datapath f16mx): f16 MFMA + one MX-scaled 8-bit MFMA for the cross terms on the plane-eligible "
+                                      "forward layers with K >= 2560, bf16x3 elsewhere; U-Net forward error 4.2e-5 vs 2.0e-5 (bf16x3) against float64"}
+        except Exception as exc:
+            extra["f16mx"] = {"error": f"{type(exc).__name__}: {exc}"}
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args)

@@ -127,11 +127,13 @@ DATAPATH = os.environ.get("DDPO_DATAPATH", "fp32")
 
 
 DATAPATHS = ("fp32", "bf16x3", "bf16", "f16mx")
-# "f16mx" (round 3, opt-in): every PLANE-ELIGIBLE forward contraction (registered weights, 32-channel k-tiles, 31-bit offsets — a function of
-# the layer, never of the batch) runs on the f16 + MX-fp8 cross-term kernel (ddpo_gemm_conv_fwd_f16mx_planes); its activation planes come from
-# the producing kernel (GroupNorm / LayerNorm / GEMM output stages) or, when the producer wrote fp32 (training forward: the weight gradients read
-# the fp32 tensor), from ddpo_split_planes_f16mx on the way in — the same bits either way, so the sampler and the training forward of a layer
-# always take the same arithmetic.  Everything else (non-eligible layers, data / weight gradients, attention) runs as under bf16x3.
+# "f16mx" (round 3, opt-in): every plane-eligible forward contraction with a LONG reduction (K >= MX_MIN_K: all 3x3 convolutions, FF2 of the
+# lower levels — a property of the layer, never of the batch) runs on the f16 + MX-fp8 cross-term kernel (ddpo_gemm_conv_fwd_f16mx_planes); its
+# activation planes come from the producing kernel (GroupNorm / LayerNorm / GEMM output stages, which ask planes_pay() for the consumer's
+# format) or, when the producer wrote fp32 (training forward: the weight gradients read the fp32 tensor), from ddpo_split_planes_f16mx on the
+# way in — the same bits either way, so the sampler and the training forward of a layer always take the same arithmetic.  Everything else
+# (short reductions — where the f16mx kernel measured no gain —, non-eligible layers, data / weight gradients, attention) runs as under bf16x3.
+MX_MIN_K = 2560
 _TLS = threading.local()
 
 
@@ -176,10 +178,23 @@ def _mx():
     return current_datapath() == "f16mx"
 
 
-def train_planes():
-    """Norm outputs as planes on the TRAINING forward (consumed by the layer's GEMM and its weight gradient): bf16x3 only — under f16mx the
-    weight gradients read the fp32 tensor and the forward GEMM splits it on the way in."""
-    return TRAIN_PLANES and not _mx()
+def mx_layer(w):
+    """True when the forward contraction with weight tensor `w` runs on the f16mx kernel: f16mx datapath, f16mx weight planes registered
+    (pack_weights packs them for K >= MX_MIN_K).  A property of the layer — the batch never enters."""
+    if not _mx():
+        return False
+    ent = PACKED.get(w.data_ptr())
+    return ent is not None and "mx" in ent
+
+
+def norm_planes(w, cin, rows, training=False):
+    """What a normalisation layer in front of the contraction with weight `w` should emit: 0 = the fp32 tensor, 1 = bf16 hi / lo planes,
+    2 = f16mx planes (= planes_pay's answer), except that the TRAINING forward keeps fp32 in front of an f16mx layer (its weight gradient runs
+    on bf16x3 from the fp32 tensor; the forward GEMM splits it on the way in) and wherever DDPO_TRAIN_PLANES is off."""
+    p = planes_pay(w, cin, rows)
+    if training and (p == 2 or not TRAIN_PLANES):
+        return 0
+    return p
 
 
 SPLITK_WS_BYTES = 64 << 20       # scratch for the deterministic split-K of under-filled launches
@@ -216,10 +231,10 @@ class Planes:
     when A_KBLOCKED and C % 32 == 0 — k-blocked (C / 32, rows, 32); `ld` is the plane row stride handed to the C ABI (0 = k-blocked)."""
     __slots__ = ("hi", "lo", "rows", "C", "kblocked", "fmt")
 
-    def __init__(self, rows, C, device, fmt=None):
+    def __init__(self, rows, C, device, fmt=0):
         self.rows, self.C = int(rows), int(C)
         # fmt 0: bf16 hi / lo; 1: f16mx (hi = the f16 plane, lo = the interleaved e5m2 chunks; same geometry, same byte counts)
-        self.fmt = int((1 if _mx() else 0) if fmt is None else fmt)
+        self.fmt = int(fmt or 0)
         if self.fmt == 1 and C % 32:
             raise DdpoHipError("f16mx planes need whole 32-channel blocks")
         self.kblocked = bool(A_KBLOCKED and C % 32 == 0)
@@ -264,29 +279,32 @@ def planes_ok(w, cin, rows):
     if not (PLANES and _x3() and cin % 32 == 0):
         return False
     ent = PACKED.get(w.data_ptr())
-    if ent is None or (_mx() and "mx" not in ent):
+    if ent is None:
         return False
     lim = 0x7FFFFFFF
     return rows * cin * 4 < lim and ent["N"] * ent["fwd"][2] * 2 < lim
 
 
 def planes_pay(w, cin, rows):
-    """planes_ok() AND the plane-fed kernel is the faster one for this layer in the model (tools/unet_gemm_breakdown.py --ab,
+    """0 / 1 / 2 (falsy = feed fp32; 1 = bf16 hi / lo planes; 2 = f16mx planes — hand the value to the producer: groupnorm / layernorm
+    `planes=`, gemm_conv / linear_geglu `planes_out` / `planes_fmt`).  Non-zero when planes_ok() AND the plane-fed kernel is the faster one for this layer in the model (tools/unet_gemm_breakdown.py --ab,
     profiles/r02_gemm_breakdown_ab.md): long reductions (every 3x3 convolution, FF2) gain 5-24 %, the 64x64-level linears 0-8 %;
     the short reductions of the 32x32 / 16x16 levels (K <= 1280 with < 32768 rows: q / k / v / proj_in, FF1) lose 2-8 % to the
     LDS-DMA loop's fill latency, so their norms keep writing fp32.  DDPO_PLANES_ALL=1 ignores the rule (tests of the kernels)."""
     if not planes_ok(w, cin, rows):
-        return False
-    if PLANES_ALL or _mx():              # f16mx: the routing must not depend on the batch — every eligible layer is plane-fed
-        return True
-    return PACKED[w.data_ptr()]["K"] >= 2560 or rows >= 32768
+        return 0
+    if mx_layer(w):                      # f16mx layer: always plane-fed, in the f16mx format (the routing must not depend on the batch)
+        return 2
+    if PLANES_ALL:
+        return 1
+    return 1 if (PACKED[w.data_ptr()]["K"] >= 2560 or rows >= 32768) else 0
 
 
 def planes_out_ok(w, cin, rows, N):
     """True when the GEMM / conv with weight `w` (reduction channels per tap `cin`, `rows` source rows, N output columns) runs on a
     buffer-addressed bf16x3 kernel, i.e. can emit its result as planes (ddpo_gemm_desc.out_hi): the conditions of planes_ok()
     except that the ACTIVATION may be fp32 (then only K % 32 and the 31-bit offsets matter), plus N % 4 == 0."""
-    if not (PLANES and PLANES_OUT and _x3() and cin % 32 == 0 and N % 4 == 0 and (not _mx() or N % 32 == 0)):
+    if not (PLANES and PLANES_OUT and _x3() and cin % 32 == 0 and N % 4 == 0):
         return False
     ent = PACKED.get(w.data_ptr())
     if ent is None:
@@ -295,10 +313,10 @@ def planes_out_ok(w, cin, rows, N):
     return rows * cin * 4 < lim and ent["N"] * ent["fwd"][2] * 2 < lim
 
 
-def split_planes(x):
-    """fp32 (rows, C) -> Planes (what a plane-emitting producer writes; used by tests and tools)."""
+def split_planes(x, fmt=0):
+    """fp32 (rows, C) -> Planes of format `fmt` (0 bf16 hi / lo, 1 f16mx): what a plane-emitting producer writes."""
     rows, C = x.shape
-    pl = Planes(rows, C, x.device)
+    pl = Planes(rows, C, x.device, fmt=fmt)
     if pl.fmt == 1:
         _check(load().ddpo_split_planes_f16mx(_p(x), C, _p(pl.hi), _p(pl.lo), pl.ld, rows, C, _stream()), "ddpo_split_planes_f16mx")
     else:
@@ -307,9 +325,10 @@ def split_planes(x):
 
 
 # ---- f16mx forward operator (ABI v7): a*b ~= a_h*b_h (f16 MFMA) + a_h8*b_l8 + a_l8*b_h8 (one block-scaled 8-bit MFMA) on the plane-fed
-# kernels.  EXPERIMENTAL: validated operator by operator (tests/test_gpu_f16mx.py, tools/native/kernel_probe mx) and measured — 1.2-1.4x
-# on the long-reduction convolutions of the 32x32 / 16x16 levels, ~1.0x at the 64x64 level, whose tiles are bound by the operand stream
-# (profiles/r03_probe_mx.log) — but NOT routed by the models: they run bf16x3.
+# kernels.  Validated operator by operator (tests/test_gpu_f16mx.py, tools/native/kernel_probe mx) and measured — 1.2-1.4x on the
+# long-reduction convolutions of the 32x32 / 16x16 levels, ~1.0x at the 64x64 level, whose tiles are bound by the operand stream
+# (profiles/r03_probe_mx.log).  The raw wrappers below are what the tests and tools call; the MODELS reach the kernel through
+# gemm_conv / linear_geglu under the opt-in `f16mx` datapath (DATAPATHS above; bf16x3 stays the default).
 def pack_weights_f16mx(w):
     """fp32 weight (..., N) viewed as (K, N) -> dict(w16, w8, scale, K, N): the f16mx weight planes of ddpo_pack_weights_f16mx."""
     N = w.shape[-1]
@@ -550,10 +569,11 @@ def _scratch(nbytes, device, tag):
 
 def groupnorm(x, B, HW, gamma, beta, groups, eps, silu, out=None, ld_x=None, ld_out=None, return_stats=False, planes=False):
     """x: (B*HW, C) NHWC rows (row stride ld_x).  Returns (B*HW, C) [and the saved statistics for the backward].
-    planes=True: the result comes back as `Planes` (bf16 hi / lo) for a plane-fed conv / linear."""
+    planes (the value of planes_pay / norm_planes for the consumer; 1 / True = bf16 hi / lo, 2 = f16mx): the result comes back as `Planes`
+    for a plane-fed conv / linear."""
     C = gamma.numel()
     if planes:
-        pl = Planes(B * HW, C, x.device)
+        pl = Planes(B * HW, C, x.device, fmt=1 if planes == 2 else 0)
         ws = _scratch(load().ddpo_groupnorm_ws_bytes(B, HW, C, groups), x.device, "gn")
         stats = torch.empty(load().ddpo_groupnorm_stats_floats(B, C, groups), dtype=torch.float32, device=x.device)
         _check(load().ddpo_groupnorm_fwd_planes(_p(x), int(ld_x or C), _p(pl.hi), _p(pl.lo), pl.ld, _p(gamma), _p(beta), B, HW, C, groups,
@@ -581,7 +601,7 @@ def groupnorm_bwd(x, dy, stats, gamma, B, HW, groups, silu, dgamma, dbeta, dx_ad
 def layernorm(x, gamma, beta, eps=1e-5, out=None, planes=False):
     rows, C = x.shape
     if planes:
-        pl = Planes(rows, C, x.device)
+        pl = Planes(rows, C, x.device, fmt=1 if planes == 2 else 0)
         _check(load().ddpo_layernorm_fwd_planes(_p(x), _p(pl.hi), _p(pl.lo), _p(gamma), _p(beta), rows, C, float(eps), int(pl.kblocked) | (2 * pl.fmt), _stream()),
                "ddpo_layernorm_fwd_planes")
         return pl
@@ -610,7 +630,7 @@ def pack_weights(w, bwd=True):
         ent["geglu"]["stale"] = True          # re-ordered GEGLU planes (pack_weights_geglu) no longer match w
     fh, fl, _ = ent["fwd"]
     bh, bl = ent["bwd"] if ent["bwd"] is not None else (None, None)
-    if _mx() and K % 32 == 0:            # f16mx forward planes next to the bf16 ones (non-eligible shapes and the backward use those)
+    if _mx() and K % 32 == 0 and K >= MX_MIN_K:            # f16mx forward planes next to the bf16 ones (mx_layer(); the backward uses the bf16 ones)
         if "mx" not in ent:
             ent["mx"] = dict(w16=torch.zeros(K // 32, N, 32, dtype=torch.int16, device=w.device), w8=torch.zeros(K // 32, N, 64, dtype=torch.uint8, device=w.device),
                              scale=torch.zeros(N, dtype=torch.uint8, device=w.device))
@@ -648,7 +668,7 @@ def pack_weights_geglu(w, bias):
         _check(load().ddpo_pack_weights_bf16_kblocked(_p(wp), K, N, _p(g["hi"]), _p(g["lo"]), _stream()), "ddpo_pack_weights_bf16_kblocked")
     else:
         _check(load().ddpo_pack_weights_bf16(_p(wp), K, N, K, _p(g["hi"]), _p(g["lo"]), None, None, _stream()), "ddpo_pack_weights_bf16")
-    if _mx():
+    if _mx() and K >= MX_MIN_K:
         if "mx" not in g:
             g["mx"] = dict(w16=torch.zeros(K // 32, N, 32, dtype=torch.int16, device=w.device), w8=torch.zeros(K // 32, N, 64, dtype=torch.uint8, device=w.device),
                            scale=torch.zeros(N, dtype=torch.uint8, device=w.device))
@@ -672,16 +692,18 @@ def linear_geglu(x, w, out=None, planes_out=False, pre_out=False):
     if (M * K * 4) >= (1 << 31):
         return None
     pl = x if isinstance(x, Planes) else None
-    if pl is None and _mx() and "mx" in g and K % 32 == 0:          # f16mx: an eligible layer ALWAYS runs on the f16mx kernel (see DATAPATHS)
-        pl = x = split_planes(x)
-    if pl is not None and (not _x3() or K % 32 or (pl.fmt == 1 and "mx" not in g)):
-        raise DdpoHipError("plane-fed linear_geglu needs the bf16x3 / f16mx datapath and K % 32 == 0 (check planes_ok before asking for planes)")
+    mxl = _mx() and "mx" in g
+    if pl is None and mxl:               # an f16mx layer ALWAYS runs on the f16mx kernel (see DATAPATHS): fp32 input is split on the way in
+        pl = x = split_planes(x, fmt=1)
+    if pl is not None and (not _x3() or K % 32 or (pl.fmt == 1) != mxl):
+        raise DdpoHipError("plane-fed linear_geglu needs the bf16x3 / f16mx datapath, K % 32 == 0 and planes of the layer's format "
+                           "(ask planes_pay / norm_planes for it)")
     d = GemmDesc()
     opl = None
     if planes_out:
         if not _x3():
             raise DdpoHipError("plane-emitting linear_geglu needs the bf16x3 / f16mx datapath")
-        opl = Planes(M, N // 2, x.device)
+        opl = Planes(M, N // 2, x.device, fmt=1 if planes_out == 2 else 0)            # planes_out = the CONSUMER's planes_pay value
         d.out_hi, d.out_lo, d.ld_planes, d.planes_fmt = opl.hi.data_ptr(), opl.lo.data_ptr(), opl.ld, opl.fmt
     else:
         if out is None:
@@ -740,19 +762,27 @@ def _bf16_route(w, K, N, conv, dgrad):
 
 
 def gemm_conv(src, w, *, M, N, K, bias=None, rowbias=None, rows_per_batch=0, residual=None, out=None, alpha=1.0,
-              w_trans=False, ld_src=None, ld_out=None, ld_res=None, conv=None, planes_out=None):
+              w_trans=False, ld_src=None, ld_out=None, ld_res=None, conv=None, planes_out=None, planes_fmt=0):
     """Generic entry: conv = dict(ksize, stride, pad, upsample, B, H, W, Cin, OH, OW) or None for a dense GEMM.
     planes_out: None -> returns the fp32 result; "both" -> (fp32, Planes) from ONE launch (the output stage also writes the
     bf16 hi / lo planes a plane-fed consumer reads); "only" -> Planes (no fp32 tensor is written).  Check
-    planes_out_ok() first: only the buffer-addressed bf16x3 kernels have the plane-emitting output stage."""
+    planes_out_ok() first: only the buffer-addressed bf16x3 kernels have the plane-emitting output stage.  planes_fmt: the format the CONSUMER
+    wants (its planes_pay value: 2 = f16mx, else bf16 hi / lo)."""
     pl = src if isinstance(src, Planes) else None
-    if pl is None and _mx() and not w_trans and ld_src is None:
-        # f16mx: an eligible layer ALWAYS runs on the f16mx kernel; a producer that wrote fp32 (training forward, layers without a plane-emitting
+    mxl = (not w_trans) and mx_layer(w)
+    if mxl:
+        # an f16mx layer ALWAYS runs on the f16mx kernel; a producer that wrote fp32 (training forward, layers without a plane-emitting
         # producer) is split on the way in — the same planes its plane-emitting form would have written
         cin_ = conv["Cin"] if conv else K
         rows_ = conv["B"] * conv["H"] * conv["W"] if conv else M
-        if planes_ok(w, cin_, rows_) and src.dim() == 2 and src.shape[0] == rows_ and src.shape[1] == cin_ and src.is_contiguous():
-            pl = src = split_planes(src)
+        if not planes_ok(w, cin_, rows_) or ld_src is not None:
+            mxl = False                      # not plane-eligible (>= 2 GiB tensors, column slices): bf16x3 like every other such layer
+        elif pl is None:
+            if not (src.dim() == 2 and src.shape[0] == rows_ and src.shape[1] == cin_ and src.is_contiguous()):
+                raise DdpoHipError("an f16mx layer needs its fp32 input as a contiguous (rows, channels) tensor")
+            pl = src = split_planes(src, fmt=1)
+    if pl is not None and (pl.fmt == 1) != bool(mxl):
+        raise DdpoHipError("activation planes of the wrong format for this layer (ask planes_pay / norm_planes: 1 = bf16 hi / lo, 2 = f16mx)")
     d = GemmDesc()
     d.src = src.data_ptr(); d.ld_src = int(ld_src if ld_src is not None else (conv["Cin"] if conv else K))
     d.w = w.data_ptr(); d.w_trans = int(bool(w_trans))
@@ -763,7 +793,7 @@ def gemm_conv(src, w, *, M, N, K, bias=None, rowbias=None, rows_per_batch=0, res
     if planes_out is not None:
         if planes_out not in ("both", "only"):
             raise ValueError(planes_out)
-        opl = Planes(M, N, src.device)
+        opl = Planes(M, N, src.device, fmt=1 if planes_fmt == 2 else 0)
         d.out_hi, d.out_lo, d.ld_planes, d.planes_fmt = opl.hi.data_ptr(), opl.lo.data_ptr(), opl.ld, opl.fmt
     if out is None and planes_out != "only":
         out = torch.empty(M, N, dtype=torch.float32, device=src.device)
@@ -781,8 +811,7 @@ def gemm_conv(src, w, *, M, N, K, bias=None, rowbias=None, rows_per_batch=0, res
         d.w_layout = PACKED[w.data_ptr()].get("w_layout", 0)
     if opl is not None and (route is None or route[3] != 3):
         raise DdpoHipError("a plane-emitting GEMM needs the bf16x3 / f16mx datapath and registered weight planes (check planes_out_ok)")
-    if pl is not None and (route is None or route[3] != 3 or (conv["Cin"] if conv else K) % 32 or ld_src is not None or
-                           (pl.fmt == 1 and "mx" not in PACKED[w.data_ptr()])):
+    if pl is not None and (route is None or route[3] != 3 or (conv["Cin"] if conv else K) % 32 or ld_src is not None):
         raise DdpoHipError("a plane-fed GEMM needs the bf16x3 / f16mx datapath, registered weight planes (of the planes' format) and 32-channel "
                            "k-tiles (check planes_ok before asking a producer for planes)")
     if PROFILE is not None:
@@ -982,7 +1011,7 @@ def gemm_wgrad(src, dy, dw, *, M, N, K, conv=None, ld_src=None, ld_dy=None, accu
         if dpl is not None:
             dy, dpl = dpl.float(), None
     if spl is not None and spl.fmt == 1:          # the weight gradients run on bf16x3: f16mx planes are decoded (tests only — the models keep
-        src, spl = spl.float(), None              # fp32 activations for the backward under f16mx, lib.train_planes())
+        src, spl = spl.float(), None              # fp32 activations for the backward in front of an f16mx layer, lib.norm_planes())
     if dpl is not None and dpl.fmt == 1:
         dy, dpl = dpl.float(), None
     d = GemmDesc()

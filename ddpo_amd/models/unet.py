@@ -198,15 +198,16 @@ class Act:
         return self.B * self.H * self.W
 
 
-def resnet_forward(P, name, x: Act, temb_act, groups, eps, tape=None, emit_planes=False):
+def resnet_forward(P, name, x: Act, temb_act, groups, eps, tape=None, emit_planes=0):
     """FlaxResnetBlock2D: GN-SiLU-conv3x3 (+time proj) - GN-SiLU-conv3x3 (+ shortcut).
-    emit_planes (sampling): conv2's output stage also writes the block output as planes (Act.pl) for a plane-fed sampler conv."""
+    emit_planes (sampling; the consuming sampler convolution's planes_pay value): conv2's output stage also writes the block output as
+    planes of that format (Act.pl)."""
     cout = P[name + ".conv1.bias"].numel()
     # inference / sampling (no tape): the two GroupNorm+SiLU results feed only their convolution, so they are written as bf16
     # hi / lo planes and the convolutions run plane-fed (LDS-DMA operands; bit-identical to the fp32-fed kernels)
     # training (tape): the same, the planes are what the weight gradients of conv1 / conv2 read (lib.TRAIN_PLANES)
-    pl1 = (tape is None or L.train_planes()) and L.planes_pay(P[name + ".conv1.kernel"], x.C, x.M)
-    pl2 = (tape is None or L.train_planes()) and L.planes_pay(P[name + ".conv2.kernel"], cout, x.M)
+    pl1 = L.norm_planes(P[name + ".conv1.kernel"], x.C, x.M, tape is not None)         # 0 fp32 / 1 bf16 planes / 2 f16mx planes
+    pl2 = L.norm_planes(P[name + ".conv2.kernel"], cout, x.M, tape is not None)
     h1, st1 = L.groupnorm(x.t, x.B, x.HW, P[name + ".norm1.scale"], P[name + ".norm1.bias"], groups, eps, True, return_stats=True,
                           planes=pl1)
     rowbias, rpb = None, x.HW
@@ -225,7 +226,7 @@ def resnet_forward(P, name, x: Act, temb_act, groups, eps, tape=None, emit_plane
     opl = None
     if emit_planes and tape is None and L.planes_out_ok(P[name + ".conv2.kernel"], cout, x.M, cout):
         (out, opl), _, _ = L.conv2d(h2, P[name + ".conv2.kernel"], P[name + ".conv2.bias"], x.B, x.H, x.W, cout, cout, 3, residual=res,
-                                    planes_out="both")
+                                    planes_out="both", planes_fmt=emit_planes)
     else:
         out, _, _ = L.conv2d(h2, P[name + ".conv2.kernel"], P[name + ".conv2.bias"], x.B, x.H, x.W, cout, cout, 3, residual=res)
     if tape is not None:
@@ -312,17 +313,19 @@ class UNet2DCondition:
             d_x = L.linear_dgrad(dv, P[name + ".to_v.kernel"], residual=d_x)
         return d_x
 
-    def _transformer(self, name, x: Act, ctx, ctx_len, heads, tape=None, emit_planes=False):
+    def _transformer(self, name, x: Act, ctx, ctx_len, heads, tape=None, emit_planes=0):
         P, cfg = self.params, self.cfg
         C, B, N = x.C, x.B, x.HW
         rec = None if tape is None else dict(name=name, x=x, heads=heads, ctx=ctx, ctx_len=ctx_len)
         tb = name + ".transformer_blocks_0"
         inf = tape is None                         # plane-fed GEMMs behind the norms (see resnet_forward)
-        npl = inf or L.train_planes()              # norm outputs as planes: sampling, and training when the wgrads read planes
-        pl_in = npl and L.planes_pay(P[name + ".proj_in.kernel"], C, B * N)
-        pl_1 = npl and all(L.planes_pay(P[f"{tb}.attn1.{n}.kernel"], C, B * N) for n in ("to_q", "to_k", "to_v"))
-        pl_2 = npl and L.planes_pay(P[tb + ".attn2.to_q.kernel"], C, B * N)
-        pl_3 = npl and L.planes_pay(P[tb + ".ff.net_0.proj.kernel"], C, B * N)
+        npf = lambda n: L.norm_planes(P[n], C, B * N, not inf)      # what the norm in front of layer n emits: 0 fp32 / 1 bf16 planes / 2 f16mx planes
+        pl_in = npf(name + ".proj_in.kernel")
+        pl_1 = min(npf(f"{tb}.attn1.{n}.kernel") for n in ("to_q", "to_k", "to_v"))     # one LayerNorm feeds all three: the same format or fp32
+        if len({npf(f"{tb}.attn1.{n}.kernel") for n in ("to_q", "to_k", "to_v")}) > 1:
+            pl_1 = 0
+        pl_2 = npf(tb + ".attn2.to_q.kernel")
+        pl_3 = npf(tb + ".ff.net_0.proj.kernel")
         F = P[tb + ".ff.net_2.kernel"].shape[0]
         pl_ff2 = inf and L.PLANES_OUT and L.planes_pay(P[tb + ".ff.net_2.kernel"], F, B * N)       # GEGLU output stage -> planes -> plane-fed FF2
         pl_out = inf and emit_planes and L.planes_out_ok(P[name + ".proj_out.kernel"], C, B * N, C)
@@ -353,7 +356,7 @@ class UNet2DCondition:
             f = L.linear(l3, P[tb + ".ff.net_0.proj.kernel"], P[tb + ".ff.net_0.proj.bias"])
             gg = L.geglu(f)
         h3 = L.linear(gg, P[tb + ".ff.net_2.kernel"], P[tb + ".ff.net_2.bias"], residual=h2)
-        po = dict(planes_out="both") if pl_out else {}
+        po = dict(planes_out="both", planes_fmt=emit_planes) if pl_out else {}
         if cfg.use_linear_projection:
             out = L.linear(h3, P[name + ".proj_out.kernel"], P[name + ".proj_out.bias"], residual=x.t, **po)
         else:
@@ -455,18 +458,22 @@ class UNet2DCondition:
                     h = Act(twice(r.t), B, r.H, r.W, r.C)
                 else:
                     # the level's last block feeds the down-sampler convolution: its output stage also emits planes (sampling)
-                    emit = tape is None and i < nlev - 1 and j == cfg.layers_per_block - 1
+                    emit = 0
+                    if tape is None and i < nlev - 1 and j == cfg.layers_per_block - 1:      # the consumer's planes_pay value (0 / 1 / 2)
+                        emit = L.planes_pay(P[f"down_blocks_{i}.downsamplers_0.conv.kernel"], boc[i], h.M)
                     h = resnet_forward(P, f"down_blocks_{i}.resnets_{j}", h, temb_act, G, 1e-5, tape,
-                                       emit_planes=emit and not cfg.cross_attn_down[i])
+                                       emit_planes=0 if cfg.cross_attn_down[i] else emit)
                 if cfg.cross_attn_down[i]:
-                    h = self._transformer(f"down_blocks_{i}.attentions_{j}", h, ctx, Lc, cfg.num_heads[i], tape,
-                                          emit_planes=tape is None and i < nlev - 1 and j == cfg.layers_per_block - 1)
+                    emit_t = 0
+                    if tape is None and i < nlev - 1 and j == cfg.layers_per_block - 1:
+                        emit_t = L.planes_pay(P[f"down_blocks_{i}.downsamplers_0.conv.kernel"], boc[i], h.M)
+                    h = self._transformer(f"down_blocks_{i}.attentions_{j}", h, ctx, Lc, cfg.num_heads[i], tape, emit_planes=emit_t)
                 skips.append(h)
                 if tape is not None:
                     tape.append(("skip_push", None))
             if i < nlev - 1:
                 name = f"down_blocks_{i}.downsamplers_0.conv"
-                src = h.pl if (h.pl is not None and L.planes_pay(P[name + ".kernel"], h.C, h.M)) else h.t
+                src = h.pl if (h.pl is not None and L.planes_pay(P[name + ".kernel"], h.C, h.M) == h.pl.fmt + 1) else h.t
                 t, OH, OW = L.conv2d(src, P[name + ".kernel"], P[name + ".bias"], B, h.H, h.W, h.C, h.C, 3, stride=2, pad=1)
                 if tape is not None:
                     tape.append(("down", dict(name=name, x=h)))
@@ -485,20 +492,22 @@ class UNet2DCondition:
                 L.copy_cols(s.t, cat, h.C, B * h.HW, s.C)
                 if tape is not None:
                     tape.append(("concat", dict(c0=h.C, c1=s.C)))
-                emit = tape is None and i < nlev - 1 and j == cfg.layers_per_block      # feeds the up-sampler convolution
+                emit = 0
+                if tape is None and i < nlev - 1 and j == cfg.layers_per_block:      # feeds the up-sampler convolution: its planes_pay value
+                    emit = L.planes_pay(P[f"up_blocks_{i}.upsamplers_0.conv.kernel"], boc[lvl], B * h.HW)
                 h = resnet_forward(P, f"up_blocks_{i}.resnets_{j}", Act(cat, B, h.H, h.W, h.C + s.C), temb_act, G, 1e-5, tape,
-                                   emit_planes=emit and not cfg.cross_attn_down[lvl])
+                                   emit_planes=0 if cfg.cross_attn_down[lvl] else emit)
                 if cfg.cross_attn_down[lvl]:
                     h = self._transformer(f"up_blocks_{i}.attentions_{j}", h, ctx, Lc, cfg.num_heads[lvl], tape, emit_planes=emit)
             if i < nlev - 1:
                 name = f"up_blocks_{i}.upsamplers_0.conv"
-                src = h.pl if (h.pl is not None and L.planes_pay(P[name + ".kernel"], h.C, h.M)) else h.t
+                src = h.pl if (h.pl is not None and L.planes_pay(P[name + ".kernel"], h.C, h.M) == h.pl.fmt + 1) else h.t
                 t, OH, OW = L.conv2d(src, P[name + ".kernel"], P[name + ".bias"], B, h.H, h.W, h.C, h.C, 3, upsample=True)
                 if tape is not None:
                     tape.append(("up", dict(name=name, x=h)))
                 h = Act(t, B, OH, OW, h.C)
         hn, st = L.groupnorm(h.t, B, h.HW, P["conv_norm_out.scale"], P["conv_norm_out.bias"], G, 1e-5, True, return_stats=True,
-                             planes=tape is None and L.planes_pay(P["conv_out.kernel"], h.C, h.M))
+                             planes=L.norm_planes(P["conv_out.kernel"], h.C, h.M, tape is not None) if tape is None else 0)
         t, _, _ = L.conv2d(hn, P["conv_out.kernel"], P["conv_out.bias"], B, h.H, h.W, h.C, cfg.out_channels, 3)
         if tape is not None:
             tape.append(("tail", dict(x=h, hn=hn, st=st)))

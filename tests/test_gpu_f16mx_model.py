@@ -1,5 +1,5 @@
-"""The opt-in `f16mx` datapath at model level (lib.DATAPATHS): every plane-eligible forward contraction on the f16 + MX-fp8 cross-term kernel,
-everything else as under bf16x3.
+"""The opt-in `f16mx` datapath at model level (lib.DATAPATHS): every plane-eligible forward contraction with a long reduction (K >= lib.MX_MIN_K)
+on the f16 + MX-fp8 cross-term kernel, everything else as under bf16x3.
   * producers: GroupNorm / LayerNorm / GEMM output stages emit exactly the planes ddpo_split_planes_f16mx makes of their fp32 result;
   * routing: an eligible layer runs the f16mx kernel whether its input arrives as planes or as fp32 (auto-split) — bit-identical outputs, and
     therefore a training forward (fp32 producers, tape) bit-identical to the sampler's forward (plane producers) of the same rows;
@@ -25,9 +25,10 @@ def _rel(a, b):
 
 
 @pytest.fixture(autouse=True)
-def _f16mx():
+def _f16mx(monkeypatch):
     old = L.DATAPATH
     L.DATAPATH = "f16mx"
+    monkeypatch.setattr(L, "MX_MIN_K", 256)         # the tiny test architecture has no reduction of 2560: make its 3x3 convolutions (K >= 288) f16mx layers
     yield
     L.DATAPATH = old
     L.PACKED.clear()
@@ -39,20 +40,23 @@ def test_norm_producers_emit_the_split_of_their_fp32_result(silu):
     B, HW, C, G = 3, 100, 96, 32
     x = torch.randn(B * HW, C, device=DEV, generator=g) * 3 + 0.5
     gamma, beta = torch.randn(C, device=DEV, generator=g), torch.randn(C, device=DEV, generator=g)
-    pl = L.groupnorm(x, B, HW, gamma, beta, G, 1e-5, silu, planes=True)
-    with L.datapath("bf16x3"):
-        y = L.groupnorm(x, B, HW, gamma, beta, G, 1e-5, silu)
-    ref = L.split_planes(y)
+    pl = L.groupnorm(x, B, HW, gamma, beta, G, 1e-5, silu, planes=2)              # 2 = the planes_pay value of an f16mx consumer
+    y = L.groupnorm(x, B, HW, gamma, beta, G, 1e-5, silu)
+    ref = L.split_planes(y, fmt=1)
     assert pl.fmt == 1 and ref.fmt == 1 and torch.equal(pl.hi, ref.hi) and torch.equal(pl.lo, ref.lo)
     assert float((pl.float() - y).abs().max() / y.abs().max()) < 2.0 ** -13
+    pl0 = L.groupnorm(x, B, HW, gamma, beta, G, 1e-5, silu, planes=1)             # a bf16x3 consumer still gets bf16 hi / lo
+    ref0 = L.split_planes(y)
+    assert pl0.fmt == 0 and torch.equal(pl0.hi, ref0.hi) and torch.equal(pl0.lo, ref0.lo)
     xl = torch.randn(130, 320, device=DEV, generator=g)
     gl, bl = torch.randn(320, device=DEV, generator=g), torch.randn(320, device=DEV, generator=g)
-    pl = L.layernorm(xl, gl, bl, planes=True)
-    ref = L.split_planes(L.layernorm(xl, gl, bl))
+    pl = L.layernorm(xl, gl, bl, planes=2)
+    ref = L.split_planes(L.layernorm(xl, gl, bl), fmt=1)
     assert pl.fmt == 1 and torch.equal(pl.hi, ref.hi) and torch.equal(pl.lo, ref.lo)
 
 
-@pytest.mark.parametrize("B,H,Cin,Cout,ks", [(2, 16, 64, 96, 3), (2, 32, 320, 320, 3), (1, 8, 1280, 1280, 3), (3, 12, 96, 160, 1), (4, 77, 768, 320, 0), (2, 640, 320, 1280, 0)])
+@pytest.mark.parametrize("B,H,Cin,Cout,ks", [(2, 16, 320, 96, 3), (2, 32, 320, 320, 3), (1, 8, 1280, 1280, 3), (3, 12, 96, 160, 1), (4, 77, 768, 320, 0), (2, 640, 320, 1280, 0),
+                                             (2, 512, 2560, 640, 0), (2, 16, 64, 96, 3)])
 def test_eligible_layers_run_f16mx_from_planes_and_from_fp32_alike(B, H, Cin, Cout, ks):
     g = torch.Generator(device=DEV).manual_seed(3)
     conv = ks > 0
@@ -62,11 +66,24 @@ def test_eligible_layers_run_f16mx_from_planes_and_from_fp32_alike(B, H, Cin, Co
     w = torch.randn((ks, ks, Cin, Cout) if conv else (Cin, Cout), device=DEV, generator=g) / K ** 0.5
     b = torch.randn(Cout, device=DEV, generator=g)
     L.pack_weights(w, bwd=False)
-    assert L.planes_ok(w, Cin, rows) and L.planes_pay(w, Cin, rows)            # under f16mx the rule is eligibility alone, whatever the rows
     run = (lambda s: L.conv2d(s, w, b, B, H, H, Cin, Cout, ks)[0]) if conv else (lambda s: L.linear(s, w, b))
+    L.MX_MIN_K = 2560                       # the shipped threshold (the fixture lowers it for the tiny architecture)
+    L.PACKED.clear()
+    L.pack_weights(w, bwd=False)
+    if K < L.MX_MIN_K:                      # short reduction: NOT an f16mx layer — exactly the bf16x3 arithmetic, whatever the feed
+        assert not L.mx_layer(w) and L.planes_pay(w, Cin, rows) in (0, 1)
+        with L.datapath("bf16x3"):
+            y3 = run(x)
+        assert torch.equal(run(x), y3) and torch.equal(run(L.split_planes(x)), y3)
+        with pytest.raises(L.DdpoHipError):
+            run(L.split_planes(x, fmt=1))                                      # f16mx planes handed to a bf16x3 layer: refused, not silently converted
+        return
+    assert L.mx_layer(w) and L.planes_ok(w, Cin, rows) and L.planes_pay(w, Cin, rows) == 2 and L.planes_pay(w, Cin, 8 * rows) == 2      # layer property
     y_fp32_in = run(x)                      # auto-split on the way in
-    y_planes = run(L.split_planes(x))       # planes from a producer
+    y_planes = run(L.split_planes(x, fmt=1))       # planes from a producer
     assert torch.equal(y_fp32_in, y_planes)
+    with pytest.raises(L.DdpoHipError):
+        run(L.split_planes(x))              # bf16 planes handed to an f16mx layer
     ref = (torch.nn.functional.conv2d(x.view(B, H, H, Cin).permute(0, 3, 1, 2).double(), w.permute(3, 2, 0, 1).double(), None, padding=ks // 2)
            .permute(0, 2, 3, 1).reshape(rows, Cout) if conv else x.double() @ w.double()) + b.double()
     err = float((y_planes.double() - ref).pow(2).mean().sqrt() / (ref - b.double()).pow(2).mean().sqrt())
@@ -76,11 +93,11 @@ def test_eligible_layers_run_f16mx_from_planes_and_from_fp32_alike(B, H, Cin, Co
     assert not torch.equal(y3, y_planes) and _rel(y3, y_planes) < 3e-4            # really another arithmetic, and close
     # plane-emitting output stage in the datapath's format
     if Cout % 32 == 0 and L.planes_out_ok(w, Cin, rows, Cout):
-        kw = dict(M=rows if not conv else B * H * H, N=Cout, K=K, bias=b, planes_out="both")
+        kw = dict(M=rows if not conv else B * H * H, N=Cout, K=K, bias=b, planes_out="both", planes_fmt=2)
         if conv:
             kw["conv"] = dict(ksize=ks, stride=1, pad=ks // 2, upsample=0, B=B, H=H, W=H, Cin=Cin, OH=H, OW=H)
         out, opl = L.gemm_conv(x, w, **kw)
-        sp = L.split_planes(out)
+        sp = L.split_planes(out, fmt=1)
         assert opl.fmt == 1 and torch.equal(out, y_planes) and torch.equal(opl.hi, sp.hi) and torch.equal(opl.lo, sp.lo)
 
 
@@ -163,6 +180,7 @@ def test_sampler_ratio_is_one_before_the_first_update_tiny():
 def test_unet_sd15_single_sample_32x32_accuracy():
     """The real architecture (SD-1.5) on one 32x32 latent: error of the datapath against float64, next to bf16x3 (emulated in round 3: 7e-5 vs 2e-5)."""
     from ddpo_amd.models.unet import UNet2DCondition, UNetConfig
+    L.MX_MIN_K = 2560                       # the shipped threshold
     op = OU.init_params(OU.unet_param_shapes(OU.SD15), seed=0)
     unet = UNet2DCondition(UNetConfig.named("sd15"), DEV)
     unet.params.load_dict(op)
