@@ -1557,14 +1557,30 @@ extern "C" int ddpo_split_planes_f16mx(const float* x, int ldx, uint16_t* p16, u
   return DDPO_OK;
 }
 
-// f16mx weight planes (include/ddpo_hip.h).  Pass 1: biased exponent of every column's largest |w| -> scale byte; pass 2: the 32x32
+// f16mx weight planes (include/ddpo_hip.h).  Pass 1 (a, b): biased exponent of every column's largest |w| -> scale byte; pass 2: the 32x32
 // tile transpose of the k-blocked packer, writing the f16 plane and the [l8 | h8] byte plane.
-__global__ void __launch_bounds__(256) mx_colscale_kernel(const float* __restrict__ w, int K, int N, uint8_t* __restrict__ scale) {
+// pass 1a: biased exponent of every column's largest |w|.  64 columns x 4 k-lanes per workgroup, the reduction split over blockIdx.y chunks of k
+// and combined with atomicMax on the (non-negative) fp32 bit patterns in a caller-provided uint32 scratch (N words, zeroed).
+__global__ void __launch_bounds__(256) mx_colmax_kernel(const float* __restrict__ w, int K, int N, int k_per_block, uint32_t* __restrict__ colmax) {
+  __shared__ uint32_t red[4][64];
+  const int c = threadIdx.x & 63, kl = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + c;
+  const int k0 = blockIdx.y * k_per_block, k1 = min(K, k0 + k_per_block);
+  uint32_t m = 0;
+  if (n < N)
+    for (int k = k0 + kl; k < k1; k += 4) m = max(m, __float_as_uint(w[(int64_t)k * N + n]) & 0x7FFFFFFFu);
+  red[kl][c] = m;
+  __syncthreads();
+  if (kl == 0 && n < N) {
+    m = max(max(red[0][c], red[1][c]), max(red[2][c], red[3][c]));
+    if (m) atomicMax(colmax + n, m);
+  }
+}
+// pass 1b: scale byte
+__global__ void __launch_bounds__(256) mx_colscale_kernel(const uint32_t* __restrict__ colmax, int N, uint8_t* __restrict__ scale) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
-  uint32_t m = 0;
-  for (int k = 0; k < K; ++k) m = max(m, __float_as_uint(w[(int64_t)k * N + n]) & 0x7FFFFFFFu);
-  int e = (int)(m >> 23);                 // 2^(e - 127) <= max|w| < 2^(e - 126)
+  int e = (int)(colmax[n] >> 23);         // 2^(e - 127) <= max|w| < 2^(e - 126)
   e = min(max(e, 32), 240);               // all-zero / denormal columns: any valid scale; keeps (byte - 11) and 2^(261 - e) in range
   scale[n] = (uint8_t)(e - 7);            // max|w| / 2^(e - 7 - 127) in [128, 256) <= 448 (e4m3 range)
 }
@@ -1600,7 +1616,15 @@ __global__ void __launch_bounds__(256) pack_weights_mx_kernel(const float* __res
 }
 extern "C" int ddpo_pack_weights_f16mx(const float* w, int K, int N, uint16_t* w16, uint16_t* w8, uint8_t* scale, void* stream) {
   if (!w || !w16 || !w8 || !scale || K <= 0 || N <= 0) return DDPO_EINVAL;
-  hipLaunchKernelGGL(mx_colscale_kernel, dim3((N + 255) / 256), dim3(256), 0, as_stream(stream), w, K, N, scale);
+  // the column maxima are gathered in the first N words of the f16 plane (>= 64 bytes per column; overwritten by the pack pass below)
+  uint32_t* colmax = reinterpret_cast<uint32_t*>(w16);
+  if (hipMemsetAsync(colmax, 0, (size_t)N * sizeof(uint32_t), as_stream(stream)) != hipSuccess) return DDPO_ELAUNCH;
+  int ky = (K + 255) / 256;
+  if (ky > 128) ky = 128;
+  const int kpb = ((K + ky - 1) / ky + 3) / 4 * 4;
+  hipLaunchKernelGGL(mx_colmax_kernel, dim3((N + 63) / 64, (K + kpb - 1) / kpb), dim3(256), 0, as_stream(stream), w, K, N, kpb, colmax);
+  DDPO_LAUNCH_CHECK();
+  hipLaunchKernelGGL(mx_colscale_kernel, dim3((N + 255) / 256), dim3(256), 0, as_stream(stream), colmax, N, scale);
   DDPO_LAUNCH_CHECK();
   hipLaunchKernelGGL(pack_weights_mx_kernel, dim3((N + 31) / 32, (K + 31) / 32), dim3(256), 0, as_stream(stream), w, K, N, scale, w16,
                      reinterpret_cast<uint8_t*>(w8));
