@@ -196,3 +196,24 @@ def test_unet_sd15_single_sample_32x32_accuracy():
     rms = lambda a: float((a.double().cpu() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
     print(f"\n[f16mx SD-1.5 forward, 32x32] rms rel err {rms(out):.2e} (bf16x3 {rms(out3):.2e})")
     assert rms(out) < 2e-4 and rms(out3) < rms(out)
+
+
+def test_entrypoint_under_f16mx_keeps_ratio_one(tmp_path, monkeypatch):
+    """pipeline/policy_gradient.py with DDPO_DATAPATH=f16mx (tiny architecture; MX_MIN_K lowered by the fixture so its convolutions are f16mx layers):
+    the first PPO steps of the epoch re-evaluate the sampled trajectory with unchanged weights — approx_kl == 0, clipfrac == 0 — i.e. the training
+    forward (fp32 producers, split on the way in, HIP-graph replay) takes the sampler's arithmetic bit for bit through the real entrypoint."""
+    import importlib
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    monkeypatch.setenv("DDPO_MODEL_CONFIG", "tiny")
+    monkeypatch.setenv("DDPO_DATAPATH", "f16mx")
+    monkeypatch.setenv("DDPO_ALLOW_SYNTHETIC", "1")
+    monkeypatch.chdir(tmp_path)
+    sys.path.insert(0, root)
+    pg = importlib.import_module("pipeline.policy_gradient")
+    out = pg.main(["--dataset", "compressed-animals", "--resolution", "64", "--n_inference_steps", "4", "--sample_batch_size", "2", "--train_batch_size", "2",
+                   "--num_train_epochs", "1", "--save_freq", "100", "--per_prompt_stats_min_count", "2", "--learning_rate", "1e-4", "--logbase", str(tmp_path / "run")])
+    assert L.DATAPATH == "f16mx" and any("mx" in e for e in L.PACKED.values())          # the run really had f16mx layers
+    info = np.load(os.path.join(out["localpath"], "train_info/0_0_0.npy"), allow_pickle=True).item()
+    assert np.isfinite(info["loss"]).all() and info["approx_kl"].max() < 1e-8 and info["clipfrac"].max() == 0.0
