@@ -636,6 +636,8 @@ def pack_weights(w, bwd=True):
                              scale=torch.zeros(N, dtype=torch.uint8, device=w.device))
         m = ent["mx"]
         _check(load().ddpo_pack_weights_f16mx(_p(w), K, N, _p(m["w16"]), _p(m["w8"]), _p(m["scale"]), _stream()), "ddpo_pack_weights_f16mx")
+    else:
+        ent.pop("mx", None)              # re-packed under another datapath: f16mx planes of the OLD weights must not survive
     if ent["w_layout"] == 1:
         _check(load().ddpo_pack_weights_bf16_kblocked(_p(w), K, N, _p(fh), _p(fl), _stream()), "ddpo_pack_weights_bf16_kblocked")
         if bh is not None:               # data-gradient planes keep the original (K, N) order: the plain split of w, no transpose
@@ -674,6 +676,8 @@ def pack_weights_geglu(w, bias):
                            scale=torch.zeros(N, dtype=torch.uint8, device=w.device))
         m = g["mx"]
         _check(load().ddpo_pack_weights_f16mx(_p(wp), K, N, _p(m["w16"]), _p(m["w8"]), _p(m["scale"]), _stream()), "ddpo_pack_weights_f16mx")
+    else:
+        g.pop("mx", None)
     g["stale"] = False
     return True
 
