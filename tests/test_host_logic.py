@@ -233,3 +233,41 @@ def test_planes_pay_rule_and_bench_train_fuse_default(monkeypatch):
     import bench
     assert bench.parse([]).train_fuse == 16 and bench.parse(["--model", "sd21"]).train_fuse == 7
     assert bench.parse(["--train-fuse", "10"]).train_fuse == 10
+
+
+def test_f16mx_routing_is_a_property_of_the_layer(monkeypatch):
+    """Host-side routing of the opt-in f16mx datapath (lib.DATAPATHS): a layer is an f16mx layer iff f16mx weight planes are registered for it
+    (pack_weights does that for K >= MX_MIN_K) — whatever the row count; planes_pay() answers with the FORMAT the producer must emit (0 fp32 /
+    1 bf16 hi-lo / 2 f16mx), norm_planes() keeps fp32 in front of an f16mx layer on the training forward (its weight gradient reads fp32), and the
+    reward towers' fp32-class override maps f16mx to bf16x3."""
+    import torch
+    from ddpo_amd import lib as L
+    monkeypatch.setattr(L, "PLANES", True)
+    monkeypatch.setattr(L, "PLANES_ALL", False)
+    monkeypatch.setattr(L, "TRAIN_PLANES", True)
+    monkeypatch.setattr(L, "DATAPATH", "f16mx")
+    entries = {}
+    def reg(K, N, mx):
+        w = torch.zeros(1)
+        entries[w.data_ptr()] = dict(fwd=(None, None, K), bwd=None, K=K, N=N, **({"mx": {}} if mx else {}))
+        return w
+    monkeypatch.setattr(L, "PACKED", entries)
+    conv = reg(2880, 320, True)            # 3x3 conv: long reduction, f16mx planes registered
+    lin = reg(320, 320, False)             # 64x64-level projection: stays a bf16x3 layer
+    assert L.mx_layer(conv) and not L.mx_layer(lin)
+    assert L.planes_pay(conv, 320, 64) == 2 and L.planes_pay(conv, 320, 1 << 20) == 2          # never a function of the rows
+    assert L.planes_pay(lin, 320, 65536) == 1 and L.planes_pay(lin, 320, 4096) == 0            # the bf16x3 speed rule (bit-identical either way)
+    assert L.norm_planes(conv, 320, 4096, training=False) == 2 and L.norm_planes(conv, 320, 4096, training=True) == 0
+    assert L.norm_planes(lin, 320, 65536, training=True) == 1
+    monkeypatch.setattr(L, "TRAIN_PLANES", False)
+    assert L.norm_planes(lin, 320, 65536, training=True) == 0 and L.norm_planes(lin, 320, 65536, training=False) == 1
+    with L.fp32_class_datapath():
+        assert L.current_datapath() == "bf16x3" and not L.mx_layer(conv) and L.planes_pay(conv, 320, 64) == 1
+    monkeypatch.setattr(L, "DATAPATH", "bf16x3")
+    assert not L.mx_layer(conv) and L.planes_pay(conv, 320, 64) == 1                            # registered planes alone do not switch the arithmetic
+    with pytest.raises(ValueError):
+        L.datapath("fp16")
+    with L.datapath("f16mx"):
+        assert L.mx_layer(conv)
+    import bench
+    assert bench.parse(["--datapath", "f16mx"]).datapath == "f16mx"
