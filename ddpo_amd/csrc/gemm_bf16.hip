@@ -1317,9 +1317,11 @@ static int dispatch_bf16(const ddpo_gemm_desc& d, const uint16_t* w_hi, const ui
     const long ntall = (long)((d.M + 255) / 256) * (d.N / 320), nwide = (long)((d.M + 127) / 128) * (d.N / 320);
     const double eff_tall = (double)ntall / (double)(((ntall + 255) / 256) * 256), eff_wide = (double)nwide / (double)(((nwide + 255) / 256) * 256);
     // (bf16x3 only.  An f16mx tall loop — the weight operand's ks = 1 fragments streamed per column block beside the 160 accumulators — was
-    // built twice in round 3: correct, but the compiler spills ~60 registers of the convolution bookkeeping around it, and their reloads sit
-    // behind the LDS-DMA requests on the in-order vmcnt counter, so every k-tile waits for its own prefetch: 0.326 ms against 0.321 (bf16x3
-    // tall) / 0.317 (f16mx 128x320) on conv 320->320 @64^2, profiles/r03_probe_mx_tall.log.  It needs the tap bookkeeping out of VGPRs first.)
+    // built twice in round 3: correct, but ~20 registers short at two waves per SIMD.  The compiler spills 44-58 values around the 8-register
+    // operands of the scaled MFMA (0 without the 8-bit weight fragments, 16 with one 8-bit activation fragment, the same 58 with the convolution
+    // bookkeeping compiled out — it is the fragments, not the addressing), and the reloads sit behind the LDS-DMA requests on the in-order
+    // vmcnt counter, so every k-tile waits for its own prefetch: 0.326 ms against 0.321 (bf16x3 tall) / 0.317 (f16mx 128x320) on conv 320->320
+    // @64^2, profiles/r03_probe_mx_tall.log.  The f16mx tall tile wants FOUR waves of 128 x 160 (one per SIMD, accumulators in AGPRs).)
     if (tall_mode && npass == 3 && d.N % 320 == 0 && d.epilogue == 0 && ntall >= 200 && eff_tall * 1.08 >= eff_wide)
       return launch_bf16_tall<5>(d, w_hi, w_lo, ldw, st);
   }
