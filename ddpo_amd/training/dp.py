@@ -124,6 +124,28 @@ class DataParallel:
             out[k] = out[k][rows, perms]
         return out
 
+    def shuffled_rows(self, devs, train_batch_size, np_random=np.random):
+        """`my_rows(shuffle(devs))` without materialising the shuffled GLOBAL set: the numpy stream is drawn exactly as `shuffle` draws it (one
+        batch permutation, then one time permutation per sample of the whole set), but only this rank's rows are gathered.  single_host with
+        num_inner_epochs == 1 (the default) uses it so that a rank holds the gathered global copy plus its own rows, not two global copies
+        (an inner epoch after the first shuffles the already shuffled set, which needs the full copy: `shuffle` + `my_rows`)."""
+        total, T = devs["log_probs"].shape
+        dev = devs["log_probs"].device
+        perm = np_random.permutation(total)
+        perms = np.array([np_random.permutation(T) for _ in range(total)])
+        if self.single_host and self.world > 1:
+            assert total % (self.world * train_batch_size) == 0
+            mine = np.arange(total).reshape(-1, self.world, train_batch_size)[:, self.rank].reshape(-1)
+        else:
+            mine = np.arange(total)
+        idx = torch.as_tensor(perm[mine], device=dev)
+        out = {k: v[idx] for k, v in devs.items()}
+        tperm = torch.as_tensor(perms[mine], device=dev)
+        rows = torch.arange(len(mine), device=dev)[:, None]
+        for k in ("latents", "next_latents", "log_probs", "ts"):
+            out[k] = out[k][rows, tperm]
+        return out
+
     def my_rows(self, devs, train_batch_size):
         """`x.reshape(-1, n_devices, train_batch_size, ...)[:, d]` (:396-404): the rows device d trains on, in mini-batch order.
         multi_host: every row is mine."""

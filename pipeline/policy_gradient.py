@@ -227,8 +227,13 @@ def main(argv=None):
             assert total_batch_size == args.num_sample_batches_per_epoch * n_devices * args.sample_batch_size * (n_workers if dp.single_host else 1)
             assert num_timesteps == args.n_inference_steps
             # shuffle samples along the batch dimension, then along time independently for each sample; keep this rank's rows
-            devs = dp.shuffle(devs)
-            mine = dp.my_rows(devs, args.train_batch_size)
+            if args.num_inner_epochs == 1:
+                mine = dp.shuffled_rows(devs, args.train_batch_size)          # same draws, only this rank's rows gathered
+                if dp.single_host:
+                    devs = None                                               # the gathered global copy is not needed again this epoch
+            else:
+                devs = dp.shuffle(devs)
+                mine = dp.my_rows(devs, args.train_batch_size)
             total_batch_size = mine["log_probs"].shape[0]
             num_train_ts = int(num_timesteps * args.train_timestep_ratio)
             n_mini = total_batch_size // (n_devices * args.train_batch_size)

@@ -192,3 +192,24 @@ def test_global_order_turns_rank_major_gather_into_the_one_process_order(world, 
     total = world * nb * sbs
     rows = [np.arange(total).reshape(-1, world, tb)[:, d].reshape(-1) for d in range(world)]
     assert np.array_equal(np.sort(np.concatenate(rows)), np.arange(total))
+
+
+@pytest.mark.parametrize("mode,world", [("multi_host", 1), ("multi_host", 2), ("single_host", 2), ("single_host", 4)])
+def test_shuffled_rows_equals_shuffle_then_my_rows(mode, world):
+    """`shuffled_rows` (one inner epoch: only this rank's rows of the shuffled set are gathered) draws the numpy stream exactly like `shuffle`
+    and returns what `my_rows(shuffle(...))` returns, for every rank — so the entrypoint's memory saving changes no sample order."""
+    import torch
+    from ddpo_amd.training.dp import DataParallel
+    total, T, tb = 16, 5, 2
+    g = torch.Generator().manual_seed(1)
+    base = {"latents": torch.randn(total, T, 4, 2, 2, generator=g), "next_latents": torch.randn(total, T, 4, 2, 2, generator=g),
+            "log_probs": torch.randn(total, T, generator=g), "ts": torch.randint(0, 1000, (total, T), generator=g),
+            "embeds": torch.randn(total, 7, 3, generator=g), "advantages": torch.randn(total, generator=g)}
+    for rank in range(world):
+        dp = DataParallel(mode, rank, world)
+        r1, r2 = np.random.RandomState(7), np.random.RandomState(7)
+        ref = dp.my_rows(DataParallel.shuffle(base, r1), tb)
+        got = dp.shuffled_rows(base, tb, r2)
+        assert set(got) == set(ref) and all(torch.equal(got[k], ref[k]) for k in ref)
+        assert r1.randint(1 << 30) == r2.randint(1 << 30)                      # the stream is left in the same state
+        assert got["log_probs"].shape[0] == (total // world if mode == "single_host" else total)
