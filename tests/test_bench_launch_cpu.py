@@ -19,17 +19,18 @@ def _env(**kw):
 
 
 @pytest.mark.timeout(300)
-def test_gpus_2_self_launches_two_ranks_and_times_the_allreduce():
-    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--mode", "comm", "--backend", "gloo", "--comm-mib", "1", "--steps", "2",
+@pytest.mark.parametrize("world", [2, 4])
+def test_gpus_n_self_launches_n_ranks_and_times_the_allreduce(world):
+    r = subprocess.run([sys.executable, BENCH, "--gpus", str(world), "--mode", "comm", "--backend", "gloo", "--comm-mib", "1", "--steps", "2",
                         "--warmup", "1"], capture_output=True, text=True, env=_env(), timeout=280)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout              # ONE JSON line, from rank 0 only
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["config"]["parallelism"] == "dp2"
+    assert d["n_gpus"] == world and d["rccl_ranks"] == world and d["config"]["parallelism"] == f"dp{world}"
     ar = d["allreduce"]
-    assert ar["ranks"] == 2 and ar["sum_correct"] is True and ar["bytes"] == 1 << 20 and ar["ms"] > 0
-    assert ar["busbw_GBps"] == pytest.approx(ar["algbw_GBps"])          # 2 (W-1)/W = 1 at W = 2
+    assert ar["ranks"] == world and ar["sum_correct"] is True and ar["bytes"] == 1 << 20 and ar["ms"] > 0
+    assert ar["busbw_GBps"] == pytest.approx(ar["algbw_GBps"] * 2 * (world - 1) / world)          # ring bus bandwidth: 2 (W-1)/W of the algorithm bandwidth
     for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
         assert k in d
 
