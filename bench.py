@@ -53,9 +53,10 @@ def parse(argv=None):
     ap.add_argument("--resolution", type=int, default=None, help="default: 512 (sd15), 768 (sd21), 64 (tiny)")
     ap.add_argument("--n-inference-steps", type=int, default=50)
     ap.add_argument("--sample-batch-size", type=int, default=8)
-    ap.add_argument("--datapath", default=os.environ.get("DDPO_DATAPATH", "bf16x3"), choices=["fp32", "bf16x3", "bf16", "f16mx"],
-                    help="contraction datapath: exact-fp32 MFMA, bf16-split MFMA x3 (fp32-accurate to ~1e-5, default), single-pass bf16, "
-                         "f16mx (opt-in: f16 MFMA + one MX-scaled 8-bit MFMA for the cross terms on every plane-eligible forward layer, ~7e-5)")
+    ap.add_argument("--datapath", default=None, choices=["fp32", "bf16x3", "bf16", "f16mx"],
+                    help="contraction datapath: exact-fp32 MFMA, bf16-split MFMA x3 (fp32-accurate to ~1e-5), single-pass bf16, f16mx (f16 MFMA + one "
+                         "MX-scaled 8-bit MFMA for the cross terms on the long-reduction layers, bf16x3 elsewhere; 4e-5 on a U-Net forward).  "
+                         "Default: DDPO_DATAPATH, else the datapath the entrypoints ship (ddpo_amd.lib.SHIPPED_DATAPATH = f16mx since round 4)")
     ap.add_argument("--mode", default="sample", choices=["sample", "train", "epoch", "comm"],
                     help="sample (headline): images/sec of the sampling hot path; train: PPO sample-timesteps/sec of train_step; "
                          "epoch: one sample batch + its PPO micro-steps + optimizer updates (gradient all-reduce included); "
@@ -70,8 +71,12 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-train-extra", action="store_true", help="skip the short train-step measurement attached to the headline line")
-    ap.add_argument("--no-f16mx-extra", action="store_true", help="skip the opt-in f16mx datapath's sampling measurement attached to the headline line (extra.f16mx)")
+    ap.add_argument("--no-alt-datapath-extra", "--no-f16mx-extra", dest="no_alt_extra", action="store_true",
+                    help="skip the sampling measurement of the OTHER fp32-class datapath attached to the headline line (extra.bf16x3 / extra.f16mx)")
     args = ap.parse_args(argv)
+    if args.datapath is None:
+        from ddpo_amd import lib as _L
+        args.datapath = _L.shipped_datapath()
     if args.resolution is None:
         args.resolution = {"sd15": 512, "sd21": 768}.get(args.model, 64)
     if args.train_fuse is None:
@@ -562,22 +567,35 @@ def main(argv=None):
         unet(lat2, ts2, ctx2)
         torch.cuda.synchronize()
         recs, L.PROFILE = L.PROFILE, None
-        dom = args.datapath if any(r[3] == args.datapath for r in recs) else "fp32"
-        recs = [r for r in recs if r[3] == dom]                    # the dominant kernel family of this datapath
+        # the dominant kernel family = every launch of the bf16-MFMA GEMM / conv template of this datapath (under f16mx: its f16 + MX-fp8
+        # instantiation on the long reductions AND the bf16x3 instantiations on the rest); the exact-fp32 launches (conv_in / conv_out) are not in it
+        fams = {"fp32": ("fp32",), "bf16": ("bf16",), "bf16x3": ("bf16x3",), "f16mx": ("f16mx", "bf16x3")}[args.datapath]
+        dom = args.datapath if any(r[3] in fams for r in recs) else "fp32"
+        recs = [r for r in recs if r[3] in (fams if dom != "fp32" else ("fp32",))]
         flops = sum(r[2] for r in recs)
         ms = sum(r[0].elapsed_time(r[1]) for r in recs)
         achieved = flops / (ms * 1e-3) / 1e12
-        passes = {"fp32": 1, "bf16": 1, "bf16x3": 3, "f16mx": 2}[dom]          # f16mx: 2 f16 + 1 fp8 (double rate) per block and k-tile = 2 pass-equivalents
+        # matrix-pipe pass-equivalents per algorithmic FLOP, FLOP-weighted over the family: 3 on bf16x3 launches, 2 on f16mx launches (2 f16 MFMAs
+        # + 1 double-rate 8-bit MFMA per block and k-tile), 1 on single-pass kernels
+        pw = {"fp32": 1, "bf16": 1, "bf16x3": 3, "f16mx": 2}
+        passes = sum(pw[r[3]] * r[2] for r in recs) / max(flops, 1.0)
+        by_fam = {}
+        for r in recs:
+            e = by_fam.setdefault(r[3], [0, 0.0, 0.0])
+            e[0] += 1; e[1] += r[2]; e[2] += r[0].elapsed_time(r[1])
         peak = FP32_MFMA_PEAK_TFLOPS if dom == "fp32" else BF16_MFMA_PEAK_TFLOPS
-        kname = "gemm_conv_kernel (v_mfma_f32_32x32x2_f32)" if dom == "fp32" else \
-            f"gemm_conv_bf16_buf_kernel<128x320 | 128x128 | 128x64, NPASS={passes}> (v_mfma_f32_32x32x16_bf16)"
+        kname = {"fp32": "gemm_conv_kernel (v_mfma_f32_32x32x2_f32)",
+                 "f16mx": "gemm_conv_bf16_buf_kernel<256x320 | 128x320 | 128x128 | 128x64>: NPASS=4 (v_mfma_f32_32x32x16_f16 + v_mfma_scale_f32_32x32x64_f8f6f4) on K >= 2560 "
+                          "layers, NPASS=3 (v_mfma_f32_32x32x16_bf16) elsewhere"}.get(
+            dom, f"gemm_conv_bf16_buf_kernel<256x320 | 128x320 | 128x128 | 128x64, NPASS={pw[dom]}> (v_mfma_f32_32x32x16_bf16)")
         traffic, traffic_note = roofline_traffic(dom)
         roofline = {"bound": "mfma", "kernel": kname, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                     "frac": achieved / peak, "traffic": traffic, "traffic_note": traffic_note,
                     "algorithmic_bytes_per_launch": sum(r[4] for r in recs) / max(len(recs), 1),
                     "launches": len(recs), "avg_launch_ms": ms / max(len(recs), 1),
                     "algorithmic_gflop_per_launch": flops / max(len(recs), 1) / 1e9,
-                    "mfma_passes_per_algorithmic_flop": passes, "mfma_issue_frac": passes * achieved / peak}
+                    "mfma_passes_per_algorithmic_flop": passes, "mfma_issue_frac": passes * achieved / peak,
+                    "by_instantiation": {k: {"launches": v[0], "tflops": v[1] / (v[2] * 1e-3) / 1e12 if v[2] else None, "ms": v[2]} for k, v in by_fam.items()}}
     ar = time_allreduce(comm, unet.params.flat.numel()) if comm.dist is not None else None
     extra = {}
     if not args.no_train_extra and args.model in ("sd15", "sd21"):
@@ -594,21 +612,21 @@ def main(argv=None):
     if rank != 0:
         comm.close()
         return
-    if world == 1 and args.datapath == "bf16x3" and not args.no_f16mx_extra and not args.no_train_extra and args.model == "sd15":
-        # the opt-in f16mx datapath (long reductions on the f16 + MX-fp8 kernel) on the same workload, in a fresh process: reported NEXT to the
-        # headline, never as it
+    alt = {"f16mx": "bf16x3", "bf16x3": "f16mx"}.get(args.datapath)
+    if world == 1 and alt and not args.no_alt_extra and not args.no_train_extra and args.model == "sd15":
+        # the OTHER fp32-class datapath on the same workload, in a fresh process: reported NEXT to the headline, never as it
+        # (f16mx ships since round 4; bf16x3 is the selectable three-pass datapath)
         try:
-            cmd = [sys.executable, os.path.abspath(__file__), "--datapath", "f16mx", "--steps", str(args.steps), "--warmup", str(args.warmup),
+            cmd = [sys.executable, os.path.abspath(__file__), "--datapath", alt, "--steps", str(args.steps), "--warmup", str(args.warmup),
                    "--no-cpu-baseline", "--no-train-extra", "--no-roofline", "--sample-batch-size", str(args.sample_batch_size)]
             env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
             pr = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
             line = [l for l in pr.stdout.splitlines() if l.startswith('{"metric"')][-1]
             dj = json.loads(line)
-            extra["f16mx"] = {"value": dj["value"], "unit": dj["unit"], "ms_per_step": dj["ms_per_step"], "dtype": dj["dtype"],
-                              "note": "opt-in datapath (--datapath f16mx): f16 MFMA + one MX-scaled 8-bit MFMA for the cross terms on the plane-eligible "
-                                      "forward layers with K >= 2560, bf16x3 elsewhere; U-Net forward error 4.2e-5 vs 2.0e-5 (bf16x3) against float64"}
+            extra[alt] = {"value": dj["value"], "unit": dj["unit"], "ms_per_step": dj["ms_per_step"], "dtype": dj["dtype"],
+                          "note": f"the same workload with --datapath {alt} (U-Net forward error against float64: f16mx 4.2e-5, bf16x3 2.0e-5)"}
         except Exception as exc:
-            extra["f16mx"] = {"error": f"{type(exc).__name__}: {exc}"}
+            extra[alt] = {"error": f"{type(exc).__name__}: {exc}"}
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args)
@@ -618,7 +636,7 @@ def main(argv=None):
         "metric": f"sampled images/sec ({args.resolution}^2, {args.n_inference_steps} DDIM steps)", "value": value, "unit": "images/sec", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": {"fp32": "f32", "bf16x3": "f32 (bf16x3-split MFMA)", "bf16": "bf16 products, f32 accumulate",
-                                                                 "f16mx": "f32 (f16 MFMA + MX-fp8 cross terms on plane-eligible forward layers, bf16x3 elsewhere)"}[args.datapath],
+                                                                 "f16mx": "f32 (f16mx: f16 MFMA + MX-fp8 cross terms on the long-reduction conv/GEMM layers, bf16x3-split MFMA elsewhere)"}[args.datapath],
         "data": "synthetic",
         "config": {"workload": f"BASELINE configs[{1 if args.model == 'sd15' else 4}]: {'compressed-animals' if args.model == 'sd15' else 'neg_jpeg'} geometry, "
                                f"{args.model} U-Net+VAE (random init), "
@@ -628,8 +646,9 @@ def main(argv=None):
                                 "bf16x3": "conv/GEMM: bf16x3-split MFMA (a_lo*b_hi + a_hi*b_lo + a_hi*b_hi, fp32 accumulate, ~1e-5 rel; "
                                           "= XLA HIGH, the reference ran TPU DEFAULT = 1 pass); attention (d in 40/64/80): same split; d=160 attention and norms: exact fp32",
                                 "bf16": "conv/GEMM: single-pass bf16 MFMA, fp32 accumulate (= XLA TPU DEFAULT precision)",
-                                "f16mx": "plane-eligible forward conv/GEMM: f16 MFMA + ONE MX-scaled 8-bit MFMA carrying both cross terms (a_h*b_h + a_h8*b_l8 + a_l8*b_h8, "
-                                         "~7e-5 rel on a U-Net forward); every other contraction as under bf16x3 (opt-in datapath, DESIGN.md section 6a)"}[args.datapath],
+                                "f16mx": "shipped default (lib.SHIPPED_DATAPATH): conv/GEMM layers with a reduction K >= 2560 run a_h*b_h on the f16 MFMA + ONE MX-scaled "
+                                         "8-bit MFMA carrying both cross terms (a_h8*b_l8 + a_l8*b_h8); every other contraction, the attention and all gradients "
+                                         "as under bf16x3; 4.2e-5 rel on an SD-1.5 U-Net forward against float64 (bf16x3 2.0e-5, north-star gate 1e-3)"}[args.datapath],
                    "parallelism": f"dp{world}",
                    "global_batch": world * B},
         "end_to_end_tflops": None if tflop_per_image is None else value * tflop_per_image,

@@ -1144,6 +1144,17 @@ static bool planes_out_ok(const ddpo_gemm_desc& d) {
   return true;
 }
 
+// Host-side launch counters per tile class (ABI v10, ddpo_gemm_tile_launch_counts): which instantiation a layer geometry was routed to is
+// otherwise invisible to a caller — tests/test_gpu_headline_geometry.py asserts that the bench geometry really ran the tall tile.
+enum { TC_TALL = 0, TC_WIDE = 1, TC_128 = 2, TC_64 = 3, TC_GENERIC = 4, TC_SPLITK_REDUCE = 5, TC_MX = 6, TC_COUNT = 8 };
+static unsigned long long g_tile_launches[TC_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0};
+extern "C" int ddpo_gemm_tile_launch_counts(unsigned long long* out_host, int n) {
+  if (!out_host || n < TC_COUNT) return DDPO_EINVAL;
+  for (int i = 0; i < TC_COUNT; ++i) out_host[i] = __atomic_load_n(&g_tile_launches[i], __ATOMIC_RELAXED);
+  return DDPO_OK;
+}
+static inline void count_tile(int cls) { __atomic_fetch_add(&g_tile_launches[cls], 1ull, __ATOMIC_RELAXED); }
+
 // buffer-addressed fast path: k-tiles never straddle a tap and every byte offset fits the 31-bit buffer range
 static bool g_force_generic = false;          // only ever set through the debug hook below (probe builds)
 static bool buf_path_ok(const ddpo_gemm_desc& d, int ldw) {
@@ -1198,10 +1209,13 @@ static int launch_bf16(const ddpo_gemm_desc& d, const uint16_t* w_hi, const uint
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
+  count_tile(BN == 128 ? TC_128 : TC_64);
+  if constexpr (NPASS == 4) count_tile(TC_MX);
   if constexpr (APL != 0) {                // the plane-fed entry points have already checked buf_path_ok
     hipLaunchKernelGGL((gemm_conv_bf16_buf_kernel<BM, BN, NPASS, 0, WM, WN, true, APL>), dim3(nblk, splits), dim3(64 * WM * WN), lds, st, d, w_hi,
                        w_lo, ldw, tiles_m, tiles_n, nblk, ktps, part);
   } else {
+    if (!buf_path_ok(d, ldw)) count_tile(TC_GENERIC);
     if (buf_path_ok(d, ldw))
       hipLaunchKernelGGL((gemm_conv_bf16_buf_kernel<BM, BN, NPASS, 0, WM, WN, true, APL>), dim3(nblk, splits), dim3(64 * WM * WN), lds, st, d, w_hi,
                          w_lo, ldw, tiles_m, tiles_n, nblk, ktps, part);
@@ -1216,6 +1230,7 @@ static int launch_bf16(const ddpo_gemm_desc& d, const uint16_t* w_hi, const uint
   if (splits > 1) {
     int64_t blocks = ((int64_t)d.M * (d.N >> 2) + 255) / 256;
     if (blocks > 4096) blocks = 4096;
+    count_tile(TC_SPLITK_REDUCE);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)blocks), dim3(256), 0, st, d, part, splits);
     DDPO_LAUNCH_CHECK();
   }
@@ -1259,12 +1274,15 @@ static int launch_bf16_wide(const ddpo_gemm_desc& d, const uint16_t* w_hi, const
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
+  count_tile(TC_WIDE);
+  if constexpr (NPASS == 4) count_tile(TC_MX);
   hipLaunchKernelGGL((gemm_conv_bf16_buf_kernel<BM, BN, NPASS, 0, WM, WN, true, APL>), dim3(nblk, splits), dim3(64 * WM * WN), lds, st, d, w_hi,
                      w_lo, ldw, tiles_m, tiles_n, nblk, ktps, part);
   DDPO_LAUNCH_CHECK();
   if (splits > 1) {
     int64_t blocks = ((int64_t)d.M * (d.N >> 2) + 255) / 256;
     if (blocks > 4096) blocks = 4096;
+    count_tile(TC_SPLITK_REDUCE);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)blocks), dim3(256), 0, st, d, part, splits);
     DDPO_LAUNCH_CHECK();
   }
@@ -1286,6 +1304,7 @@ static int launch_bf16_tall(const ddpo_gemm_desc& d, const uint16_t* w_hi, const
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
+  count_tile(TC_TALL);
   hipLaunchKernelGGL((gemm_conv_bf16_buf_kernel<BM, BN, 3, 0, WM, WN, true, APL>), dim3(nblk, 1), dim3(64 * WM * WN), lds, st, d, w_hi, w_lo, ldw,
                      tiles_m, tiles_n, nblk, nk_total, (float*)nullptr);
   DDPO_LAUNCH_CHECK();

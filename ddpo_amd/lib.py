@@ -39,12 +39,13 @@ class GemmDesc(ctypes.Structure):
                 ("w_scale", c_void_p), ("planes_fmt", c_int), ("colsum", c_void_p), ("aux_out", c_void_p)]
 
 
-ABI_VERSION = 9          # must equal ddpo_abi_version() of the loaded library (include/ddpo_hip.h)
+ABI_VERSION = 10         # must equal ddpo_abi_version() of the loaded library (include/ddpo_hip.h)
 
 _SIGS = {
     "ddpo_abi_version": (c_int, []),
     "ddpo_sizeof_gemm_desc": (c_size_t, []),
     "ddpo_sizeof_ddim_consts": (c_size_t, []),
+    "ddpo_gemm_tile_launch_counts": (c_int, [c_void_p, c_int]),
     "ddpo_threefry_bits_host": (c_int, [c_uint32, c_uint32, c_int64, c_void_p]),
     "ddpo_threefry_normal": (c_int, [c_uint32, c_uint32, c_void_p, c_void_p, c_int64, c_void_p]),
     "ddpo_ddim_step_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, POINTER(DdimConsts),
@@ -127,7 +128,21 @@ DATAPATH = os.environ.get("DDPO_DATAPATH", "fp32")
 
 
 DATAPATHS = ("fp32", "bf16x3", "bf16", "f16mx")
-# "f16mx" (round 3, opt-in): every plane-eligible forward contraction with a LONG reduction (K >= MX_MIN_K: all 3x3 convolutions, FF2 of the
+# The datapath the entrypoints (pipeline/*.py), load_unet and bench.py select when DDPO_DATAPATH is not set — since round 4 the f16mx
+# operator (bf16x3 stays selectable: DDPO_DATAPATH=bf16x3).  The full-size parity tests are parametrised over this name, so whatever ships
+# is what is held to the oracle (tests/test_gpu_train_parity.py, test_gpu_model.py, test_gpu_rwr.py, test_gpu_headline_geometry.py).
+SHIPPED_DATAPATH = "f16mx"
+
+
+def shipped_datapath():
+    """DDPO_DATAPATH if set, else SHIPPED_DATAPATH."""
+    name = os.environ.get("DDPO_DATAPATH") or SHIPPED_DATAPATH
+    if name not in DATAPATHS:
+        raise ValueError(f"DDPO_DATAPATH={name!r}: expected one of {DATAPATHS}")
+    return name
+
+
+# "f16mx" (round 3; the shipped default since round 4): every plane-eligible forward contraction with a LONG reduction (K >= MX_MIN_K: all 3x3 convolutions, FF2 of the
 # lower levels — a property of the layer, never of the batch) runs on the f16 + MX-fp8 cross-term kernel (ddpo_gemm_conv_fwd_f16mx_planes); its
 # activation planes come from the producing kernel (GroupNorm / LayerNorm / GEMM output stages, which ask planes_pay() for the consumer's
 # format) or, when the producer wrote fp32 (training forward: the weight gradients read the fp32 tensor), from ddpo_split_planes_f16mx on the
@@ -328,7 +343,7 @@ def split_planes(x, fmt=0):
 # kernels.  Validated operator by operator (tests/test_gpu_f16mx.py, tools/native/kernel_probe mx) and measured — 1.2-1.4x on the
 # long-reduction convolutions of the 32x32 / 16x16 levels, ~1.0x at the 64x64 level, whose tiles are bound by the operand stream
 # (profiles/r03_probe_mx.log).  The raw wrappers below are what the tests and tools call; the MODELS reach the kernel through
-# gemm_conv / linear_geglu under the opt-in `f16mx` datapath (DATAPATHS above; bf16x3 stays the default).
+# gemm_conv / linear_geglu under the `f16mx` datapath (DATAPATHS above; the shipped default since round 4).
 def pack_weights_f16mx(w):
     """fp32 weight (..., N) viewed as (K, N) -> dict(w16, w8, scale, K, N): the f16mx weight planes of ddpo_pack_weights_f16mx."""
     N = w.shape[-1]
@@ -382,6 +397,17 @@ def gemm_conv_f16mx(planes, wp, *, M, bias=None, residual=None, conv=None, out=N
 # When set to a list, every ddpo_gemm_conv_fwd launch appends (start_event, end_event, algorithmic_flops);
 # used by bench.py for the live roofline measurement of the dominant kernel.
 PROFILE = None
+
+
+TILE_CLASSES = ("tall_256x320", "wide_128x320", "t128x128", "t128x64", "generic_loader", "splitk_reduce", "f16mx", "reserved")
+
+
+def gemm_tile_launch_counts():
+    """Cumulative host-side launch counts of the bf16-MFMA GEMM / conv template per tile class (ddpo_gemm_tile_launch_counts)."""
+    import ctypes as _ct
+    buf = (_ct.c_ulonglong * 8)()
+    _check(load().ddpo_gemm_tile_launch_counts(_ct.cast(buf, c_void_p), 8), "ddpo_gemm_tile_launch_counts")
+    return dict(zip(TILE_CLASSES, (int(v) for v in buf)))
 
 
 class DdpoHipError(RuntimeError):
@@ -740,7 +766,8 @@ def linear_geglu(x, w, out=None, planes_out=False, pre_out=False):
         _check(load().ddpo_gemm_conv_fwd_bf16(byref(d), _p(g["hi"]), _p(g["lo"]), K, npass, None, 0, _stream()), "ddpo_gemm_conv_fwd_bf16")
     if PROFILE is not None:
         e1.record()
-        PROFILE.append((e0, e1, 2.0 * M * N * K, current_datapath(), 4.0 * (M * K + K * N + M * N // 2)))
+        fam = "f16mx" if (pl is not None and pl.fmt == 1) else ("bf16x3" if _x3() else current_datapath())
+        PROFILE.append((e0, e1, 2.0 * M * N * K, fam, 4.0 * (M * K + K * N + M * N // 2)))
     res = opl if planes_out else out
     return (res, pre) if pre_out else res
 
@@ -844,7 +871,9 @@ def gemm_conv(src, w, *, M, N, K, bias=None, rowbias=None, rows_per_batch=0, res
         a_bytes = 4.0 * (conv["B"] * conv["H"] * conv["W"] * conv["Cin"] if conv else M * K)       # unique operand bytes
         w_bytes = (4.0 if route is None else (4.0 if _x3() else 2.0)) * K * N
         io_bytes = a_bytes + w_bytes + 4.0 * M * N * (2 if residual is not None else 1)
-        PROFILE.append((e0, e1, 2.0 * M * N * K, "fp32" if route is None else current_datapath(), io_bytes))
+        # family tag: "fp32" (exact-fp32 kernel), "f16mx" (this launch ran the f16 + MX-fp8 kernel), else the bf16 datapath's name
+        fam = "fp32" if route is None else ("f16mx" if (pl is not None and pl.fmt == 1) else ("bf16x3" if _x3() else current_datapath()))
+        PROFILE.append((e0, e1, 2.0 * M * N * K, fam, io_bytes))
     if planes_out == "only":
         return opl
     return (out, opl) if planes_out == "both" else out

@@ -114,7 +114,7 @@ class GradBucketer:
     depend on the segmentation (rounding-level differences, identical on every rank) (tests/test_distributed_cpu.py: gloo, worlds 2 and
     4, random progress)."""
 
-    def __init__(self, flat, bucket_numel=64 << 20, group=None):
+    def __init__(self, flat, bucket_numel=64 << 20, group=None):          # 64 Mi floats = 256 MiB (DDPO_GRAD_BUCKET_MIB)
         self.flat, self.group = flat, group
         n = flat.numel()
         bn = max(1, int(bucket_numel))

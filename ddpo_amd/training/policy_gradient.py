@@ -82,14 +82,17 @@ class AccumulatingTrainState:
         return 1
 
     def overlap_bucketer(self):
-        """A GradBucketer for the backward pass that closes an optimizer update (world > 1, DDPO_GRAD_OVERLAP != 0), else None: its
+        """A GradBucketer for the backward pass that closes an optimizer update (a process group exists — world > 1, or the forced one-rank
+        group of the RCCL tests — and DDPO_GRAD_OVERLAP != 0), else None: its
         bucketed all-reduce runs on a side stream behind the rest of that backward (training/distributed.GradBucketer); the blocking
         single all-reduce below stays the path of graph-replayed steps and of DDPO_GRAD_OVERLAP=0."""
         import os
-        if self.world() <= 1 or os.environ.get("DDPO_GRAD_OVERLAP", "1") == "0":
+        from .distributed import GradBucketer, _through_backend
+        # world 1 only under DDPO_FORCE_DIST=1 (a one-rank RCCL group: the side stream, the per-bucket async all_reduce and finish() all
+        # execute on hardware, tests/test_gpu_rccl_single_rank.py); a plain single process has no process group and keeps graph replay
+        if not _through_backend() or os.environ.get("DDPO_GRAD_OVERLAP", "1") == "0":
             return None
-        from .distributed import GradBucketer
-        mib = float(os.environ.get("DDPO_GRAD_BUCKET_MIB", "256"))
+        mib = float(os.environ.get("DDPO_GRAD_BUCKET_MIB", "256"))      # 256 MiB = 14 buckets over the 3.44 GB SD-1.5 gradient
         return GradBucketer(self.grad_acc.flat, bucket_numel=int(mib * (1 << 20)) // 4, group=self.process_group)
 
     def apply_gradients(self, *, grads=None, do_update, reduced=False):

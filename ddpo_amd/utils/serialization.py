@@ -19,7 +19,7 @@ What `pretrained_model` may be (the reference hands it to `FlaxStableDiffusionPi
   `pipeline.synthetic_weights` is True and the entrypoint records that in args.json and in every checkpoint.
 
 `dtype` (reference :343-350 casts every parameter tree to it and computes in it): "float32" keeps fp32 parameters on the
-fp32-equivalent datapaths (lib.DATAPATH: bf16x3 by default in the entrypoint, or exact fp32); "bfloat16" rounds the
+fp32-equivalent datapaths (lib.DATAPATH: lib.SHIPPED_DATAPATH in the entrypoints, bf16x3 or exact fp32 on request); "bfloat16" rounds the
 parameters to bf16 and selects the single-pass bf16 MFMA datapath with fp32 accumulation — what XLA does with bf16
 parameters.  Activations between layers stay fp32 here (XLA would round them to bf16 as well): strictly more precise.
 
@@ -191,7 +191,7 @@ def load_unet(loadpath=None, epoch="latest", pretrained_model="duongna/stable-di
     elif dname in ("float32", "fp32", "f32"):
         bf16_params = False
         if L.DATAPATH == "bf16":      # an earlier load_unet(dtype=bfloat16) in this process: back to the fp32-class default
-            L.DATAPATH = os.environ.get("DDPO_DATAPATH", "bf16x3")
+            L.DATAPATH = L.shipped_datapath()
     else:
         raise ValueError(f"dtype must be float32 or bfloat16 (reference config/base.py:71), got {dtype!r}")
     family = model_family(pretrained_model)

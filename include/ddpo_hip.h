@@ -27,6 +27,12 @@ extern "C" {
 int ddpo_abi_version(void);
 size_t ddpo_sizeof_gemm_desc(void);     /* for binding self-checks (ctypes / cffi struct mirrors) */
 size_t ddpo_sizeof_ddim_consts(void);
+/* ABI v10.  Cumulative HOST-side launch counts of the bf16-MFMA GEMM / conv template per tile class since the library was loaded (out_host:
+ * n >= 8 counters): [0] 256x320 "tall", [1] 128x320 "wide", [2] 128x128, [3] 128x64, [4] launches that fell back to the pointer-addressed
+ * generic loader, [5] split-K reduce passes, [6] launches of the f16mx (NPASS = 4) instantiation (also counted under their tile), [7] 0.
+ * Introspection only (which instantiation a layer geometry is routed to is otherwise invisible to the caller); kernels replayed from a
+ * captured HIP graph are counted once, at capture. */
+int ddpo_gemm_tile_launch_counts(unsigned long long* out_host, int n);
 
 /* ---- PRNG: jax.random (Threefry-2x32) -------------------------------------------------------------
  * jax.random.split / PRNGKey bookkeeping, pipeline/policy_gradient.py:51,201,244-245 and

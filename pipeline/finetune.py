@@ -40,7 +40,7 @@ def main(argv=None):
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     from ddpo_amd import lib as L
-    L.DATAPATH = os.environ.get("DDPO_DATAPATH", "bf16x3")
+    L.DATAPATH = L.shipped_datapath()
 
     args = Parser(argv).parse_args("train")                  # one seed for the whole pod: transformers.set_seed(args.seed), reference :52
     utils.init_logging("finetune", args.verbose)

@@ -63,9 +63,9 @@ def main(argv=None):
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    # contraction datapath of the HIP kernels: bf16x3-split MFMA by default, DDPO_DATAPATH=fp32 for exact fp32
+    # contraction datapath of the HIP kernels: lib.SHIPPED_DATAPATH (f16mx since round 4); DDPO_DATAPATH=bf16x3 / fp32 select the others
     from ddpo_amd import lib as L
-    L.DATAPATH = os.environ.get("DDPO_DATAPATH", "bf16x3")
+    L.DATAPATH = L.shipped_datapath()
 
     # which reference run the ranks reproduce: one PROCESS each (default) or one DEVICE each of a single-host run
     # (DDPO_DP_SEMANTICS=single_host: identical seeds, global prompt / permutation streams, trajectories all-gathered; training/dp.py)

@@ -39,7 +39,7 @@ def main(argv=None):
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     from ddpo_amd import lib as L
-    L.DATAPATH = os.environ.get("DDPO_DATAPATH", "bf16x3")
+    L.DATAPATH = L.shipped_datapath()
 
     args = Parser(argv).parse_args("sample", process_index=worker_id)
     rng = prng.PRNGKey(args.seed)

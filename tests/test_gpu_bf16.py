@@ -280,7 +280,7 @@ def test_bfloat16_dtype_path_is_held_to_the_reference_bf16_arithmetic(datapath, 
     # ... and a later float32 load in the same process is back on the fp32-class datapath
     monkeypatch.delenv("DDPO_DATAPATH", raising=False)
     load_unet(None, pretrained_model="none", dtype="float32", device=DEV, seed=7)
-    assert L.DATAPATH == "bf16x3"
+    assert L.DATAPATH == L.SHIPPED_DATAPATH
 
 
 @pytest.mark.parametrize("case", [("dense", 1000, 320, 320), ("dense", 4096, 1280, 640), ("dense", 300, 40, 64), ("dense", 16, 1280, 320),

@@ -15,6 +15,7 @@ from oracle.ddim import DDIMOracle
 from oracle.sampler import sample as oracle_sample
 
 DEV = "cuda"
+SHIPPED = __import__("os").environ.get("DDPO_PARITY_DATAPATH") or L.SHIPPED_DATAPATH      # full-size tests run on what the entrypoints ship (f16mx)
 
 
 def _rel(a, b):
@@ -196,15 +197,14 @@ def test_unet_sd15_single_sample_64x64():
     assert _rel(out.numpy(), ref.numpy()) < 1e-3
 
 
-def test_unet_sd21_single_sample_96x96_bf16x3():
+def test_unet_sd21_single_sample_96x96_shipped_datapath():
     """BASELINE configs[4] architecture at full size: SD-2.1 U-Net (865.9 M params; linear proj_in/out, d_head 64 with
     5/10/20/20 heads, 1024-wide context) on a 768^2 latent (96x96 -> self-attention over 9216 keys), one sample, on the
-    bf16x3 datapath (buffer-addressed GEMMs, pre-packed K/V attention) against the torch-CPU fp32 oracle."""
-    from ddpo_amd import lib as L
+    shipped datapath (buffer-addressed GEMMs, f16mx long reductions, pre-packed K/V attention) against the torch-CPU fp32 oracle."""
     shapes = OU.unet_param_shapes(OU.SD21)
     op = OU.init_params(shapes, seed=0)
     old = L.DATAPATH
-    L.DATAPATH = "bf16x3"
+    L.DATAPATH = SHIPPED
     try:
         unet = UNet2DCondition(UNetConfig.named("sd21"), DEV)
         assert unet.params.n_params == 865910724
@@ -231,10 +231,9 @@ def test_sampler_sd21_full_size_96x96_graph_path():
     /root/reference/ddpo/diffusers_patch/pipeline_flax_stable_diffusion.py:355-365), time-projection table and cached text K/V
     included, against the fp32 oracle's sampling loop: timesteps equal, trajectories / final latents / log-probs within the
     north-star tolerance.  The eager path must agree with the graph replay bit for bit."""
-    from ddpo_amd import lib as L
     op = OU.init_params(OU.unet_param_shapes(OU.SD21), seed=0)
     old = L.DATAPATH
-    L.DATAPATH = "bf16x3"
+    L.DATAPATH = SHIPPED
     try:
         unet = UNet2DCondition(UNetConfig.named("sd21"), DEV)
         unet.params.load_dict(op)

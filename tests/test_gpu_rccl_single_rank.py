@@ -2,7 +2,9 @@
 covered by the gloo tests (world 2, CPU) and by the 2-rank entrypoint test that shares the GPU over gloo; what THIS test adds is that
 the `nccl` backend — RCCL on ROCm — really initialises, binds its communicator to the device and carries every collective of the
 data-parallel path (all_reduce of the gradient buffer, all_gather of rewards / prompts / trajectories, barrier, the benchmark's
-max-over-ranks) with one rank, through the same code the N-rank job runs (DDPO_FORCE_DIST=1 builds the group for world size 1)."""
+max-over-ranks) with one rank, through the same code the N-rank job runs (DDPO_FORCE_DIST=1 builds the group for world size 1) —
+including, since round 4, the DEFAULT gradient path of world > 1: the bucketed all-reduce on a side stream behind the backward pass
+(training/distributed.GradBucketer), against the blocking single all-reduce."""
 import json
 import os
 import subprocess
@@ -42,6 +44,12 @@ def test_collectives_through_rccl_with_one_rank():
     assert out["allgather_array"] == [[0.0, 1.0], [2.0, 3.0], [4.0, 5.0]] and out["allgather_strings"] == ["a cat", "a dog"]
     assert out["allgather_tensor_ok"] and out["allreduce_ok"] and out["gather_global_ok"]
     assert abs(out["pmean"]["loss"] - 2.0) < 1e-6 and abs(out["pmean"]["kl"] - 0.5) < 1e-6
+    # the default data-parallel gradient path (GradBucketer: side stream + async all_reduce per bucket + finish) executed on RCCL:
+    # same applied update as the blocking all-reduce bit for bit on fixed gradients, several buckets launched BEFORE finish();
+    # and through train_step / train_steps_fused (UNet.backward(on_ready=...)) equal up to the order of the weight gradients' fp32 atomics
+    assert out["bucketed_update_bit_equal"] and out["buckets"] > 8 and 0 < out["launched_before_finish"] < out["buckets"]
+    assert out["train_step_update_l2"] > 1e-3 and out["train_step_overlap_l2_diff"] < 1e-2 * out["train_step_update_l2"], out
+    assert abs(out["train_step_loss"][0] - out["train_step_loss"][1]) < 1e-4 * abs(out["train_step_loss"][0]) + 1e-6
 
 
 @pytest.mark.timeout(600)

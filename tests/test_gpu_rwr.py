@@ -5,6 +5,7 @@ ddpo/training/diffusion.py executed in place: tests/test_reference_rwr_goldens.p
   * the whole step (U-Net forward / backward between the two kernels): loss, gradient norm and per-parameter gradients vs float64 autograd through the
     oracle U-Net (tiny, fp32 and bf16x3 datapaths; full-size SD-1.5 on bf16x3), and the applied AdamW update vs the optax restatement."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -165,12 +166,12 @@ def test_rwr_train_step_applies_the_optax_update_tiny():
     assert checked > 50
 
 
-def test_rwr_step_sd15_full_size_bf16x3():
+def test_rwr_step_sd15_full_size_shipped_datapath():
     """One RWR step of the real architecture (SD-1.5, 859.5 M parameters, 64x64 latents = 512^2 images) on the shipped datapath against
     float32 autograd through the oracle U-Net: loss and gradient norm within the north-star 1e-3, gradient vector within 2e-3."""
     from ddpo_amd.models.unet import UNet2DCondition, UNetConfig
     from ddpo_amd.training.diffusion import DDPMNoiseScheduler
-    L.DATAPATH = "bf16x3"
+    L.DATAPATH = os.environ.get("DDPO_PARITY_DATAPATH") or L.SHIPPED_DATAPATH          # f16mx since round 4
     B, hw = 1, 64
     op = OU.init_params(OU.unet_param_shapes(OU.SD15), seed=1)
     unet = UNet2DCondition(UNetConfig.named("sd15"), DEV)
