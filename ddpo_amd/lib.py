@@ -239,6 +239,13 @@ W_KBLOCKED = os.environ.get("DDPO_W_KBLOCKED", "1") == "1"
 # stores get ten 64-byte segments per row instead of one 640-byte run.  The weight operand, streamed from HBM by every launch, is
 # where the layout pays (+3.0 %).
 A_KBLOCKED = os.environ.get("DDPO_A_KBLOCKED", "0") == "1"
+# Data gradients as FORWARD contractions (round 4).  dX of y = conv(x, W) is conv(dY, W') with W'[ky, kx, co, ci] = W[k-1-ky, k-1-kx, ci, co]
+# (stride 2: over the zero-inserted dY), dX of y = x W is dY W^T: pack_weights(bwd=True) registers W' / W^T as one more set of FORWARD weight
+# planes (k-blocked; f16mx planes too where the reduction 9 * Cout / N is >= MX_MIN_K), and conv2d_dgrad / linear_dgrad run the plane-fed /
+# f16mx / tall-tile forward kernels on them with dY split into planes on the way in — instead of the fp32-fed kernel's `w_dgrad` addressing of
+# row-major (K, N) planes, which had none of: LDS-DMA operands, k-blocked weight stream, 256x320 tiles, the f16mx operator.
+# DDPO_DGRAD_FWD=0 restores the round-3 path (bit-different, same bf16x3 arithmetic class).
+DGRAD_FWD = os.environ.get("DDPO_DGRAD_FWD", "1") == "1"
 
 
 class Planes:
@@ -329,13 +336,15 @@ def planes_out_ok(w, cin, rows, N):
 
 
 def split_planes(x, fmt=0):
-    """fp32 (rows, C) -> Planes of format `fmt` (0 bf16 hi / lo, 1 f16mx): what a plane-emitting producer writes."""
+    """fp32 (rows, C) -> Planes of format `fmt` (0 bf16 hi / lo, 1 f16mx): what a plane-emitting producer writes.  x may be a row-strided
+    2-D view (a column slice of a wider row-major buffer)."""
     rows, C = x.shape
     pl = Planes(rows, C, x.device, fmt=fmt)
+    ldx = int(x.stride(0)) if rows > 1 else C
     if pl.fmt == 1:
-        _check(load().ddpo_split_planes_f16mx(_p(x), C, _p(pl.hi), _p(pl.lo), pl.ld, rows, C, _stream()), "ddpo_split_planes_f16mx")
+        _check(load().ddpo_split_planes_f16mx(_p_rows(x), ldx, _p(pl.hi), _p(pl.lo), pl.ld, rows, C, _stream()), "ddpo_split_planes_f16mx")
     else:
-        _check(load().ddpo_split_planes_bf16(_p(x), C, _p(pl.hi), _p(pl.lo), pl.ld, rows, C, _stream()), "ddpo_split_planes_bf16")
+        _check(load().ddpo_split_planes_bf16(_p_rows(x), ldx, _p(pl.hi), _p(pl.lo), pl.ld, rows, C, _stream()), "ddpo_split_planes_bf16")
     return pl
 
 
@@ -598,19 +607,24 @@ def groupnorm(x, B, HW, gamma, beta, groups, eps, silu, out=None, ld_x=None, ld_
     planes (the value of planes_pay / norm_planes for the consumer; 1 / True = bf16 hi / lo, 2 = f16mx): the result comes back as `Planes`
     for a plane-fed conv / linear."""
     C = gamma.numel()
+    if ld_x is None and x.dim() == 2 and x.stride(0) != C:          # a column slice of a wider row-major buffer (skip-concat storage)
+        ld_x = x.stride(0)
+    _p = _p_rows if ld_x else globals()["_p"]
     if planes:
         pl = Planes(B * HW, C, x.device, fmt=1 if planes == 2 else 0)
         ws = _scratch(load().ddpo_groupnorm_ws_bytes(B, HW, C, groups), x.device, "gn")
         stats = torch.empty(load().ddpo_groupnorm_stats_floats(B, C, groups), dtype=torch.float32, device=x.device)
-        _check(load().ddpo_groupnorm_fwd_planes(_p(x), int(ld_x or C), _p(pl.hi), _p(pl.lo), pl.ld, _p(gamma), _p(beta), B, HW, C, groups,
-                                                float(eps), int(bool(silu)) | (2 * pl.fmt), _p(ws), _p(stats), _stream()), "ddpo_groupnorm_fwd_planes")
+        _p2 = globals()["_p"]
+        _check(load().ddpo_groupnorm_fwd_planes(_p(x), int(ld_x or C), _p2(pl.hi), _p2(pl.lo), pl.ld, _p2(gamma), _p2(beta), B, HW, C, groups,
+                                                float(eps), int(bool(silu)) | (2 * pl.fmt), _p2(ws), _p2(stats), _stream()), "ddpo_groupnorm_fwd_planes")
         return (pl, stats) if return_stats else pl
     if out is None:
         out = torch.empty(B * HW, C, dtype=torch.float32, device=x.device)
     ws = _scratch(load().ddpo_groupnorm_ws_bytes(B, HW, C, groups), x.device, "gn")
     stats = torch.empty(load().ddpo_groupnorm_stats_floats(B, C, groups), dtype=torch.float32, device=x.device)
-    _check(load().ddpo_groupnorm_fwd(_p(x), int(ld_x or C), _p(out), int(ld_out or C), _p(gamma), _p(beta), B, HW, C, groups,
-                                     float(eps), int(bool(silu)), _p(ws), _p(stats), _stream()), "ddpo_groupnorm_fwd")
+    _p2 = globals()["_p"]
+    _check(load().ddpo_groupnorm_fwd(_p(x), int(ld_x or C), _p2(out), int(ld_out or C), _p2(gamma), _p2(beta), B, HW, C, groups,
+                                     float(eps), int(bool(silu)), _p2(ws), _p2(stats), _stream()), "ddpo_groupnorm_fwd")
     return (out, stats) if return_stats else out
 
 
@@ -650,7 +664,15 @@ def pack_weights(w, bwd=True):
     if ent is None or ent["K"] != K or ent["N"] != N or ent.get("w_layout", 0) != lay:
         ent = dict(K=K, N=N, fwd=(mk(N, Kp), mk(N, Kp), Kp), bwd=None, w_layout=lay)
         PACKED[w.data_ptr()] = ent
-    if bwd and ent["bwd"] is None:
+    # data-gradient planes: the transposed / tap-flipped weight as a forward operand (DGRAD_FWD) where the buffer-addressed kernels can take it,
+    # else the original (K, N) order for the fp32-fed kernel's w_dgrad addressing
+    n_dg = w.shape[2] if w.dim() == 4 else K              # output columns of the data gradient: the layer's input channels
+    dg_ok = bool(bwd and DGRAD_FWD and _x3() and W_KBLOCKED and w.dim() in (2, 4) and N % 32 == 0 and n_dg % 4 == 0)
+    if dg_ok:
+        _pack_dgrad_planes(w, ent)
+    else:
+        ent.pop("dg", None)
+    if bwd and ent["bwd"] is None and not dg_ok:
         ent["bwd"] = (mk(K, N), mk(K, N))
     if "geglu" in ent:
         ent["geglu"]["stale"] = True          # re-ordered GEGLU planes (pack_weights_geglu) no longer match w
@@ -671,6 +693,83 @@ def pack_weights(w, bwd=True):
     else:
         _check(load().ddpo_pack_weights_bf16(_p(w), K, N, Kp, _p(fh), _p(fl), _p(bh), _p(bl), _stream()), "ddpo_pack_weights_bf16")
     return ent
+
+
+def _pack_dgrad_planes(w, ent):
+    """ent["dg"]: forward-style planes of the data-gradient weight of `w` — conv (kh, kw, ci, co): W'[ky, kx, co, ci] = W[kh-1-ky, kw-1-kx, ci, co],
+    i.e. K' = kh * kw * co reduction rows, N' = ci output columns; dense (K, N): W^T, K' = N, N' = K."""
+    wt = w.flip(0, 1).permute(0, 1, 3, 2).contiguous() if w.dim() == 4 else w.t().contiguous()
+    Nd = wt.shape[-1]
+    Kd = wt.numel() // Nd
+    Kp = (Kd + 31) // 32 * 32
+    dg = ent.get("dg")
+    if dg is None or dg["K"] != Kd or dg["N"] != Nd:
+        mk = lambda *sh: torch.zeros(*sh, dtype=torch.int16, device=w.device)
+        dg = ent["dg"] = dict(K=Kd, N=Nd, hi=mk(Nd, Kp), lo=mk(Nd, Kp))
+    _check(load().ddpo_pack_weights_bf16_kblocked(_p(wt), Kd, Nd, _p(dg["hi"]), _p(dg["lo"]), _stream()), "ddpo_pack_weights_bf16_kblocked")
+    if _mx() and Kd % 32 == 0 and Kd >= MX_MIN_K:
+        if "mx" not in dg:
+            dg["mx"] = dict(w16=torch.zeros(Kd // 32, Nd, 32, dtype=torch.int16, device=w.device), w8=torch.zeros(Kd // 32, Nd, 64, dtype=torch.uint8, device=w.device),
+                            scale=torch.zeros(Nd, dtype=torch.uint8, device=w.device))
+        m = dg["mx"]
+        _check(load().ddpo_pack_weights_f16mx(_p(wt), Kd, Nd, _p(m["w16"]), _p(m["w8"]), _p(m["scale"]), _stream()), "ddpo_pack_weights_f16mx")
+    else:
+        dg.pop("mx", None)
+    return dg
+
+
+def _dgrad_fwd(dy, dg, *, M, conv=None, residual=None, ld_res=None, out=None):
+    """dX = the forward contraction of dY with the registered data-gradient planes `dg` (see DGRAD_FWD).  dy: fp32 (rows, K' per tap) or Planes.
+    Long reductions (K' >= 2560: every 3x3 convolution, FF1) run plane-fed — dY split on the way in, f16mx where f16mx planes are registered;
+    short ones stay fp32-fed (the plane-fed loop's fill latency, planes_pay) on the k-blocked weight stream."""
+    Kd, Nd = dg["K"], dg["N"]
+    cin = conv["Cin"] if conv else Kd
+    rows = conv["B"] * conv["H"] * conv["W"] if conv else M
+    lim = 0x7FFFFFFF
+    if conv is None and rows * cin * 4 >= lim and not isinstance(dy, Planes):
+        # a dense dY of >= 2 GiB (FF1's (M, 8C) gradient at training batch sizes) would leave the buffer-addressed kernels: run it in row chunks
+        n = -(-rows * cin * 4 // (lim - 4 * cin))
+        step = (-(-rows // n) + 255) // 256 * 256
+        out = torch.empty(M, Nd, dtype=torch.float32, device=dy.device)
+        for r0 in range(0, rows, step):
+            r1 = min(rows, r0 + step)
+            _dgrad_fwd(dy[r0:r1], dg, M=r1 - r0, residual=None if residual is None else residual[r0:r1], ld_res=ld_res, out=out[r0:r1])
+        return out
+    mxl = _mx() and "mx" in dg
+    buf_ok = cin % 32 == 0 and rows * cin * 4 < lim and Nd * ((Kd + 31) // 32 * 32) * 2 < lim
+    pl = dy if isinstance(dy, Planes) else None
+    if pl is not None and ((pl.fmt == 1) != bool(mxl) or not buf_ok):
+        dy, pl = pl.float(), None
+    if pl is None and buf_ok and PLANES and (mxl or Kd >= 2560 or PLANES_ALL):
+        pl = split_planes(dy, fmt=1 if mxl else 0)
+    if pl is None and mxl:
+        mxl = False                          # not plane-eligible (>= 2 GiB): bf16x3, like the forward of such a layer
+    d = GemmDesc()
+    dev = pl.device if pl is not None else dy.device
+    if out is None:
+        out = torch.empty(M, Nd, dtype=torch.float32, device=dev)
+    if residual is not None:
+        d.residual = residual.data_ptr(); d.ld_res = int(ld_res if ld_res is not None else Nd)
+    d.out = out.data_ptr(); d.ld_out = int(Nd)
+    d.alpha = 1.0
+    d.M, d.N, d.K = int(M), int(Nd), int(Kd)
+    d.w_layout = 1
+    if conv:
+        for k in ("ksize", "stride", "pad", "upsample", "B", "H", "W", "Cin", "OH", "OW"):
+            setattr(d, k, int(conv[k]))
+    ws = _scratch(SPLITK_WS_BYTES, dev, "splitk")
+    if pl is not None and mxl:
+        m = dg["mx"]
+        d.w_scale = m["scale"].data_ptr()
+        _check(load().ddpo_gemm_conv_fwd_f16mx_planes(byref(d), _p(pl.hi), _p(pl.lo), pl.ld, _p(m["w16"]), _p(m["w8"]), _p(ws), SPLITK_WS_BYTES, _stream()),
+               "ddpo_gemm_conv_fwd_f16mx_planes(dgrad)")
+    elif pl is not None:
+        _check(load().ddpo_gemm_conv_fwd_bf16_planes(byref(d), _p(pl.hi), _p(pl.lo), pl.ld, _p(dg["hi"]), _p(dg["lo"]), 0, _p(ws), SPLITK_WS_BYTES, _stream()),
+               "ddpo_gemm_conv_fwd_bf16_planes(dgrad)")
+    else:
+        d.src = dy.data_ptr(); d.ld_src = int(cin)
+        _check(load().ddpo_gemm_conv_fwd_bf16(byref(d), _p(dg["hi"]), _p(dg["lo"]), 0, 3, _p(ws), SPLITK_WS_BYTES, _stream()), "ddpo_gemm_conv_fwd_bf16(dgrad)")
+    return out
 
 
 def pack_weights_geglu(w, bias):
@@ -806,12 +905,16 @@ def gemm_conv(src, w, *, M, N, K, bias=None, rowbias=None, rows_per_batch=0, res
         # producer) is split on the way in — the same planes its plane-emitting form would have written
         cin_ = conv["Cin"] if conv else K
         rows_ = conv["B"] * conv["H"] * conv["W"] if conv else M
-        if not planes_ok(w, cin_, rows_) or ld_src is not None:
-            mxl = False                      # not plane-eligible (>= 2 GiB tensors, column slices): bf16x3 like every other such layer
+        if not planes_ok(w, cin_, rows_):
+            mxl = False                      # not plane-eligible (>= 2 GiB tensors): bf16x3 like every other such layer
         elif pl is None:
-            if not (src.dim() == 2 and src.shape[0] == rows_ and src.shape[1] == cin_ and src.is_contiguous()):
-                raise DdpoHipError("an f16mx layer needs its fp32 input as a contiguous (rows, channels) tensor")
+            # (a row-strided view — a column slice of a skip-concat buffer — is split like a contiguous tensor: the layer's arithmetic must
+            # never depend on where its input is stored)
+            if not (src.dim() == 2 and src.shape[0] == rows_ and src.shape[1] == cin_ and src.stride(1) == 1 and
+                    (ld_src is None or ld_src == src.stride(0))):
+                raise DdpoHipError("an f16mx layer needs its fp32 input as a (rows, channels) tensor or row-strided view")
             pl = src = split_planes(src, fmt=1)
+            ld_src = None
     if pl is not None and (pl.fmt == 1) != bool(mxl):
         raise DdpoHipError("activation planes of the wrong format for this layer (ask planes_pay / norm_planes: 1 = bf16 hi / lo, 2 = f16mx)")
     d = GemmDesc()
@@ -1005,6 +1108,8 @@ def linear_dgrad(dy, w, residual=None):
     M, N = dy.shape
     K = w.shape[0]
     ent = PACKED.get(w.data_ptr()) if current_datapath() != "fp32" else None
+    if ent is not None and ent.get("dg") is not None and _x3():
+        return _dgrad_fwd(dy, ent["dg"], M=M, residual=residual)
     if ent is not None and ent["bwd"] is not None and N % 8 == 0:
         # the original (K, N) order is exactly "output column k, reduction index n contiguous": forward-style planes with ldw = N
         d = GemmDesc()
@@ -1109,6 +1214,11 @@ def conv2d_dgrad(dy, w, B, H, W, Cin, Cout, ksize, stride=1, residual=None):
     if stride == 2 and (H != 2 * OH or W != 2 * OW):
         raise DdpoHipError("stride-2 dgrad expects even input sizes")
     conv = dict(ksize=ksize, stride=1, pad=pad, upsample=2 if stride == 2 else 0, B=B, H=OH, W=OW, Cin=Cout, OH=H, OW=W)
+    ent = PACKED.get(w.data_ptr()) if current_datapath() != "fp32" else None
+    if ent is not None and ent.get("dg") is not None and _x3():
+        return _dgrad_fwd(dy, ent["dg"], M=B * H * W, conv=conv, residual=residual)
+    if isinstance(dy, Planes):
+        dy = dy.float()
     d = GemmDesc()
     d.src = dy.data_ptr(); d.ld_src = int(Cout)
     d.w = w.data_ptr(); d.w_trans = 1; d.w_dgrad = 1

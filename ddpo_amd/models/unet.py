@@ -181,6 +181,10 @@ def unet_param_shapes(cfg: UNetConfig):
     return d
 
 
+# skip concatenations of the sampling forward are formed in place by the producers (UNet2DCondition.forward); DDPO_SKIP_INPLACE=0: copies
+SKIP_INPLACE = os.environ.get("DDPO_SKIP_INPLACE", "1") == "1"
+
+
 class Act:
     """An NHWC activation: rows (B*H*W, C).  `pl`: the same values as bf16 hi / lo planes when the producing GEMM's output stage
     also emitted them (sampling only) — a plane-fed consumer (down / up-sampler convolution) reads those instead of `t`."""
@@ -188,6 +192,12 @@ class Act:
 
     def __init__(self, t, B, H, W, C, pl=None):
         self.t, self.B, self.H, self.W, self.C, self.pl = t, B, H, W, C, pl
+
+    @property
+    def ld(self):
+        """Row stride of `t` in elements when it is a column slice of a wider row-major buffer (a skip tensor stored inside the concat
+        buffer of the up block that consumes it), else None."""
+        return int(self.t.stride(0)) if (self.t.dim() == 2 and self.t.shape[0] > 1 and self.t.stride(0) != self.C) else None
 
     @property
     def HW(self):
@@ -198,11 +208,15 @@ class Act:
         return self.B * self.H * self.W
 
 
-def resnet_forward(P, name, x: Act, temb_act, groups, eps, tape=None, emit_planes=0):
+def resnet_forward(P, name, x: Act, temb_act, groups, eps, tape=None, emit_planes=0, dest=None):
     """FlaxResnetBlock2D: GN-SiLU-conv3x3 (+time proj) - GN-SiLU-conv3x3 (+ shortcut).
     emit_planes (sampling; the consuming sampler convolution's planes_pay value): conv2's output stage also writes the block output as
-    planes of that format (Act.pl)."""
+    planes of that format (Act.pl).
+    dest (sampling): a row-strided (rows, cout) view the block output is written into — its column range of the concat buffer of the up
+    block that will consume it (UNet2DCondition.forward); x.t may be such a view too (GroupNorm / shortcut / residual take row strides)."""
     cout = P[name + ".conv1.bias"].numel()
+    ldx = x.ld
+    okw = {} if dest is None else dict(out=dest, ld_out=int(dest.stride(0)))
     # inference / sampling (no tape): the two GroupNorm+SiLU results feed only their convolution, so they are written as bf16
     # hi / lo planes and the convolutions run plane-fed (LDS-DMA operands; bit-identical to the fp32-fed kernels)
     # training (tape): the same, the planes are what the weight gradients of conv1 / conv2 read (lib.TRAIN_PLANES)
@@ -222,13 +236,16 @@ def resnet_forward(P, name, x: Act, temb_act, groups, eps, tape=None, emit_plane
     res = x.t
     shortcut = (name + ".conv_shortcut.kernel") in P
     if shortcut:
-        res, _, _ = L.conv2d(x.t, P[name + ".conv_shortcut.kernel"], P[name + ".conv_shortcut.bias"], x.B, x.H, x.W, x.C, cout, 1)
+        res, _, _ = L.conv2d(x.t, P[name + ".conv_shortcut.kernel"], P[name + ".conv_shortcut.bias"], x.B, x.H, x.W, x.C, cout, 1,
+                             **({} if ldx is None else dict(ld_src=ldx)))
+    elif ldx is not None:
+        okw["ld_res"] = ldx
     opl = None
     if emit_planes and tape is None and L.planes_out_ok(P[name + ".conv2.kernel"], cout, x.M, cout):
         (out, opl), _, _ = L.conv2d(h2, P[name + ".conv2.kernel"], P[name + ".conv2.bias"], x.B, x.H, x.W, cout, cout, 3, residual=res,
-                                    planes_out="both", planes_fmt=emit_planes)
+                                    planes_out="both", planes_fmt=emit_planes, **okw)
     else:
-        out, _, _ = L.conv2d(h2, P[name + ".conv2.kernel"], P[name + ".conv2.bias"], x.B, x.H, x.W, cout, cout, 3, residual=res)
+        out, _, _ = L.conv2d(h2, P[name + ".conv2.kernel"], P[name + ".conv2.bias"], x.B, x.H, x.W, cout, cout, 3, residual=res, **okw)
     if tape is not None:
         tape.append(("resnet", dict(name=name, x=x, st1=st1, h1=h1, c1=c1, st2=st2, h2=h2, cout=cout, shortcut=shortcut,
                                     temb=temb_act is not None, groups=groups)))
@@ -313,7 +330,8 @@ class UNet2DCondition:
             d_x = L.linear_dgrad(dv, P[name + ".to_v.kernel"], residual=d_x)
         return d_x
 
-    def _transformer(self, name, x: Act, ctx, ctx_len, heads, tape=None, emit_planes=0):
+    def _transformer(self, name, x: Act, ctx, ctx_len, heads, tape=None, emit_planes=0, dest=None):
+        """dest / strided x.t: as in resnet_forward (sampling: the block output lands in its consumer's concat buffer)."""
         P, cfg = self.params, self.cfg
         C, B, N = x.C, x.B, x.HW
         rec = None if tape is None else dict(name=name, x=x, heads=heads, ctx=ctx, ctx_len=ctx_len)
@@ -357,6 +375,10 @@ class UNet2DCondition:
             gg = L.geglu(f)
         h3 = L.linear(gg, P[tb + ".ff.net_2.kernel"], P[tb + ".ff.net_2.bias"], residual=h2)
         po = dict(planes_out="both", planes_fmt=emit_planes) if pl_out else {}
+        if dest is not None:
+            po.update(out=dest, ld_out=int(dest.stride(0)))
+        if x.ld is not None:
+            po["ld_res"] = x.ld
         if cfg.use_linear_projection:
             out = L.linear(h3, P[name + ".proj_out.kernel"], P[name + ".proj_out.bias"], residual=x.t, **po)
         else:
@@ -444,12 +466,44 @@ class UNet2DCondition:
         dup = bool(cfg_dup) and tape is None and B % 2 == 0 and cfg.cross_attn_down[0]
         Bh = B // 2 if dup else B
         twice = (lambda a: torch.cat([a, a])) if dup else (lambda a: a)
+        # Skip concatenation without copies (sampling; round 4): every tensor of the down path that is also a skip connection is written by its
+        # producer straight into ITS column range of the concat buffer of the up block that consumes it, and so is the up path's running
+        # activation (column range 0 .. c0) — the two ddpo_copy_cols launches per up block (1248 per 50-step sampling call, re-reading and
+        # re-writing both halves) disappear.  Same kernels, same arithmetic: only row strides change (bit-identical, tests/test_gpu_model.py).
+        # The training forward (tape) keeps contiguous tensors: its backward kernels take them.
+        inplace = tape is None and SKIP_INPLACE
+        plan = self._concat_plan() if inplace else None              # (c0, c1) per up block, in consumption order
+        cat_bufs = []                                                  # concat buffers of the pushed skips, parallel to `skips`
+
+        def skip_dest(rows):
+            """Destination view (rows, c1) of the NEXT skip to be pushed, inside a fresh concat buffer of its consumer."""
+            if not inplace:
+                return None
+            c0, c1 = plan[len(plan) - 1 - len(cat_bufs)]
+            buf = torch.empty(rows, c0 + c1, dtype=torch.float32, device=self.device)
+            cat_bufs.append(buf)
+            return buf[:, c0:]
+
+        def up_dest(k):
+            """Destination view (rows, c0) for the activation that up block number k (consumption order) concatenates in front of its skip."""
+            if not inplace or k >= len(plan):
+                return None
+            return cat_bufs[-1][:, :plan[k][0]]
+
         x = L.nchw_to_nhwc(sample[:Bh].contiguous())
-        t, _, _ = L.conv2d(x, P["conv_in.kernel"], P["conv_in.bias"], Bh, H, W, Cin, boc[0], 3)
+        d0 = skip_dest(B * H * W)
+        if d0 is not None:
+            t, _, _ = L.conv2d(x, P["conv_in.kernel"], P["conv_in.bias"], Bh, H, W, Cin, boc[0], 3, out=d0[:Bh * H * W], ld_out=int(d0.stride(0)))
+            if dup:
+                d0[Bh * H * W:].copy_(d0[:Bh * H * W])
+            t_full = d0
+        else:
+            t, _, _ = L.conv2d(x, P["conv_in.kernel"], P["conv_in.bias"], Bh, H, W, Cin, boc[0], 3)
+            t_full = twice(t)
         if tape is not None:
             tape.append(("head", dict(emb=emb, t1=t1, s1=s1, temb=temb, temb_act=temb_act, x=Act(x, B, H, W, Cin))))
         h_half = Act(t, Bh, H, W, boc[0])
-        h = Act(twice(t), B, H, W, boc[0])
+        h = Act(t_full, B, H, W, boc[0])
         skips = [h]
         for i in range(nlev):
             for j in range(cfg.layers_per_block):
@@ -462,19 +516,25 @@ class UNet2DCondition:
                     if tape is None and i < nlev - 1 and j == cfg.layers_per_block - 1:      # the consumer's planes_pay value (0 / 1 / 2)
                         emit = L.planes_pay(P[f"down_blocks_{i}.downsamplers_0.conv.kernel"], boc[i], h.M)
                     h = resnet_forward(P, f"down_blocks_{i}.resnets_{j}", h, temb_act, G, 1e-5, tape,
-                                       emit_planes=0 if cfg.cross_attn_down[i] else emit)
+                                       emit_planes=0 if cfg.cross_attn_down[i] else emit,
+                                       dest=None if cfg.cross_attn_down[i] else skip_dest(h.M))
                 if cfg.cross_attn_down[i]:
                     emit_t = 0
                     if tape is None and i < nlev - 1 and j == cfg.layers_per_block - 1:
                         emit_t = L.planes_pay(P[f"down_blocks_{i}.downsamplers_0.conv.kernel"], boc[i], h.M)
-                    h = self._transformer(f"down_blocks_{i}.attentions_{j}", h, ctx, Lc, cfg.num_heads[i], tape, emit_planes=emit_t)
+                    h = self._transformer(f"down_blocks_{i}.attentions_{j}", h, ctx, Lc, cfg.num_heads[i], tape, emit_planes=emit_t,
+                                          dest=skip_dest(h.M))
                 skips.append(h)
                 if tape is not None:
                     tape.append(("skip_push", None))
             if i < nlev - 1:
                 name = f"down_blocks_{i}.downsamplers_0.conv"
                 src = h.pl if (h.pl is not None and L.planes_pay(P[name + ".kernel"], h.C, h.M) == h.pl.fmt + 1) else h.t
-                t, OH, OW = L.conv2d(src, P[name + ".kernel"], P[name + ".bias"], B, h.H, h.W, h.C, h.C, 3, stride=2, pad=1)
+                skw = {} if (src is not h.t or h.ld is None) else dict(ld_src=h.ld)
+                dd = skip_dest(B * (h.H // 2) * (h.W // 2))
+                if dd is not None:
+                    skw.update(out=dd, ld_out=int(dd.stride(0)))
+                t, OH, OW = L.conv2d(src, P[name + ".kernel"], P[name + ".bias"], B, h.H, h.W, h.C, h.C, 3, stride=2, pad=1, **skw)
                 if tape is not None:
                     tape.append(("down", dict(name=name, x=h)))
                     tape.append(("skip_push", None))
@@ -482,27 +542,38 @@ class UNet2DCondition:
                 skips.append(h)
         h = resnet_forward(P, "mid_block.resnets_0", h, temb_act, G, 1e-5, tape)
         h = self._transformer("mid_block.attentions_0", h, ctx, Lc, cfg.num_heads[-1], tape)
-        h = resnet_forward(P, "mid_block.resnets_1", h, temb_act, G, 1e-5, tape)
+        h = resnet_forward(P, "mid_block.resnets_1", h, temb_act, G, 1e-5, tape, dest=up_dest(0))
+        kblk = 0                                                       # up blocks consumed so far
         for i in range(nlev):
             lvl = nlev - 1 - i
             for j in range(cfg.layers_per_block + 1):
                 s = skips.pop()
-                cat = torch.empty(B * h.HW, h.C + s.C, dtype=torch.float32, device=self.device)
-                L.copy_cols(h.t, cat, 0, B * h.HW, h.C)
-                L.copy_cols(s.t, cat, h.C, B * h.HW, s.C)
+                if inplace:                                            # both halves are already in place (written by their producers)
+                    cat = cat_bufs.pop()
+                    assert cat.shape == (B * h.HW, h.C + s.C) and h.t.data_ptr() == cat.data_ptr() and s.t.data_ptr() == cat.data_ptr() + 4 * h.C
+                else:
+                    cat = torch.empty(B * h.HW, h.C + s.C, dtype=torch.float32, device=self.device)
+                    L.copy_cols(h.t, cat, 0, B * h.HW, h.C)
+                    L.copy_cols(s.t, cat, h.C, B * h.HW, s.C)
                 if tape is not None:
                     tape.append(("concat", dict(c0=h.C, c1=s.C)))
+                kblk += 1
                 emit = 0
-                if tape is None and i < nlev - 1 and j == cfg.layers_per_block:      # feeds the up-sampler convolution: its planes_pay value
+                last_of_level = j == cfg.layers_per_block
+                if tape is None and i < nlev - 1 and last_of_level:      # feeds the up-sampler convolution: its planes_pay value
                     emit = L.planes_pay(P[f"up_blocks_{i}.upsamplers_0.conv.kernel"], boc[lvl], B * h.HW)
+                # where this block's output goes: the next up block's concat buffer — unless an up-sampler convolution (or conv_norm_out) reads it
+                nxt = None if last_of_level else up_dest(kblk)
                 h = resnet_forward(P, f"up_blocks_{i}.resnets_{j}", Act(cat, B, h.H, h.W, h.C + s.C), temb_act, G, 1e-5, tape,
-                                   emit_planes=0 if cfg.cross_attn_down[lvl] else emit)
+                                   emit_planes=0 if cfg.cross_attn_down[lvl] else emit, dest=None if cfg.cross_attn_down[lvl] else nxt)
                 if cfg.cross_attn_down[lvl]:
-                    h = self._transformer(f"up_blocks_{i}.attentions_{j}", h, ctx, Lc, cfg.num_heads[lvl], tape, emit_planes=emit)
+                    h = self._transformer(f"up_blocks_{i}.attentions_{j}", h, ctx, Lc, cfg.num_heads[lvl], tape, emit_planes=emit, dest=nxt)
             if i < nlev - 1:
                 name = f"up_blocks_{i}.upsamplers_0.conv"
                 src = h.pl if (h.pl is not None and L.planes_pay(P[name + ".kernel"], h.C, h.M) == h.pl.fmt + 1) else h.t
-                t, OH, OW = L.conv2d(src, P[name + ".kernel"], P[name + ".bias"], B, h.H, h.W, h.C, h.C, 3, upsample=True)
+                dd = up_dest(kblk)
+                t, OH, OW = L.conv2d(src, P[name + ".kernel"], P[name + ".bias"], B, h.H, h.W, h.C, h.C, 3, upsample=True,
+                                     **({} if dd is None else dict(out=dd, ld_out=int(dd.stride(0)))))
                 if tape is not None:
                     tape.append(("up", dict(name=name, x=h)))
                 h = Act(t, B, OH, OW, h.C)
@@ -515,7 +586,24 @@ class UNet2DCondition:
 
     __call__ = forward
 
-    # -------------------------------------------------------------------------------- HIP-graph replay
+    def _concat_plan(self):
+        """(c0, c1) = (channels of the up path's running activation, channels of the popped skip) of every up block, in consumption order."""
+        cfg = self.cfg
+        boc = cfg.block_out_channels
+        nlev = len(boc)
+        pushed = [boc[0]]
+        for i in range(nlev):
+            pushed += [boc[i]] * cfg.layers_per_block
+            if i < nlev - 1:
+                pushed.append(boc[i])
+        plan, ch, rev = [], boc[-1], boc[::-1]
+        for i in range(nlev):
+            for _ in range(cfg.layers_per_block + 1):
+                plan.append((ch, pushed.pop()))
+                ch = rev[i]
+        assert not pushed
+        return plan
+
     # -------------------------------------------------------------------------------- text-context K/V cache (sampling)
     def cross_attention_names(self):
         return [n[:-len(".to_k.kernel")] for n in self.params.views if n.endswith(".attn2.to_k.kernel")]

@@ -312,3 +312,36 @@ def test_sd21_shaped_config_sampler_and_train_step(datapath):
     finally:
         L.DATAPATH = old
         L.PACKED.clear()
+
+
+@pytest.mark.parametrize("family,ctx_dim,datapath", [("tiny", 64, "fp32"), ("tiny", 64, "bf16x3"), ("tiny21", 96, "bf16x3"), ("tiny", 64, "f16mx")])
+def test_skip_concat_in_place_is_bit_identical_to_copies(family, ctx_dim, datapath, monkeypatch):
+    """Round 4: the sampling forward forms every skip concatenation in place — the down path's producers write their output into its column
+    range of the consuming up block's concat buffer, the up path's producers into the columns in front of it — instead of two ddpo_copy_cols
+    launches per up block.  Only row strides change: outputs (and the planes the sampler convolutions read) must not move by a bit, with and
+    without the CFG-shared front of the network, eagerly and under graph replay."""
+    from ddpo_amd.models import unet as U
+    monkeypatch.setattr(L, "DATAPATH", datapath)
+    if datapath == "f16mx":
+        monkeypatch.setattr(L, "MX_MIN_K", 256)
+    unet = UNet2DCondition(UNetConfig.named(family), DEV)
+    unet.params.init_synthetic(2)
+    if datapath != "fp32":
+        unet.params.pack_bf16(bwd=False)
+    g = torch.Generator().manual_seed(12)
+    x1 = torch.randn(3, 4, 16, 16, generator=g).to(DEV)
+    x = torch.cat([x1, x1])
+    t = torch.full((6,), 481, dtype=torch.int32, device=DEV)
+    c = torch.randn(6, 77, ctx_dim, generator=g).to(DEV)
+    out = {}
+    for inplace in (False, True):
+        monkeypatch.setattr(U, "SKIP_INPLACE", inplace)
+        before = L.gemm_tile_launch_counts()
+        out[inplace] = [unet(x, t, c).clone(), unet(x, t, c, cfg_dup=True).clone(), unet.forward_graphed(x, t, c, cfg_dup=True).clone()]
+        unet._graphs.clear()
+    for a, b in zip(out[False], out[True]):
+        assert torch.equal(a, b)
+    assert torch.equal(out[True][0], out[True][1]) and torch.equal(out[True][1], out[True][2])
+    # the training forward keeps contiguous tensors and the same bits
+    monkeypatch.setattr(U, "SKIP_INPLACE", True)
+    assert torch.equal(unet.forward(x, t, c, tape=[]), out[True][0])
