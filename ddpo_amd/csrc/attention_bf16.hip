@@ -1,15 +1,24 @@
-// Flash attention forward on the bf16 MFMA datapath (v_mfma_f32_32x32x16_bf16) with every operand (Q, K, V and the
-// probabilities P) split into bf16 hi + lo and three MFMA passes per product (a_lo*b_hi + a_hi*b_lo + a_hi*b_hi, fp32
-// accumulate) — the same "bf16x3" arithmetic as gemm_bf16.hip, ~1e-5 relative.  Structure mirrors attention.hip:
-//   S^T (keys x queries) = K Q^T : A = K tile (LDS, [key][dk] bf16), B = Q^T (registers, pre-scaled by scale*log2 e)
-//   O^T (d x queries)    = V^T P^T: A = V^T tile (LDS, [d][key] bf16, transposed while it is staged), B = P^T
-// One workgroup = 4 waves x 32 queries; the 32x32 C fragment of S^T (row = key, col = query = lane&31) is converted
+// Flash attention forward on the 16-bit MFMA datapath.
+//   S^T (keys x queries) = K Q^T : bf16x3 — K and the pre-scaled Q split into bf16 hi + lo, three MFMA passes (a_lo*b_hi + a_hi*b_lo + a_hi*b_hi,
+//                                  fp32 accumulate, ~1e-5 relative: the scores are exponentiated, they keep the full split)
+//   O^T (d x queries)    = V^T P^T: since round 4 the probabilities are ONE f16 term and V is split into f16 hi + lo — two passes of
+//                                  v_mfma_f32_32x32x16_f16 instead of three bf16 passes, and one v_cvt_pk_f16_f32 per probability pair instead of
+//                                  the six-instruction bf16 hi / lo split.  p = exp2(s - m + 14) lies in (0, 2^14]: everything down to 2^-28 of the
+//                                  row maximum is a NORMAL f16 number (11 significant bits, round to nearest even).  The softmax denominator is
+//                                  the sum of the SAME rounded probabilities — row D of V^T is all ones wherever the head dim leaves a spare row
+//                                  of the 32-row MFMA tile (d = 8, 16, 40, 80: the sum falls out of the second product for free), the sum of the
+//                                  values converted back for d = 64 — so O = sum(p~ v) / sum(p~) is an exact convex combination of the values
+//                                  with weights perturbed by <= 2^-12 relative: a row dominated by one key returns that value exactly.
+// Structure mirrors attention.hip: A = K tile (LDS, [key][dk] bf16), B = Q^T (registers); A = V^T tile (LDS, [d][key] f16, transposed while it
+// is staged), B = P^T.  One workgroup = 4 waves x 32 queries; the 32x32 C fragment of S^T (row = key, col = query = lane&31) is converted
 // in registers to the B operand of the second product: for lane half h the 8 k-slots of MFMA step u are the keys
 // 16u + 4h + {0,1,2,3, 8,9,10,11} (exactly the rows that half holds), and the V^T fragment is read with the same map.
 #include "common.h"
 #include <cstdlib>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ uint32_t cvt_pk_bf16_a(float lo, float hi) {
@@ -17,12 +26,112 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16_a(float lo, float hi) {
   asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
   return r;
 }
+__device__ __forceinline__ uint32_t cvt_pk_f16_a(float lo, float hi) {      // round to nearest even (kernel FP mode)
+  uint32_t r;
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
 // two floats -> packed bf16 hi pair and packed bf16 lo pair
 __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
   hi = cvt_pk_bf16_a(a, b);
   lo = cvt_pk_bf16_a(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xFFFF0000u));
 }
+// two floats -> packed f16 hi pair and packed f16 lo pair (the V operand; magnitudes beyond the f16 range saturate)
+__device__ __forceinline__ void split2h(float a, float b, uint32_t& hi, uint32_t& lo) {
+  const float lim = 65504.f;
+  a = fminf(fmaxf(a, -lim), lim);
+  b = fminf(fmaxf(b, -lim), lim);
+  hi = cvt_pk_f16_a(a, b);
+  const f16x2 h = __builtin_bit_cast(f16x2, hi);
+  lo = cvt_pk_f16_a(a - (float)h[0], b - (float)h[1]);
+}
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+#define MFMA32H(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+#define ATTN_P_SHIFT 14.0f            /* p = exp2(s - m + 14): the f16 probabilities use the exponent range [2^-14, 2^14] */
+#define ATTN_F16_ONE 0x3C00u
+
+// Online-softmax step shared by the three kernels below (identical instruction sequence -> identical bits): running maximum, the tile's
+// probabilities as f16 B-operand fragments (step u = 2j + half uses accumulator registers 8 half .. 8 half + 7 of sub-tile j), and — only when
+// the denominator does not come out of the second product (ONES == false) — the sum of the rounded probabilities.
+template <bool ONES>
+__device__ __forceinline__ void attn_softmax_tile(const f32x16 (&sacc)[2], float& m_run, float& l_run, f16x8 (&ph)[4], float& alpha, bool& grew) {
+  float mx = sacc[0][0];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[j][r]);
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  const float m_new = fmaxf(m_run, mx);
+  alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+  grew = m_new > m_run;
+  m_run = m_new;
+  const float m_sh = m_new - ATTN_P_SHIFT;
+  float ls = 0.f;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      uint32_t pk[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float p0 = __builtin_amdgcn_exp2f(sacc[j][8 * half + 2 * e] - m_sh);
+        const float p1 = __builtin_amdgcn_exp2f(sacc[j][8 * half + 2 * e + 1] - m_sh);
+        pk[e] = cvt_pk_f16_a(p0, p1);
+        if (!ONES) {
+          const f16x2 q = __builtin_bit_cast(f16x2, pk[e]);
+          ls += (float)q[0] + (float)q[1];
+        }
+      }
+      ph[2 * j + half] = __builtin_bit_cast(f16x8, make_uint4(pk[0], pk[1], pk[2], pk[3]));
+    }
+  }
+  if (!ONES) l_run = l_run * alpha + ls;
+}
+
+// O^T += V^T P^T for one 64-key tile: A fragment of step u = V^T[d = 32n + li][16u + 4h + {0..3, 8..11}] (f16 hi / lo planes in LDS), B = ph[u].
+// Per accumulator the order is fixed (lo then hi, u ascending) — shared by all three kernels; the fragments of step u + 1 are requested before
+// the MFMAs of step u are issued, and the two passes of a step alternate between the accumulators.
+template <int NDT, int LDVT, int QB = 1>
+__device__ __forceinline__ void attn_pv_tile(const char* Vhi, const char* Vlo, int li, int h, const f16x8 (*ph)[4], f32x16 (*oacc)[NDT]) {
+  f16x8 vh[2][NDT], vl[2][NDT];
+  auto fetch = [&](int u, int slot) {
+#pragma unroll
+    for (int n = 0; n < NDT; ++n) {
+      const int off = ((32 * n + li) * LDVT + 16 * u + 4 * h) * 2;
+      const uint2 a0 = *reinterpret_cast<const uint2*>(Vhi + off), a1 = *reinterpret_cast<const uint2*>(Vhi + off + 16);
+      const uint2 c0 = *reinterpret_cast<const uint2*>(Vlo + off), c1 = *reinterpret_cast<const uint2*>(Vlo + off + 16);
+      vh[slot][n] = __builtin_bit_cast(f16x8, make_uint4(a0.x, a0.y, a1.x, a1.y));
+      vl[slot][n] = __builtin_bit_cast(f16x8, make_uint4(c0.x, c0.y, c1.x, c1.y));
+    }
+  };
+  fetch(0, 0);
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    if (u + 1 < 4) fetch(u + 1, (u + 1) & 1);
+    __builtin_amdgcn_sched_barrier(0);       // keep the requests of step u + 1 in front of the MFMAs of step u (the scheduler sinks them otherwise)
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+      for (int n = 0; n < NDT; ++n) oacc[qb][n] = MFMA32H(vl[u & 1][n], ph[qb][u], oacc[qb][n]);
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+      for (int n = 0; n < NDT; ++n) oacc[qb][n] = MFMA32H(vh[u & 1][n], ph[qb][u], oacc[qb][n]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// softmax denominator of query li (scaled by 2^14 like the accumulators): row D of O^T where V^T carries the ones row, else the running sum
+template <int D, int NDT, bool ONES>
+__device__ __forceinline__ float attn_row_sum(const f32x16 (&oacc)[NDT], float l_run, int li) {
+  if constexpr (ONES) {
+    constexpr int n1 = D / 32, r1 = D % 32;
+    static_assert(r1 % 8 == 0 && n1 < NDT, "row D must be register 4 (r1 / 8) of the lanes with h == 0");
+    return __shfl(oacc[n1][4 * (r1 / 8)], li, 64);         // registers 4g .. 4g+3 of lane (li, h) are rows 32n + 8g + 4h + {0..3}
+  } else {
+    return l_run + __shfl_xor(l_run, 32, 64);
+  }
+}
 
 template <int D, int DKP, int DVP>     // head dim, padded to 16 (QK^T reduction) and to 32 (rows of O^T)
 __global__ void __launch_bounds__(256) attn_fwd_bf16_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
@@ -30,9 +139,10 @@ __global__ void __launch_bounds__(256) attn_fwd_bf16_kernel(const float* __restr
                                                             float* __restrict__ lse, int heads, int Nq, int Nk, float scale_log2e) {
   constexpr int KT = 64;                  // keys per tile
   constexpr int LDK = DKP + 8;            // bf16 per K row: (DKP+8)*2 bytes = odd multiple of 16 B -> conflict-free b128 rows
-  constexpr int LDVT = KT + 4;            // bf16 per V^T row: 136 B -> 32 rows hit distinct even banks for ds_read_b64
+  constexpr int LDVT = KT + 4;            // f16 per V^T row: 136 B -> 32 rows hit distinct even banks for ds_read_b64
   constexpr int NKS = DKP / 16;           // k-steps of S^T
   constexpr int NDT = DVP / 32;           // 32-row tiles of O^T
+  constexpr bool ONES = DVP > D;          // V^T row D = 1: the softmax denominator is row D of O^T
   constexpr int K_BYTES = KT * LDK * 2, VT_BYTES = DVP * LDVT * 2;
   __shared__ __attribute__((aligned(16))) char smem[2 * K_BYTES + 2 * VT_BYTES];
   char* Khi = smem; char* Klo = smem + K_BYTES;
@@ -62,8 +172,12 @@ __global__ void __launch_bounds__(256) attn_fwd_bf16_kernel(const float* __restr
       ql[s] = __builtin_bit_cast(bf16x8, make_uint4(lo[0], lo[1], lo[2], lo[3]));
     }
   }
-  // zero the padding of both LDS images once (K columns D..DKP, V^T rows D..DVP are never written again)
+  // zero the padding of both LDS images once (K columns D..DKP, V^T rows D..DVP are never written again), then the ones row of V^T hi
   for (int i = t; i < (2 * K_BYTES + 2 * VT_BYTES) / 16; i += 256) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0u, 0u, 0u, 0u);
+  if constexpr (ONES) {
+    __syncthreads();
+    if (t < KT) reinterpret_cast<uint16_t*>(Vhi)[D * LDVT + t] = (uint16_t)ATTN_F16_ONE;
+  }
 
   f32x16 oacc[NDT];
 #pragma unroll
@@ -76,7 +190,7 @@ __global__ void __launch_bounds__(256) attn_fwd_bf16_kernel(const float* __restr
 
   for (int kt0 = 0; kt0 < Nk; kt0 += KT) {
     __syncthreads();
-    // stage K (row-major) and V (transposed) as bf16 hi / lo
+    // stage K (row-major, bf16 hi / lo) and V (transposed, f16 hi / lo)
     for (int i = t; i < KT * (D / 4); i += 256) {
       const int key = i / (D / 4), c4 = i - key * (D / 4);
       float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
@@ -89,8 +203,8 @@ __global__ void __launch_bounds__(256) attn_fwd_bf16_kernel(const float* __restr
       split2(kv.z, kv.w, h1, l1);
       *reinterpret_cast<uint2*>(Khi + (key * LDK + c4 * 4) * 2) = make_uint2(h0, h1);
       *reinterpret_cast<uint2*>(Klo + (key * LDK + c4 * 4) * 2) = make_uint2(l0, l1);
-      split2(vv.x, vv.y, h0, l0);
-      split2(vv.z, vv.w, h1, l1);
+      split2h(vv.x, vv.y, h0, l0);
+      split2h(vv.z, vv.w, h1, l1);
       uint16_t* vh = reinterpret_cast<uint16_t*>(Vhi);
       uint16_t* vl = reinterpret_cast<uint16_t*>(Vlo);
       const int d0 = c4 * 4;
@@ -120,62 +234,30 @@ __global__ void __launch_bounds__(256) attn_fwd_bf16_kernel(const float* __restr
       }
     }
     // ---- online softmax: query = lane column; this lane holds keys 32j + (r&3) + 8(r>>2) + 4h
-    float mx = -INFINITY;
+    if (kt0 + KT > Nk) {                   // only the last tile can hold padded keys (uniform branch)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        if (kt0 + 32 * j + (r & 3) + 8 * (r >> 2) + 4 * h >= Nk) sacc[j][r] = -INFINITY;
-        mx = fmaxf(mx, sacc[j][r]);
-      }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = exp2f(m_run - m_new);
-    m_run = m_new;
-    float ls = 0.f;
-    // P^T as B-operand fragments: step u = 2j + (r>>3) uses registers 8(u&1) .. +8 of sub-tile j
-    bf16x8 ph[4], pl[4];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        uint32_t hi[4], lo[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float p0 = exp2f(sacc[j][8 * half + 2 * e] - m_new);
-          const float p1 = exp2f(sacc[j][8 * half + 2 * e + 1] - m_new);
-          ls += p0 + p1;
-          split2(p0, p1, hi[e], lo[e]);
-        }
-        ph[2 * j + half] = __builtin_bit_cast(bf16x8, make_uint4(hi[0], hi[1], hi[2], hi[3]));
-        pl[2 * j + half] = __builtin_bit_cast(bf16x8, make_uint4(lo[0], lo[1], lo[2], lo[3]));
-      }
+        for (int r = 0; r < 16; ++r)
+          if (kt0 + 32 * j + (r & 3) + 8 * (r >> 2) + 4 * h >= Nk) sacc[j][r] = -INFINITY;
     }
-    l_run = l_run * alpha + ls;
+    f16x8 ph[4];
+    float alpha;
+    bool grew;
+    attn_softmax_tile<ONES>(sacc, m_run, l_run, ph, alpha, grew);
+    if (__any(grew)) {                     // the running maximum settles after a few tiles; skip the no-op rescale (alpha == 1)
 #pragma unroll
-    for (int n = 0; n < NDT; ++n)
+      for (int n = 0; n < NDT; ++n)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[n][r] *= alpha;
+        for (int r = 0; r < 16; ++r) oacc[n][r] *= alpha;
+    }
     // ---- O^T += V^T P^T ; A fragment of step u: V^T[d = 32n + li][16u + 4h + {0..3, 8..11}]
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-#pragma unroll
-      for (int n = 0; n < NDT; ++n) {
-        const int off = ((32 * n + li) * LDVT + 16 * u + 4 * h) * 2;
-        const uint2 a0 = *reinterpret_cast<const uint2*>(Vhi + off), a1 = *reinterpret_cast<const uint2*>(Vhi + off + 16);
-        const uint2 c0 = *reinterpret_cast<const uint2*>(Vlo + off), c1 = *reinterpret_cast<const uint2*>(Vlo + off + 16);
-        const bf16x8 vh = __builtin_bit_cast(bf16x8, make_uint4(a0.x, a0.y, a1.x, a1.y));
-        const bf16x8 vl = __builtin_bit_cast(bf16x8, make_uint4(c0.x, c0.y, c1.x, c1.y));
-        oacc[n] = MFMA32(vl, ph[u], oacc[n]);
-        oacc[n] = MFMA32(vh, pl[u], oacc[n]);
-        oacc[n] = MFMA32(vh, ph[u], oacc[n]);
-      }
-    }
+    attn_pv_tile<NDT, LDVT>(Vhi, Vlo, li, h, &ph, &oacc);
   }
 
-  float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float l_tot = attn_row_sum<D, NDT, ONES>(oacc, l_run, li);
   const float inv = 1.0f / l_tot;
-  if (lse && h == 0 && q0 + li < Nq) lse[(int64_t)bh * Nq + q0 + li] = m_run + log2f(l_tot);
+  if (lse && h == 0 && q0 + li < Nq) lse[(int64_t)bh * Nq + q0 + li] = m_run + log2f(l_tot) - ATTN_P_SHIFT;
   if (q0 + li < Nq) {
     float* op = o + ((int64_t)b * Nq + q0 + li) * ldo + hd * D;
 #pragma unroll
@@ -217,6 +299,7 @@ __global__ void __launch_bounds__(256) attn_pack_kv_kernel(const float* __restri
   const int kt0 = tile * I::KT;
   for (int i = t; i < I::CHUNKS; i += 256) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0u, 0u, 0u, 0u);
   __syncthreads();
+  if (DVP > D && t < I::KT) reinterpret_cast<uint16_t*>(Vhi)[D * I::LDVT + t] = (uint16_t)ATTN_F16_ONE;      // the ones row (softmax denominator)
   const float* kb = k + (int64_t)b * Nk * ldk + hd * D;
   const float* vb = v + (int64_t)b * Nk * ldv + hd * D;
   for (int i = t; i < I::KT * (D / 4); i += 256) {
@@ -229,8 +312,8 @@ __global__ void __launch_bounds__(256) attn_pack_kv_kernel(const float* __restri
     split2(kv.z, kv.w, h1, l1);
     *reinterpret_cast<uint2*>(Khi + (key * I::LDK + c4 * 4) * 2) = make_uint2(h0, h1);
     *reinterpret_cast<uint2*>(Klo + (key * I::LDK + c4 * 4) * 2) = make_uint2(l0, l1);
-    split2(vv.x, vv.y, h0, l0);
-    split2(vv.z, vv.w, h1, l1);
+    split2h(vv.x, vv.y, h0, l0);
+    split2h(vv.z, vv.w, h1, l1);
     uint16_t* vh = reinterpret_cast<uint16_t*>(Vhi);
     uint16_t* vl = reinterpret_cast<uint16_t*>(Vlo);
     const int d0 = c4 * 4;
@@ -251,6 +334,7 @@ __global__ void __launch_bounds__(256, (DVP <= 32 ? 4 : (DKP <= 48 ? 3 : 2))) at
   using I = AttnImg<D, DKP, DVP>;
   constexpr int KT = I::KT, LDK = I::LDK, LDVT = I::LDVT;
   constexpr int NKS = DKP / 16, NDT = DVP / 32;
+  constexpr bool ONES = DVP > D;
   constexpr int NCH = (I::CHUNKS + 255) / 256;
   __shared__ __attribute__((aligned(16))) char smem[I::BYTES];
   const char* Khi = smem; const char* Klo = smem + I::K_BYTES;
@@ -337,60 +421,22 @@ __global__ void __launch_bounds__(256, (DVP <= 32 ? 4 : (DKP <= 48 ? 3 : 2))) at
         for (int r = 0; r < 16; ++r)
           if (kt0 + 32 * j + (r & 3) + 8 * (r >> 2) + 4 * h >= Nk) sacc[j][r] = -INFINITY;
     }
-    float mx = sacc[0][0];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[j][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    const bool grew = m_new > m_run;
-    m_run = m_new;
-    float ls = 0.f;
-    bf16x8 ph[4], pl[4];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        uint32_t hi[4], lo[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float p0 = __builtin_amdgcn_exp2f(sacc[j][8 * half + 2 * e] - m_new);
-          const float p1 = __builtin_amdgcn_exp2f(sacc[j][8 * half + 2 * e + 1] - m_new);
-          ls += p0 + p1;
-          split2(p0, p1, hi[e], lo[e]);
-        }
-        ph[2 * j + half] = __builtin_bit_cast(bf16x8, make_uint4(hi[0], hi[1], hi[2], hi[3]));
-        pl[2 * j + half] = __builtin_bit_cast(bf16x8, make_uint4(lo[0], lo[1], lo[2], lo[3]));
-      }
-    }
-    l_run = l_run * alpha + ls;
+    f16x8 ph[4];
+    float alpha;
+    bool grew;
+    attn_softmax_tile<ONES>(sacc, m_run, l_run, ph, alpha, grew);
     if (__any(grew)) {                     // the running maximum settles after a few tiles; skip the no-op rescale (alpha == 1)
 #pragma unroll
       for (int n = 0; n < NDT; ++n)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[n][r] *= alpha;
     }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-#pragma unroll
-      for (int n = 0; n < NDT; ++n) {
-        const int off = ((32 * n + li) * LDVT + 16 * u + 4 * h) * 2;
-        const uint2 a0 = *reinterpret_cast<const uint2*>(Vhi + off), a1 = *reinterpret_cast<const uint2*>(Vhi + off + 16);
-        const uint2 c0 = *reinterpret_cast<const uint2*>(Vlo + off), c1 = *reinterpret_cast<const uint2*>(Vlo + off + 16);
-        const bf16x8 vh = __builtin_bit_cast(bf16x8, make_uint4(a0.x, a0.y, a1.x, a1.y));
-        const bf16x8 vl = __builtin_bit_cast(bf16x8, make_uint4(c0.x, c0.y, c1.x, c1.y));
-        oacc[n] = MFMA32(vl, ph[u], oacc[n]);
-        oacc[n] = MFMA32(vh, pl[u], oacc[n]);
-        oacc[n] = MFMA32(vh, ph[u], oacc[n]);
-      }
-    }
+    attn_pv_tile<NDT, LDVT>(Vhi, Vlo, li, h, &ph, &oacc);
   }
 
-  float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float l_tot = attn_row_sum<D, NDT, ONES>(oacc, l_run, li);
   const float inv = 1.0f / l_tot;
-  if (lse && h == 0 && q0 + li < Nq) lse[(int64_t)bh * Nq + q0 + li] = m_run + log2f(l_tot);
+  if (lse && h == 0 && q0 + li < Nq) lse[(int64_t)bh * Nq + q0 + li] = m_run + log2f(l_tot) - ATTN_P_SHIFT;
   if (q0 + li < Nq) {
     float* op = o + ((int64_t)b * Nq + q0 + li) * ldo + hd * D;
 #pragma unroll
@@ -431,6 +477,7 @@ __global__ void __launch_bounds__(256, (QB == 2 ? 2 : (DVP <= 32 ? 4 : (DKP <= 4
   using I = AttnImg<D, DKP, DVP>;
   constexpr int KT = I::KT, LDK = I::LDK, LDVT = I::LDVT;
   constexpr int NKS = DKP / 16, NDT = DVP / 32;
+  constexpr bool ONES = DVP > D;
   constexpr int KP = 2 * I::K_BYTES, VP = 2 * I::VT_BYTES;          // K part (hi | lo) and V^T part (hi | lo) of an image
   static_assert(KP % 1024 == 0 && VP % 1024 == 0, "LDS-DMA moves whole KiB pieces");
   constexpr int NPK = KP / 1024, NPV = VP / 1024;
@@ -497,7 +544,7 @@ __global__ void __launch_bounds__(256, (QB == 2 ? 2 : (DVP <= 32 ? 4 : (DKP <= 4
     fill(2 * KP, KP, NPV, tile);                                   // V(tile) -> V region (nobody reads V(tile - 1) any more)
     if (tile + 1 < ntiles) fill((tile & 1) ? 0 : KP, 0, NPK, tile + 1);   // K(tile + 1) -> the other K region
 
-    bf16x8 ph[QB][4], pl[QB][4];
+    f16x8 ph[QB][4];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
       f32x16 sacc[2];
@@ -524,34 +571,9 @@ __global__ void __launch_bounds__(256, (QB == 2 ? 2 : (DVP <= 32 ? 4 : (DKP <= 4
           for (int r = 0; r < 16; ++r)
             if (kt0 + 32 * j + (r & 3) + 8 * (r >> 2) + 4 * h >= Nk) sacc[j][r] = -INFINITY;
       }
-      float mx = sacc[0][0];
-  #pragma unroll
-      for (int j = 0; j < 2; ++j)
-  #pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[j][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run[qb], mx);
-      const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_new);
-      const bool grew = m_new > m_run[qb];
-      m_run[qb] = m_new;
-      float ls = 0.f;
-  #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-  #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-          uint32_t hi[4], lo[4];
-  #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float p0 = __builtin_amdgcn_exp2f(sacc[j][8 * half + 2 * e] - m_new);
-            const float p1 = __builtin_amdgcn_exp2f(sacc[j][8 * half + 2 * e + 1] - m_new);
-            ls += p0 + p1;
-            split2(p0, p1, hi[e], lo[e]);
-          }
-          ph[qb][2 * j + half] = __builtin_bit_cast(bf16x8, make_uint4(hi[0], hi[1], hi[2], hi[3]));
-          pl[qb][2 * j + half] = __builtin_bit_cast(bf16x8, make_uint4(lo[0], lo[1], lo[2], lo[3]));
-        }
-      }
-      l_run[qb] = l_run[qb] * alpha + ls;
+      float alpha;
+      bool grew;
+      attn_softmax_tile<ONES>(sacc, m_run[qb], l_run[qb], ph[qb], alpha, grew);
       if (__any(grew)) {
   #pragma unroll
         for (int n = 0; n < NDT; ++n)
@@ -562,31 +584,15 @@ __global__ void __launch_bounds__(256, (QB == 2 ? 2 : (DVP <= 32 ? 4 : (DKP <= 4
     // V(tile) (and K(tile + 1)) have landed; my K fragment reads have returned
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-#pragma unroll
-      for (int n = 0; n < NDT; ++n) {
-        const int off = ((32 * n + li) * LDVT + 16 * u + 4 * h) * 2;
-        const uint2 a0 = *reinterpret_cast<const uint2*>(Vhi + off), a1 = *reinterpret_cast<const uint2*>(Vhi + off + 16);
-        const uint2 c0 = *reinterpret_cast<const uint2*>(Vlo + off), c1 = *reinterpret_cast<const uint2*>(Vlo + off + 16);
-        const bf16x8 vh = __builtin_bit_cast(bf16x8, make_uint4(a0.x, a0.y, a1.x, a1.y));
-        const bf16x8 vl = __builtin_bit_cast(bf16x8, make_uint4(c0.x, c0.y, c1.x, c1.y));
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb) {          // one V^T fragment, QB query blocks
-          oacc[qb][n] = MFMA32(vl, ph[qb][u], oacc[qb][n]);
-          oacc[qb][n] = MFMA32(vh, pl[qb][u], oacc[qb][n]);
-          oacc[qb][n] = MFMA32(vh, ph[qb][u], oacc[qb][n]);
-        }
-      }
-    }
+    attn_pv_tile<NDT, LDVT, QB>(Vhi, Vlo, li, h, ph, oacc);      // one V^T fragment feeds QB query blocks
   }
 
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
     const int qi = q0 + 32 * qb + li;
-    const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
+    const float l_tot = attn_row_sum<D, NDT, ONES>(oacc[qb], l_run[qb], li);
     const float inv = 1.0f / l_tot;
-    if (lse && h == 0 && qi < Nq) lse[(int64_t)bh * Nq + qi] = m_run[qb] + log2f(l_tot);
+    if (lse && h == 0 && qi < Nq) lse[(int64_t)bh * Nq + qi] = m_run[qb] + log2f(l_tot) - ATTN_P_SHIFT;
     if (qi < Nq) {
       float* op = o + ((int64_t)b * Nq + qi) * ldo + hd * D;
 #pragma unroll

@@ -522,16 +522,22 @@ def ddim_step_fwd(eps_u, eps_c, x, z, ts, guidance_scale, consts, x_next=None, l
 
 
 def ddim_logprob_ppo_fwd_bwd(eps_c, eps_u, x, x_next, ts, old_logp, advantages, guidance_scale, clip_range, train_cfg, consts,
-                             group=None):
+                             group=None, out=None):
     """`group` (default: the whole batch) = rows per PPO micro-batch when several micro-batches are scored in one call:
-    rows [j*group, (j+1)*group) are micro-batch j, each with its own mean loss; info comes back as (B // group, 3)."""
+    rows [j*group, (j+1)*group) are micro-batch j, each with its own mean loss; info comes back as (B // group, 3).
+    out: optional pre-allocated (d_c, d_u, per_sample, info) of a previous call with the same geometry (the launch then allocates nothing)."""
     B = x.shape[0]
     chw = x.numel() // B
-    d_c = torch.empty_like(eps_c)
-    d_u = torch.empty_like(eps_c) if train_cfg else None
-    per_sample = torch.empty(B, 4, dtype=torch.float32, device=x.device)
+    if out is not None:
+        d_c, d_u, per_sample, info = out
+    else:
+        d_c = torch.empty_like(eps_c)
+        d_u = torch.empty_like(eps_c) if train_cfg else None
+        per_sample = torch.empty(B, 4, dtype=torch.float32, device=x.device)
+        info = None
     if group is None:
-        info = torch.empty(3, dtype=torch.float32, device=x.device)
+        if info is None:
+            info = torch.empty(3, dtype=torch.float32, device=x.device)
         _check(load().ddpo_ddim_logprob_ppo_fwd_bwd(_p(eps_c), _p(eps_u), _p(x), _p(x_next), _p(ts), _p(old_logp), _p(advantages),
                                                     float(guidance_scale), float(clip_range), int(bool(train_cfg)), byref(consts),
                                                     _p(d_c), _p(d_u), _p(per_sample), _p(info), B, chw, _stream()),
@@ -539,7 +545,8 @@ def ddim_logprob_ppo_fwd_bwd(eps_c, eps_u, x, x_next, ts, old_logp, advantages, 
     else:
         if group <= 0 or B % group:
             raise ValueError(f"batch of {B} rows is not a whole number of micro-batches of {group}")
-        info = torch.empty(B // group, 3, dtype=torch.float32, device=x.device)
+        if info is None:
+            info = torch.empty(B // group, 3, dtype=torch.float32, device=x.device)
         _check(load().ddpo_ddim_logprob_ppo_fwd_bwd_grouped(_p(eps_c), _p(eps_u), _p(x), _p(x_next), _p(ts), _p(old_logp),
                                                             _p(advantages), float(guidance_scale), float(clip_range),
                                                             int(bool(train_cfg)), byref(consts), _p(d_c), _p(d_u), _p(per_sample),
