@@ -229,30 +229,22 @@ extern "C" int ddpo_groupnorm_fwd_planes(const float* x, int ldx, uint16_t* y_hi
 // LayerNorm: one wave per row, row held in registers (C <= 64*4*LN_MAXV = 2560)
 // ------------------------------------------------------------------------------------------------
 #define LN_MAXV 10
-template <bool PL>
-__global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                        int rows, int C, float eps, uint16_t* __restrict__ y_hi,
-                                                        uint16_t* __restrict__ y_lo, int pair, int ldy = -1) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const int C4 = C >> 2;
-  const float* xr = x + (int64_t)row * C;
-  float4 v[LN_MAXV];
+#define LN_RPW 4          // rows per wave of the batched variant (C <= 512: two float4 per lane and row)
+// One row's arithmetic (shared by both kernels: identical lane assignment, summation order and rounding -> identical bits)
+template <bool PL, int NV>
+__device__ __forceinline__ void ln_row(const float4 (&v)[NV], int lane, int C4, int C, float eps, int64_t row, int64_t rows, float* __restrict__ y,
+                                       const float* __restrict__ gamma, const float* __restrict__ beta, uint16_t* __restrict__ y_hi,
+                                       uint16_t* __restrict__ y_lo, int pair, int ldy) {
   float s = 0.f;
 #pragma unroll
-  for (int j = 0; j < LN_MAXV; ++j) {
+  for (int j = 0; j < NV; ++j) {
     const int c4 = lane + j * 64;
-    if (c4 < C4) {
-      v[j] = *reinterpret_cast<const float4*>(xr + (c4 << 2));
-      s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
-    }
+    if (c4 < C4) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
   }
   const float mean = wave_sum(s) / (float)C;
   float q = 0.f;
 #pragma unroll
-  for (int j = 0; j < LN_MAXV; ++j) {
+  for (int j = 0; j < NV; ++j) {
     const int c4 = lane + j * 64;
     if (c4 < C4) {
       const float a = v[j].x - mean, b = v[j].y - mean, c = v[j].z - mean, d = v[j].w - mean;
@@ -260,9 +252,9 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
     }
   }
   const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
-  float* yr = y + (int64_t)row * C;
+  float* yr = PL ? nullptr : y + row * C;
 #pragma unroll
-  for (int j = 0; j < LN_MAXV; ++j) {
+  for (int j = 0; j < NV; ++j) {
     const int c4 = lane + j * 64;
     if (c4 < C4) {
       const float4 g = *reinterpret_cast<const float4*>(gamma + (c4 << 2));
@@ -293,11 +285,61 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
   }
 }
 
+template <bool PL>
+__global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        int rows, int C, float eps, uint16_t* __restrict__ y_hi,
+                                                        uint16_t* __restrict__ y_lo, int pair, int ldy = -1) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int C4 = C >> 2;
+  const float* xr = x + (int64_t)row * C;
+  float4 v[LN_MAXV];
+#pragma unroll
+  for (int j = 0; j < LN_MAXV; ++j) {
+    const int c4 = lane + j * 64;
+    if (c4 < C4) v[j] = *reinterpret_cast<const float4*>(xr + (c4 << 2));
+  }
+  ln_row<PL, LN_MAXV>(v, lane, C4, C, eps, row, rows, y, gamma, beta, y_hi, y_lo, pair, ldy);
+}
+
+// Narrow rows (C <= 512, i.e. the 64x64 / 32x32-level transformer blocks: 65536 / 16384 rows of 320 / 640 channels): one row per wave leaves
+// a single 1 KiB + 256 B request in flight per wave and the kernel latency-bound at ~2.9 TB/s; here a wave requests LN_RPW rows before it
+// reduces the first.  Per-row arithmetic is ln_row's: bit-identical to layernorm_kernel.
+template <bool PL>
+__global__ void __launch_bounds__(256) layernorm_rows_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             int rows, int C, float eps, uint16_t* __restrict__ y_hi,
+                                                             uint16_t* __restrict__ y_lo, int pair, int ldy = -1) {
+  const int lane = threadIdx.x & 63;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * LN_RPW;
+  if (row0 >= rows) return;
+  const int C4 = C >> 2;
+  float4 v[LN_RPW][2];
+#pragma unroll
+  for (int r = 0; r < LN_RPW; ++r) {
+    const float* xr = x + (int64_t)min(row0 + r, rows - 1) * C;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c4 = lane + j * 64;
+      if (c4 < C4) v[r][j] = *reinterpret_cast<const float4*>(xr + (c4 << 2));
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < LN_RPW; ++r)
+    if (row0 + r < rows) ln_row<PL, 2>(v[r], lane, C4, C, eps, row0 + r, rows, y, gamma, beta, y_hi, y_lo, pair, ldy);
+}
+
 extern "C" int ddpo_layernorm_fwd(const float* x, float* y, const float* gamma, const float* beta, int rows, int C, float eps,
                                   void* stream) {
   if (!x || !y || !gamma || !beta || rows <= 0 || C <= 0 || (C & 3) || C > 256 * LN_MAXV) return DDPO_EINVAL;
   uint16_t* const no = nullptr;
-  hipLaunchKernelGGL(layernorm_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, as_stream(stream), x, y, gamma, beta, rows, C, eps, no, no, 0);
+  if (C <= 512 && rows >= 4096)
+    hipLaunchKernelGGL(layernorm_rows_kernel<false>, dim3((rows + 4 * LN_RPW - 1) / (4 * LN_RPW)), dim3(256), 0, as_stream(stream), x, y, gamma, beta, rows, C,
+                       eps, no, no, 0);
+  else
+    hipLaunchKernelGGL(layernorm_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, as_stream(stream), x, y, gamma, beta, rows, C, eps, no, no, 0);
   DDPO_LAUNCH_CHECK();
   return DDPO_OK;
 }
@@ -311,8 +353,12 @@ extern "C" int ddpo_layernorm_fwd_planes(const float* x, uint16_t* y_hi, uint16_
   if ((reinterpret_cast<uintptr_t>(y_hi) | reinterpret_cast<uintptr_t>(y_lo)) & 7) return DDPO_EINVAL;
   float* const nof = nullptr;
   const int pair = mx ? 2 : ((C & 7) == 0 && ((reinterpret_cast<uintptr_t>(y_hi) | reinterpret_cast<uintptr_t>(y_lo)) & 15) == 0) ? 1 : 0;
-  hipLaunchKernelGGL(layernorm_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, as_stream(stream), x, nof, gamma, beta, rows, C, eps, y_hi,
-                     y_lo, pair, kblocked ? 0 : C);
+  if (C <= 512 && rows >= 4096)
+    hipLaunchKernelGGL(layernorm_rows_kernel<true>, dim3((rows + 4 * LN_RPW - 1) / (4 * LN_RPW)), dim3(256), 0, as_stream(stream), x, nof, gamma, beta, rows, C,
+                       eps, y_hi, y_lo, pair, kblocked ? 0 : C);
+  else
+    hipLaunchKernelGGL(layernorm_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, as_stream(stream), x, nof, gamma, beta, rows, C, eps, y_hi,
+                       y_lo, pair, kblocked ? 0 : C);
   DDPO_LAUNCH_CHECK();
   return DDPO_OK;
 }

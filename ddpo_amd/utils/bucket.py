@@ -96,7 +96,12 @@ class LocalWriter:
     def __init__(self, savepath, split_size=1000, rank=0):
         self.savepath, self.split_size, self.rank = savepath, int(split_size), int(rank)
         os.makedirs(savepath, exist_ok=True)
+        # shards of an EARLIER run of this rank into the same directory (fewer shards now, another split_size) must not survive next to the
+        # new ones; other ranks' files are theirs to clean.  The manifest written by close() is what LocalReader trusts.
+        for stale in glob.glob(os.path.join(savepath, f"{self.rank}_*.npz")) + glob.glob(os.path.join(savepath, f"manifest_{self.rank}.json")):
+            os.remove(stale)
         self._encode, self._rows, self._shard, self._total = {}, [], 0, 0
+        self._files = []
 
     def configure(self, field, max_size=None, vlen=False, encode_fn=None, decode_fn=None):
         self._encode[field] = encode_fn
@@ -129,11 +134,17 @@ class LocalWriter:
             arr = np.empty(len(vals), dtype=object)
             arr[:] = vals
             cols[k] = arr
-        np.savez(os.path.join(self.savepath, f"{self.rank}_{self._shard:05d}.npz"), **cols)
+        name = f"{self.rank}_{self._shard:05d}.npz"
+        np.savez(os.path.join(self.savepath, name), **cols)
+        self._files.append({"file": name, "rows": len(self._rows)})
         self._rows, self._shard = [], self._shard + 1
 
-    def close(self, metadata=None):
+    def close(self, metadata=None, world=1):
+        """Flush, write this rank's manifest (its shard files and row counts; `world` = number of ranks writing into this directory) and, on
+        rank 0, metadata.json."""
         self._flush()
+        with open(os.path.join(self.savepath, f"manifest_{self.rank}.json"), "w") as f:
+            json.dump({"rank": self.rank, "world": int(world), "n_samples": self._total, "shards": self._files}, f, indent=2)
         if metadata is not None and self.rank == 0:
             with open(os.path.join(self.savepath, "metadata.json"), "w") as f:
                 json.dump(metadata, f, indent=2, default=str)
@@ -141,7 +152,25 @@ class LocalWriter:
 
 class LocalReader:
     def __init__(self, loadpath):
-        files = sorted(glob.glob(os.path.join(loadpath, "*.npz")))
+        """Reads exactly the shards the writers' manifests list (manifest_<rank>.json, one per rank of the sampling run: a stale shard of an
+        earlier run with more ranks / shards is ignored, a missing listed shard or a missing rank's manifest is an error); a directory without
+        manifests (written before round 4) falls back to every *.npz."""
+        manifests = sorted(glob.glob(os.path.join(loadpath, "manifest_*.json")))
+        if manifests:
+            metas = [json.load(open(m)) for m in manifests]
+            r0 = [m for m in metas if int(m["rank"]) == 0]
+            if not r0:
+                raise FileNotFoundError(f"'{loadpath}': rank 0's manifest is missing")
+            world = int(r0[0].get("world", 1))           # the run that wrote LAST is rank 0's: a stale manifest of a wider earlier run is ignored
+            ranks = sorted(int(m["rank"]) for m in metas if int(m["rank"]) < world)
+            if ranks != list(range(world)):
+                raise FileNotFoundError(f"'{loadpath}': manifests of ranks {ranks} found, the sampling run had {world} ranks")
+            files = [os.path.join(loadpath, sh["file"]) for m in sorted(metas, key=lambda m: int(m["rank"])) if int(m["rank"]) < world for sh in m["shards"]]
+            missing = [f for f in files if not os.path.exists(f)]
+            if missing:
+                raise FileNotFoundError(f"'{loadpath}': shards listed in the manifest are missing: {missing[:3]}")
+        else:
+            files = sorted(glob.glob(os.path.join(loadpath, "*.npz")))
         if not files:
             raise FileNotFoundError(f"no sample shards (*.npz) in '{loadpath}'")
         self._cols = {}

@@ -64,6 +64,7 @@ def resolve_pretrained(pretrained_model, cache="cache"):
         return pm
     roots = [r for r in (cache, os.path.join(os.environ["HF_HOME"], "hub") if os.environ.get("HF_HOME") else None,
                          os.environ.get("HUGGINGFACE_HUB_CACHE"), os.path.expanduser("~/.cache/huggingface/hub")) if r]
+    missing_rev = None                   # a wanted revision absent from one cache root may still be in a later one: raise only at the end
     for root in roots:
         repo = os.path.join(root, "models--" + pm.replace("/", "--"))
         snaps = [d for d in glob.glob(os.path.join(repo, "snapshots", "*")) if os.path.isdir(d)]
@@ -82,11 +83,16 @@ def resolve_pretrained(pretrained_model, cache="cache"):
                 if want and os.path.basename(d) == want:
                     return d
             if want and ref != "main":
-                raise FileNotFoundError(f"revision '{ref}' of '{pm}' is not in the cache '{repo}'")
-            return max(snaps, key=os.path.getmtime)
+                missing_rev = missing_rev or repo
+                continue
+            pick = max(snaps, key=lambda d: (os.path.getmtime(d), os.path.basename(d)))      # ties broken by name: deterministic on one machine
+            print(f"[ utils/serialization ] '{pm}': no usable refs/{ref} in '{repo}', using the most recently written snapshot {os.path.basename(pick)}")
+            return pick
         for cand in (os.path.join(root, pm), os.path.join(root, pm.split("/")[-1])):
             if os.path.isdir(cand):
                 return cand
+    if missing_rev is not None:
+        raise FileNotFoundError(f"revision '{os.environ.get('DDPO_PRETRAINED_REVISION')}' of '{pm}' is in none of the caches searched (first: '{missing_rev}')")
     return None
 
 

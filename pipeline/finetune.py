@@ -42,7 +42,11 @@ def main(argv=None):
     from ddpo_amd import lib as L
     L.DATAPATH = L.shipped_datapath()
 
-    args = Parser(argv).parse_args("train")                  # one seed for the whole pod: transformers.set_seed(args.seed), reference :52
+    # Rank mapping: every rank is a reference PROCESS with one local device — the multi-host run of the reference.  Its parser
+    # offsets the seed by jax.process_index() (/root/reference/ddpo/utils/parser.py:173-178), BucketDataset.shard() gives process p the p-th
+    # contiguous chunk of the dataset (/root/reference/ddpo/datasets/bucket.py:32-37) and the step key is row 0 of
+    # split(PRNGKey(seed + p), n_local_devices = 1) (/root/reference/pipeline/finetune.py:134-135).
+    args = Parser(argv).parse_args("train", process_index=worker_id)
     utils.init_logging("finetune", args.verbose)
     modelpath = None if args.iteration == 0 else args.modelpath
 
@@ -70,7 +74,7 @@ def main(argv=None):
 
     # -------------------------- generic training setup ------------------------#
     rng = prng.PRNGKey(args.seed)
-    train_rng = prng.split(rng, n_workers)[worker_id]        # jax.random.split(rng, n_local_devices): device d of the pod takes row d
+    train_rng = prng.split(rng, 1)[0]                        # jax.random.split(rng, len(jax.local_devices())): one local device per process
     num_update_steps_per_epoch = math.ceil(len(train_dataloader))
     if args.max_train_steps is None:
         args.max_train_steps = args.num_train_epochs * num_update_steps_per_epoch
@@ -101,9 +105,11 @@ def main(argv=None):
             global_step += 1
             if global_step >= args.max_train_steps:
                 break
-        loss_avg = float(torch.stack(losses).mean()) if losses else float("nan")
+        # the reference's step returns lax.pmean(loss, "batch") — the mean over ALL devices of the pod (ddpo/training/diffusion.py:97)
+        loss_avg = D.pmean_info({"loss": torch.stack(losses).mean()})["loss"] if losses else float("nan")
         history.append(loss_avg)
-        print(f"[ finetune ] Epoch {epoch} | steps {global_step} | average loss {loss_avg:.6f} | cfg: {args.train_cfg} | scale: {args.guidance_scale}")
+        if worker_id == 0:
+            print(f"[ finetune ] Epoch {epoch} | steps {global_step} | average loss {loss_avg:.6f} | cfg: {args.train_cfg} | scale: {args.guidance_scale}")
         if (epoch + 1) % args.save_freq == 0 or epoch == args.num_train_epochs - 1:
             if worker_id == 0:
                 save_checkpoint(os.path.join(savepath, "checkpoints"), unet.params, (epoch + 1) // args.save_freq * args.save_freq,

@@ -108,7 +108,7 @@ def main(argv=None):
             break
         if args.max_samples is not None and n_samples >= args.max_samples:
             break
-    writer.close(metadata={"guidance_scale": args.guidance_scale, "filter_field": args.filter_field, "n_samples": int(n_samples),
+    writer.close(world=n_workers, metadata={"guidance_scale": args.guidance_scale, "filter_field": args.filter_field, "n_samples": int(n_samples),
                            "synthetic_weights": bool(pipeline.synthetic_weights)})
     return savepath
 

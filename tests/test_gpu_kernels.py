@@ -202,6 +202,30 @@ def test_layernorm(rows, C):
     assert _rel(y.cpu().numpy(), ref.numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("rows,C", [(4096, 320), (16384 + 3, 640), (5000, 64), (4097, 512)])
+def test_layernorm_batched_rows_kernel_is_bit_identical_per_row(rows, C, monkeypatch):
+    """Round 4: rows >= 4096 of C <= 512 channels run layernorm_rows_kernel (four rows requested per wave before the first is reduced); a row's
+    arithmetic is the one-row-per-wave kernel's — the training forward of a sub-batch must see the sampler's bits — for the fp32 result and for
+    both plane formats."""
+    g = torch.Generator().manual_seed(rows + C)
+    x = (torch.randn(rows, C, generator=g) * 3 + 1).to(DEV)
+    gamma, beta = torch.randn(C, generator=g).to(DEV), torch.randn(C, generator=g).to(DEV)
+    y = L.layernorm(x, gamma, beta, 1e-5)
+    ref = torch.nn.functional.layer_norm(x.cpu().double(), (C,), gamma.cpu().double(), beta.cpu().double(), 1e-5)
+    assert _rel(y.cpu().numpy(), ref.numpy()) < 1e-5
+    sub = [slice(0, 100), slice(rows - 1001, rows)]              # < 4096 rows: the one-row-per-wave kernel
+    for sl in sub:
+        assert torch.equal(L.layernorm(x[sl].contiguous(), gamma, beta, 1e-5), y[sl])
+    monkeypatch.setattr(L, "DATAPATH", "bf16x3")
+    for fmt in ((1, 2) if C % 32 == 0 else (1,)):
+        pl = L.layernorm(x, gamma, beta, 1e-5, planes=fmt)
+        for sl in sub:
+            ps = L.layernorm(x[sl].contiguous(), gamma, beta, 1e-5, planes=fmt)
+            assert torch.equal(ps.plane("hi"), pl.plane("hi")[sl]) and torch.equal(ps.plane("lo"), pl.plane("lo")[sl])
+        rf = L.split_planes(y, fmt=fmt - 1)
+        assert torch.equal(pl.plane("hi"), rf.plane("hi")) and torch.equal(pl.plane("lo"), rf.plane("lo"))
+
+
 def test_small_elementwise():
     g = torch.Generator().manual_seed(0)
     x = torch.randn(50, 2 * 128, generator=g) * 2

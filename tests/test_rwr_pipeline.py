@@ -40,6 +40,34 @@ def test_local_writer_reader_round_trip_and_masking(tmp_path):
     assert np.array_equal(rd[4]["vae"], b2["vae"][0])
 
 
+def test_rerun_into_the_same_directory_does_not_mix_stale_shards(tmp_path):
+    """a second sampling run into the same samples/<iteration> directory with fewer shards / fewer ranks must not leave the first
+    run's shards in the RWR training set.  A writer removes ITS rank's old shards; the reader reads what the manifests list, and only the
+    ranks of the run that wrote last (manifest `world`)."""
+    for rank in (0, 1):                                   # first run: two ranks, three shards each
+        w = bucket.LocalWriter(str(tmp_path), split_size=2, rank=rank)
+        w.add_batch(_rows(6, 10 + rank))
+        w.close(metadata={"guidance_scale": 5.0}, world=2)
+    assert len(bucket.LocalReader(str(tmp_path))) == 12
+    w = bucket.LocalWriter(str(tmp_path), split_size=4, rank=0)      # second run: one rank, one shard
+    b = _rows(3, 99)
+    w.add_batch(b)
+    w.close(metadata={"guidance_scale": 5.0}, world=1)
+    assert sorted(f for f in os.listdir(tmp_path) if f.startswith("0_")) == ["0_00000.npz"]          # rank 0's old shards are gone
+    rd = bucket.LocalReader(str(tmp_path))                                                            # rank 1's stale shards are ignored
+    assert len(rd) == 3 and [rd[i]["inference_prompts"] for i in range(3)] == list(b["inference_prompts"])
+    os.remove(tmp_path / "0_00000.npz")
+    with pytest.raises(FileNotFoundError):
+        bucket.LocalReader(str(tmp_path))
+    # a run whose rank-1 manifest is missing is refused rather than silently halved
+    w = bucket.LocalWriter(str(tmp_path), split_size=4, rank=0)
+    w.add_batch(b)
+    w.close(world=2)
+    os.remove(tmp_path / "manifest_1.json")
+    with pytest.raises(FileNotFoundError):
+        bucket.LocalReader(str(tmp_path))
+
+
 def test_maskers_and_dataset_weights(tmp_path):
     xs = np.random.RandomState(0).randn(40, 1)
     m = bucket.make_masker("percentile", 90)
