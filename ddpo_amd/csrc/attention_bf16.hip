@@ -26,10 +26,13 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16_a(float lo, float hi) {
   asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
   return r;
 }
-__device__ __forceinline__ uint32_t cvt_pk_f16_a(float lo, float hi) {      // round to nearest even (kernel FP mode)
-  uint32_t r;
-  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-  return r;
+// Two floats -> packed f16 pair, round to nearest even (v_cvt_pk_f16_f32).  Deliberately NOT inline assembly: the operands are the results
+// of v_exp_f32, a transcendental-unit instruction, and gfx950 needs a wait state between a TRANS result and a VALU consumer — the compiler's
+// hazard recognizer inserts it for instructions it selects itself and does not look inside an asm statement (round 4: the asm form read stale
+// registers whenever the scheduler put the last exponential of a pair directly in front of it: ~10 % errors on long key sequences, NaNs at d = 64).
+__device__ __forceinline__ uint32_t cvt_pk_f16_a(float lo, float hi) {
+  const f16x2 v = {(_Float16)lo, (_Float16)hi};
+  return __builtin_bit_cast(uint32_t, v);
 }
 // two floats -> packed bf16 hi pair and packed bf16 lo pair
 __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
