@@ -1,4 +1,6 @@
-// Flash attention forward on the 16-bit MFMA datapath.
+// Flash attention forward on the 16-bit MFMA datapath, in two arithmetic variants of the second product (template flag F16P; the first product
+// is the same in both).  F16P = false is the `bf16x3` datapath's operator (ddpo_attention_fwd_bf16x3*): P and V split into bf16 hi + lo, three
+// passes, ~1e-6 on the output.  F16P = true is the `f16mx` datapath's (ddpo_attention_fwd_f16p*, round 4): described below, ~1e-5.
 //   S^T (keys x queries) = K Q^T : bf16x3 — K and the pre-scaled Q split into bf16 hi + lo, three MFMA passes (a_lo*b_hi + a_hi*b_lo + a_hi*b_hi,
 //                                  fp32 accumulate, ~1e-5 relative: the scores are exponentiated, they keep the full split)
 //   O^T (d x queries)    = V^T P^T: since round 4 the probabilities are ONE f16 term and V is split into f16 hi + lo — two passes of
@@ -21,10 +23,10 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__device__ __forceinline__ uint32_t cvt_pk_bf16_a(float lo, float hi) {
-  uint32_t r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-  return r;
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t cvt_pk_bf16_a(float lo, float hi) {      // v_cvt_pk_bf16_f32, selected by the compiler (see cvt_pk_f16_a)
+  const bf16x2 v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(uint32_t, v);
 }
 // Two floats -> packed f16 pair, round to nearest even (v_cvt_pk_f16_f32).  Deliberately NOT inline assembly: the operands are the results
 // of v_exp_f32, a transcendental-unit instruction, and gfx950 needs a wait state between a TRANS result and a VALU consumer — the compiler's
@@ -136,7 +138,92 @@ __device__ __forceinline__ float attn_row_sum(const f32x16 (&oacc)[NDT], float l
   }
 }
 
-template <int D, int DKP, int DVP>     // head dim, padded to 16 (QK^T reduction) and to 32 (rows of O^T)
+// ---- the bf16x3 variant of the same two steps (F16P == false): probabilities split into bf16 hi + lo, the denominator summed in fp32 from
+// the unrounded values, three MFMA passes per accumulator and step in the order vl*ph, vh*pl, vh*ph
+__device__ __forceinline__ void attn_softmax_tile_x3(const f32x16 (&sacc)[2], float& m_run, float& l_run, bf16x8 (&ph)[4], bf16x8 (&pl)[4], float& alpha,
+                                                     bool& grew) {
+  float mx = sacc[0][0];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[j][r]);
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  const float m_new = fmaxf(m_run, mx);
+  alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+  grew = m_new > m_run;
+  m_run = m_new;
+  float ls = 0.f;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      uint32_t hi[4], lo[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float p0 = __builtin_amdgcn_exp2f(sacc[j][8 * half + 2 * e] - m_new);
+        const float p1 = __builtin_amdgcn_exp2f(sacc[j][8 * half + 2 * e + 1] - m_new);
+        ls += p0 + p1;
+        split2(p0, p1, hi[e], lo[e]);
+      }
+      ph[2 * j + half] = __builtin_bit_cast(bf16x8, make_uint4(hi[0], hi[1], hi[2], hi[3]));
+      pl[2 * j + half] = __builtin_bit_cast(bf16x8, make_uint4(lo[0], lo[1], lo[2], lo[3]));
+    }
+  }
+  l_run = l_run * alpha + ls;
+}
+
+template <int NDT, int LDVT, int QB = 1>
+__device__ __forceinline__ void attn_pv_tile_x3(const char* Vhi, const char* Vlo, int li, int h, const bf16x8 (*ph)[4], const bf16x8 (*pl)[4],
+                                                f32x16 (*oacc)[NDT]) {
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+#pragma unroll
+    for (int n = 0; n < NDT; ++n) {
+      const int off = ((32 * n + li) * LDVT + 16 * u + 4 * h) * 2;
+      const uint2 a0 = *reinterpret_cast<const uint2*>(Vhi + off), a1 = *reinterpret_cast<const uint2*>(Vhi + off + 16);
+      const uint2 c0 = *reinterpret_cast<const uint2*>(Vlo + off), c1 = *reinterpret_cast<const uint2*>(Vlo + off + 16);
+      const bf16x8 vh = __builtin_bit_cast(bf16x8, make_uint4(a0.x, a0.y, a1.x, a1.y));
+      const bf16x8 vl = __builtin_bit_cast(bf16x8, make_uint4(c0.x, c0.y, c1.x, c1.y));
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) {
+        oacc[qb][n] = MFMA32(vl, ph[qb][u], oacc[qb][n]);
+        oacc[qb][n] = MFMA32(vh, pl[qb][u], oacc[qb][n]);
+        oacc[qb][n] = MFMA32(vh, ph[qb][u], oacc[qb][n]);
+      }
+    }
+  }
+}
+
+// One tile's softmax + second product for either variant (all three kernels call this, so a variant's bits do not depend on the kernel)
+template <bool F16P, bool ONES, int NDT, int LDVT>
+__device__ __forceinline__ void attn_tile_tail(const f32x16 (&sacc)[2], float& m_run, float& l_run, f32x16 (&oacc)[NDT], const char* Vhi, const char* Vlo,
+                                               int li, int h) {
+  float alpha;
+  bool grew;
+  if constexpr (F16P) {
+    f16x8 ph[4];
+    attn_softmax_tile<ONES>(sacc, m_run, l_run, ph, alpha, grew);
+    if (__any(grew)) {                     // the running maximum settles after a few tiles; skip the no-op rescale (alpha == 1)
+#pragma unroll
+      for (int n = 0; n < NDT; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[n][r] *= alpha;
+    }
+    attn_pv_tile<NDT, LDVT>(Vhi, Vlo, li, h, &ph, &oacc);
+  } else {
+    bf16x8 ph[4], pl[4];
+    attn_softmax_tile_x3(sacc, m_run, l_run, ph, pl, alpha, grew);
+    if (__any(grew)) {
+#pragma unroll
+      for (int n = 0; n < NDT; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[n][r] *= alpha;
+    }
+    attn_pv_tile_x3<NDT, LDVT>(Vhi, Vlo, li, h, &ph, &pl, &oacc);
+  }
+}
+
+template <int D, int DKP, int DVP, bool F16P>     // head dim, padded to 16 (QK^T reduction) and to 32 (rows of O^T)
 __global__ void __launch_bounds__(256) attn_fwd_bf16_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
                                                             const float* __restrict__ v, int ldv, float* __restrict__ o, int ldo,
                                                             float* __restrict__ lse, int heads, int Nq, int Nk, float scale_log2e) {
@@ -145,7 +232,7 @@ __global__ void __launch_bounds__(256) attn_fwd_bf16_kernel(const float* __restr
   constexpr int LDVT = KT + 4;            // f16 per V^T row: 136 B -> 32 rows hit distinct even banks for ds_read_b64
   constexpr int NKS = DKP / 16;           // k-steps of S^T
   constexpr int NDT = DVP / 32;           // 32-row tiles of O^T
-  constexpr bool ONES = DVP > D;          // V^T row D = 1: the softmax denominator is row D of O^T
+  constexpr bool ONES = F16P && DVP > D;  // V^T row D = 1: the softmax denominator is row D of O^T
   constexpr int K_BYTES = KT * LDK * 2, VT_BYTES = DVP * LDVT * 2;
   __shared__ __attribute__((aligned(16))) char smem[2 * K_BYTES + 2 * VT_BYTES];
   char* Khi = smem; char* Klo = smem + K_BYTES;
@@ -206,8 +293,8 @@ __global__ void __launch_bounds__(256) attn_fwd_bf16_kernel(const float* __restr
       split2(kv.z, kv.w, h1, l1);
       *reinterpret_cast<uint2*>(Khi + (key * LDK + c4 * 4) * 2) = make_uint2(h0, h1);
       *reinterpret_cast<uint2*>(Klo + (key * LDK + c4 * 4) * 2) = make_uint2(l0, l1);
-      split2h(vv.x, vv.y, h0, l0);
-      split2h(vv.z, vv.w, h1, l1);
+      if (F16P) { split2h(vv.x, vv.y, h0, l0); split2h(vv.z, vv.w, h1, l1); }
+      else { split2(vv.x, vv.y, h0, l0); split2(vv.z, vv.w, h1, l1); }
       uint16_t* vh = reinterpret_cast<uint16_t*>(Vhi);
       uint16_t* vl = reinterpret_cast<uint16_t*>(Vlo);
       const int d0 = c4 * 4;
@@ -244,23 +331,13 @@ __global__ void __launch_bounds__(256) attn_fwd_bf16_kernel(const float* __restr
         for (int r = 0; r < 16; ++r)
           if (kt0 + 32 * j + (r & 3) + 8 * (r >> 2) + 4 * h >= Nk) sacc[j][r] = -INFINITY;
     }
-    f16x8 ph[4];
-    float alpha;
-    bool grew;
-    attn_softmax_tile<ONES>(sacc, m_run, l_run, ph, alpha, grew);
-    if (__any(grew)) {                     // the running maximum settles after a few tiles; skip the no-op rescale (alpha == 1)
-#pragma unroll
-      for (int n = 0; n < NDT; ++n)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[n][r] *= alpha;
-    }
-    // ---- O^T += V^T P^T ; A fragment of step u: V^T[d = 32n + li][16u + 4h + {0..3, 8..11}]
-    attn_pv_tile<NDT, LDVT>(Vhi, Vlo, li, h, &ph, &oacc);
+    // ---- online softmax + O^T += V^T P^T ; A fragment of step u: V^T[d = 32n + li][16u + 4h + {0..3, 8..11}]
+    attn_tile_tail<F16P, ONES, NDT, LDVT>(sacc, m_run, l_run, oacc, Vhi, Vlo, li, h);
   }
 
   const float l_tot = attn_row_sum<D, NDT, ONES>(oacc, l_run, li);
   const float inv = 1.0f / l_tot;
-  if (lse && h == 0 && q0 + li < Nq) lse[(int64_t)bh * Nq + q0 + li] = m_run + log2f(l_tot) - ATTN_P_SHIFT;
+  if (lse && h == 0 && q0 + li < Nq) lse[(int64_t)bh * Nq + q0 + li] = m_run + log2f(l_tot) - (F16P ? ATTN_P_SHIFT : 0.f);
   if (q0 + li < Nq) {
     float* op = o + ((int64_t)b * Nq + q0 + li) * ldo + hd * D;
 #pragma unroll
@@ -290,7 +367,7 @@ struct AttnImg {
   static constexpr int CHUNKS = BYTES / 16;
 };
 
-template <int D, int DKP, int DVP>
+template <int D, int DKP, int DVP, bool F16P>
 __global__ void __launch_bounds__(256) attn_pack_kv_kernel(const float* __restrict__ k, int ldk, const float* __restrict__ v, int ldv,
                                                            uint4* __restrict__ img, int heads, int Nk, int ntiles) {
   using I = AttnImg<D, DKP, DVP>;
@@ -302,7 +379,7 @@ __global__ void __launch_bounds__(256) attn_pack_kv_kernel(const float* __restri
   const int kt0 = tile * I::KT;
   for (int i = t; i < I::CHUNKS; i += 256) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0u, 0u, 0u, 0u);
   __syncthreads();
-  if (DVP > D && t < I::KT) reinterpret_cast<uint16_t*>(Vhi)[D * I::LDVT + t] = (uint16_t)ATTN_F16_ONE;      // the ones row (softmax denominator)
+  if (F16P && DVP > D && t < I::KT) reinterpret_cast<uint16_t*>(Vhi)[D * I::LDVT + t] = (uint16_t)ATTN_F16_ONE;      // the ones row (softmax denominator)
   const float* kb = k + (int64_t)b * Nk * ldk + hd * D;
   const float* vb = v + (int64_t)b * Nk * ldv + hd * D;
   for (int i = t; i < I::KT * (D / 4); i += 256) {
@@ -315,8 +392,8 @@ __global__ void __launch_bounds__(256) attn_pack_kv_kernel(const float* __restri
     split2(kv.z, kv.w, h1, l1);
     *reinterpret_cast<uint2*>(Khi + (key * I::LDK + c4 * 4) * 2) = make_uint2(h0, h1);
     *reinterpret_cast<uint2*>(Klo + (key * I::LDK + c4 * 4) * 2) = make_uint2(l0, l1);
-    split2h(vv.x, vv.y, h0, l0);
-    split2h(vv.z, vv.w, h1, l1);
+    if (F16P) { split2h(vv.x, vv.y, h0, l0); split2h(vv.z, vv.w, h1, l1); }
+    else { split2(vv.x, vv.y, h0, l0); split2(vv.z, vv.w, h1, l1); }
     uint16_t* vh = reinterpret_cast<uint16_t*>(Vhi);
     uint16_t* vl = reinterpret_cast<uint16_t*>(Vlo);
     const int d0 = c4 * 4;
@@ -330,14 +407,14 @@ __global__ void __launch_bounds__(256) attn_pack_kv_kernel(const float* __restri
   for (int i = t; i < I::CHUNKS; i += 256) dst[i] = reinterpret_cast<const uint4*>(smem)[i];
 }
 
-template <int D, int DKP, int DVP>
+template <int D, int DKP, int DVP, bool F16P>
 __global__ void __launch_bounds__(256, (DVP <= 32 ? 4 : (DKP <= 48 ? 3 : 2))) attn_fwd_bf16_pk_kernel(const float* __restrict__ q, int ldq, const uint4* __restrict__ img,
                                                                float* __restrict__ o, int ldo, float* __restrict__ lse, int heads,
                                                                int Nq, int Nk, int ntiles, float scale_log2e) {
   using I = AttnImg<D, DKP, DVP>;
   constexpr int KT = I::KT, LDK = I::LDK, LDVT = I::LDVT;
   constexpr int NKS = DKP / 16, NDT = DVP / 32;
-  constexpr bool ONES = DVP > D;
+  constexpr bool ONES = F16P && DVP > D;
   constexpr int NCH = (I::CHUNKS + 255) / 256;
   __shared__ __attribute__((aligned(16))) char smem[I::BYTES];
   const char* Khi = smem; const char* Klo = smem + I::K_BYTES;
@@ -424,22 +501,12 @@ __global__ void __launch_bounds__(256, (DVP <= 32 ? 4 : (DKP <= 48 ? 3 : 2))) at
         for (int r = 0; r < 16; ++r)
           if (kt0 + 32 * j + (r & 3) + 8 * (r >> 2) + 4 * h >= Nk) sacc[j][r] = -INFINITY;
     }
-    f16x8 ph[4];
-    float alpha;
-    bool grew;
-    attn_softmax_tile<ONES>(sacc, m_run, l_run, ph, alpha, grew);
-    if (__any(grew)) {                     // the running maximum settles after a few tiles; skip the no-op rescale (alpha == 1)
-#pragma unroll
-      for (int n = 0; n < NDT; ++n)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[n][r] *= alpha;
-    }
-    attn_pv_tile<NDT, LDVT>(Vhi, Vlo, li, h, &ph, &oacc);
+    attn_tile_tail<F16P, ONES, NDT, LDVT>(sacc, m_run, l_run, oacc, Vhi, Vlo, li, h);
   }
 
   const float l_tot = attn_row_sum<D, NDT, ONES>(oacc, l_run, li);
   const float inv = 1.0f / l_tot;
-  if (lse && h == 0 && q0 + li < Nq) lse[(int64_t)bh * Nq + q0 + li] = m_run + log2f(l_tot) - ATTN_P_SHIFT;
+  if (lse && h == 0 && q0 + li < Nq) lse[(int64_t)bh * Nq + q0 + li] = m_run + log2f(l_tot) - (F16P ? ATTN_P_SHIFT : 0.f);
   if (q0 + li < Nq) {
     float* op = o + ((int64_t)b * Nq + q0 + li) * ldo + hd * D;
 #pragma unroll
@@ -473,14 +540,14 @@ typedef unsigned int u32x4_a __attribute__((ext_vector_type(4)));
 // QB: 32-query blocks per wave.  QB = 2: a workgroup covers 256 queries, every V^T fragment read from LDS feeds the MFMAs of two
 // blocks and half as many workgroups stream the images; the score + softmax phases run one block after the other (their K fragments
 // are re-read: both blocks' score accumulators at once do not fit two waves per SIMD).  Per-query arithmetic and order unchanged.
-template <int D, int DKP, int DVP, int QB>
+template <int D, int DKP, int DVP, int QB, bool F16P>
 __global__ void __launch_bounds__(256, (QB == 2 ? 2 : (DVP <= 32 ? 4 : (DKP <= 48 ? 3 : 2)))) attn_fwd_bf16_dma_kernel(const float* __restrict__ q, int ldq, const uint4* __restrict__ img,
                                                                float* __restrict__ o, int ldo, float* __restrict__ lse, int heads,
                                                                int Nq, int Nk, int ntiles, float scale_log2e) {
   using I = AttnImg<D, DKP, DVP>;
   constexpr int KT = I::KT, LDK = I::LDK, LDVT = I::LDVT;
   constexpr int NKS = DKP / 16, NDT = DVP / 32;
-  constexpr bool ONES = DVP > D;
+  constexpr bool ONES = F16P && DVP > D;
   constexpr int KP = 2 * I::K_BYTES, VP = 2 * I::VT_BYTES;          // K part (hi | lo) and V^T part (hi | lo) of an image
   static_assert(KP % 1024 == 0 && VP % 1024 == 0, "LDS-DMA moves whole KiB pieces");
   constexpr int NPK = KP / 1024, NPV = VP / 1024;
@@ -547,7 +614,8 @@ __global__ void __launch_bounds__(256, (QB == 2 ? 2 : (DVP <= 32 ? 4 : (DKP <= 4
     fill(2 * KP, KP, NPV, tile);                                   // V(tile) -> V region (nobody reads V(tile - 1) any more)
     if (tile + 1 < ntiles) fill((tile & 1) ? 0 : KP, 0, NPK, tile + 1);   // K(tile + 1) -> the other K region
 
-    f16x8 ph[QB][4];
+    f16x8 ph[QB][4];                       // F16P: the tile's probabilities, one f16 term
+    bf16x8 xh[QB][4], xl[QB][4];           // bf16x3: bf16 hi / lo
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
       f32x16 sacc[2];
@@ -576,7 +644,8 @@ __global__ void __launch_bounds__(256, (QB == 2 ? 2 : (DVP <= 32 ? 4 : (DKP <= 4
       }
       float alpha;
       bool grew;
-      attn_softmax_tile<ONES>(sacc, m_run[qb], l_run[qb], ph[qb], alpha, grew);
+      if constexpr (F16P) attn_softmax_tile<ONES>(sacc, m_run[qb], l_run[qb], ph[qb], alpha, grew);
+      else attn_softmax_tile_x3(sacc, m_run[qb], l_run[qb], xh[qb], xl[qb], alpha, grew);
       if (__any(grew)) {
   #pragma unroll
         for (int n = 0; n < NDT; ++n)
@@ -587,7 +656,8 @@ __global__ void __launch_bounds__(256, (QB == 2 ? 2 : (DVP <= 32 ? 4 : (DKP <= 4
     // V(tile) (and K(tile + 1)) have landed; my K fragment reads have returned
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    attn_pv_tile<NDT, LDVT, QB>(Vhi, Vlo, li, h, ph, oacc);      // one V^T fragment feeds QB query blocks
+    if constexpr (F16P) attn_pv_tile<NDT, LDVT, QB>(Vhi, Vlo, li, h, ph, oacc);      // one V^T fragment feeds QB query blocks
+    else attn_pv_tile_x3<NDT, LDVT, QB>(Vhi, Vlo, li, h, xh, xl, oacc);
   }
 
 #pragma unroll
@@ -595,7 +665,7 @@ __global__ void __launch_bounds__(256, (QB == 2 ? 2 : (DVP <= 32 ? 4 : (DKP <= 4
     const int qi = q0 + 32 * qb + li;
     const float l_tot = attn_row_sum<D, NDT, ONES>(oacc[qb], l_run[qb], li);
     const float inv = 1.0f / l_tot;
-    if (lse && h == 0 && qi < Nq) lse[(int64_t)bh * Nq + qi] = m_run[qb] + log2f(l_tot) - ATTN_P_SHIFT;
+    if (lse && h == 0 && qi < Nq) lse[(int64_t)bh * Nq + qi] = m_run[qb] + log2f(l_tot) - (F16P ? ATTN_P_SHIFT : 0.f);
     if (qi < Nq) {
       float* op = o + ((int64_t)b * Nq + qi) * ldo + hd * D;
 #pragma unroll
@@ -613,40 +683,40 @@ __global__ void __launch_bounds__(256, (QB == 2 ? 2 : (DVP <= 32 ? 4 : (DKP <= 4
 
 #define ATTN_PK_MIN_NK 256      /* shorter key sequences (cross-attention over 77 tokens) stay on the self-staging kernel */
 
-template <int D, int DKP, int DVP>
+template <int D, int DKP, int DVP, bool F16P>
 static int launch_pack_kv(const float* k, int ldk, const float* v, int ldv, uint4* img, int B, int heads, int Nk, hipStream_t st) {
   using I = AttnImg<D, DKP, DVP>;
   const int ntiles = (Nk + I::KT - 1) / I::KT;
-  hipLaunchKernelGGL((attn_pack_kv_kernel<D, DKP, DVP>), dim3(ntiles, B * heads), dim3(256), 0, st, k, ldk, v, ldv, img, heads, Nk, ntiles);
+  hipLaunchKernelGGL((attn_pack_kv_kernel<D, DKP, DVP, F16P>), dim3(ntiles, B * heads), dim3(256), 0, st, k, ldk, v, ldv, img, heads, Nk, ntiles);
   DDPO_LAUNCH_CHECK();
   return DDPO_OK;
 }
 
 // attention from pre-packed K / V^T images (one image per 64-key tile and (batch, head))
-template <int D, int DKP, int DVP>
+template <int D, int DKP, int DVP, bool F16P>
 static int launch_attn_images(const float* q, int ldq, const uint4* img, float* o, int ldo, float* lse, int B, int heads, int Nq, int Nk,
                               float scale, hipStream_t st) {
   using I = AttnImg<D, DKP, DVP>;
   dim3 grid((Nq + 127) / 128, B * heads);
   const int ntiles = (Nk + I::KT - 1) / I::KT;
   // LDS-DMA image streaming wherever the image's K and V^T parts are whole KiB (d = 40, 64): 1.50 -> 1.42 ms on 4096^2, d = 40, batch 16
-  // (profiles/r02_probe_attn_dma.log); the register-staged kernel below takes the other head sizes (d = 80) and >= 2 GiB image sets.
-  // (Two query blocks per wave on top measured 1.40 ms at 256 VGPRs with spills — not kept.)
+  // (profiles/r02_probe_attn_dma.log; 1.29 ms with the f16p second product, profiles/r04_probe_attn.log); the register-staged kernel below
+  // takes the other head sizes (d = 80) and >= 2 GiB image sets.  (Two query blocks per wave on top measured 1.40 ms at 256 VGPRs with spills — not kept.)
   if constexpr ((2 * I::K_BYTES) % 1024 == 0 && (2 * I::VT_BYTES) % 1024 == 0) {
     if ((int64_t)ntiles * I::BYTES < 0x7FFFFFFF) {
-      hipLaunchKernelGGL((attn_fwd_bf16_dma_kernel<D, DKP, DVP, 1>), grid, dim3(256), 0, st, q, ldq, img, o, ldo, lse, heads, Nq, Nk, ntiles,
+      hipLaunchKernelGGL((attn_fwd_bf16_dma_kernel<D, DKP, DVP, 1, F16P>), grid, dim3(256), 0, st, q, ldq, img, o, ldo, lse, heads, Nq, Nk, ntiles,
                          scale * 1.4426950408889634f);
       DDPO_LAUNCH_CHECK();
       return DDPO_OK;
     }
   }
-  hipLaunchKernelGGL((attn_fwd_bf16_pk_kernel<D, DKP, DVP>), grid, dim3(256), 0, st, q, ldq, img, o, ldo, lse, heads, Nq, Nk, ntiles,
+  hipLaunchKernelGGL((attn_fwd_bf16_pk_kernel<D, DKP, DVP, F16P>), grid, dim3(256), 0, st, q, ldq, img, o, ldo, lse, heads, Nq, Nk, ntiles,
                      scale * 1.4426950408889634f);
   DDPO_LAUNCH_CHECK();
   return DDPO_OK;
 }
 
-template <int D, int DKP, int DVP>
+template <int D, int DKP, int DVP, bool F16P>
 static int launch_attn_bf16(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo, float* lse,
                             int B, int heads, int Nq, int Nk, float scale, void* ws, size_t ws_bytes, hipStream_t st) {
   using I = AttnImg<D, DKP, DVP>;
@@ -655,11 +725,11 @@ static int launch_attn_bf16(const float* q, int ldq, const float* k, int ldk, co
   const size_t need = (size_t)B * heads * ntiles * I::BYTES;
   if (Nk >= ATTN_PK_MIN_NK && ws && ws_bytes >= need && !(reinterpret_cast<uintptr_t>(ws) & 15)) {
     uint4* img = reinterpret_cast<uint4*>(ws);
-    const int rc = launch_pack_kv<D, DKP, DVP>(k, ldk, v, ldv, img, B, heads, Nk, st);
+    const int rc = launch_pack_kv<D, DKP, DVP, F16P>(k, ldk, v, ldv, img, B, heads, Nk, st);
     if (rc != DDPO_OK) return rc;
-    return launch_attn_images<D, DKP, DVP>(q, ldq, img, o, ldo, lse, B, heads, Nq, Nk, scale, st);
+    return launch_attn_images<D, DKP, DVP, F16P>(q, ldq, img, o, ldo, lse, B, heads, Nq, Nk, scale, st);
   }
-  hipLaunchKernelGGL((attn_fwd_bf16_kernel<D, DKP, DVP>), grid, dim3(256), 0, st, q, ldq, k, ldk, v, ldv, o, ldo, lse, heads, Nq, Nk,
+  hipLaunchKernelGGL((attn_fwd_bf16_kernel<D, DKP, DVP, F16P>), grid, dim3(256), 0, st, q, ldq, k, ldk, v, ldv, o, ldo, lse, heads, Nq, Nk,
                      scale * 1.4426950408889634f);
   DDPO_LAUNCH_CHECK();
   return DDPO_OK;
@@ -688,28 +758,43 @@ extern "C" size_t ddpo_attention_fwd_bf16x3_ws_bytes(int B, int heads, int Nk, i
   }
 }
 
-extern "C" int ddpo_attention_fwd_bf16x3(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
-                                         float* lse, int B, int heads, int Nq, int Nk, int d, float scale, void* ws, size_t ws_bytes,
-                                         void* stream) {
+#define ATTN_BY_D(CALL)                                      \
+  switch (d) {                                               \
+    case 8:  return CALL(8, 16, 32);                         \
+    case 16: return CALL(16, 16, 32);                        \
+    case 40: return CALL(40, 48, 64);                        \
+    case 64: return CALL(64, 64, 64);                        \
+    case 80: return CALL(80, 80, 96);                        \
+    default: return DDPO_EINVAL; /* other head dims stay on the exact-fp32 kernel */ \
+  }
+
+template <bool F16P>
+static int attention_fwd_impl(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
+                              float* lse, int B, int heads, int Nq, int Nk, int d, float scale, void* ws, size_t ws_bytes, void* stream) {
   if (!q || !k || !v || !o || B <= 0 || heads <= 0 || Nq <= 0 || Nk <= 0) return DDPO_EINVAL;
   if ((ldq & 3) || (ldk & 3) || (ldv & 3) || (ldo & 3) || (long)B * heads > 65535) return DDPO_EINVAL;
   if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v) |
        reinterpret_cast<uintptr_t>(o)) & 15) return DDPO_EINVAL;
   hipStream_t st = as_stream(stream);
-  switch (d) {
-    case 8:  return launch_attn_bf16<8, 16, 32>(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, heads, Nq, Nk, scale, ws, ws_bytes, st);
-    case 16: return launch_attn_bf16<16, 16, 32>(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, heads, Nq, Nk, scale, ws, ws_bytes, st);
-    case 40: return launch_attn_bf16<40, 48, 64>(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, heads, Nq, Nk, scale, ws, ws_bytes, st);
-    case 64: return launch_attn_bf16<64, 64, 64>(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, heads, Nq, Nk, scale, ws, ws_bytes, st);
-    case 80: return launch_attn_bf16<80, 80, 96>(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, heads, Nq, Nk, scale, ws, ws_bytes, st);
-    default: return DDPO_EINVAL;      // other head dims stay on the exact-fp32 kernel
-  }
+#define CALL(DD, DK, DV) launch_attn_bf16<DD, DK, DV, F16P>(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, heads, Nq, Nk, scale, ws, ws_bytes, st)
+  ATTN_BY_D(CALL)
+#undef CALL
+}
+extern "C" int ddpo_attention_fwd_bf16x3(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
+                                         float* lse, int B, int heads, int Nq, int Nk, int d, float scale, void* ws, size_t ws_bytes,
+                                         void* stream) {
+  return attention_fwd_impl<false>(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, heads, Nq, Nk, d, scale, ws, ws_bytes, stream);
+}
+extern "C" int ddpo_attention_fwd_f16p(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
+                                       float* lse, int B, int heads, int Nq, int Nk, int d, float scale, void* ws, size_t ws_bytes,
+                                       void* stream) {
+  return attention_fwd_impl<true>(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, heads, Nq, Nk, d, scale, ws, ws_bytes, stream);
 }
 
 /* K / V of a (batch, head) set packed ONCE into the per-64-key-tile LDS images the attention kernels stream (any Nk), for callers whose
  * keys / values are constant over many attention calls — the text context of the cross-attention layers over the 50 DDIM steps of a
- * sampling call.  ddpo_attention_kv_images_bytes gives the image size; ddpo_attention_fwd_bf16x3_images runs the attention from them
- * (same kernels as ddpo_attention_fwd_bf16x3 with a workspace: identical results). */
+ * sampling call.  ddpo_attention_kv_images_bytes gives the image size (the same for both variants); ddpo_attention_fwd_{bf16x3,f16p}_images runs
+ * the attention from the images of ITS variant's pack function (same kernels as the workspace form: identical results). */
 extern "C" size_t ddpo_attention_kv_images_bytes(int B, int heads, int Nk, int d) {
   if (B <= 0 || heads <= 0 || Nk <= 0) return 0;
   switch (d) {
@@ -722,26 +807,31 @@ extern "C" size_t ddpo_attention_kv_images_bytes(int B, int heads, int Nk, int d
   }
 }
 
-extern "C" int ddpo_attention_pack_kv_bf16x3(const float* k, int ldk, const float* v, int ldv, void* images, size_t images_bytes, int B, int heads,
-                                             int Nk, int d, void* stream) {
+template <bool F16P>
+static int pack_kv_impl(const float* k, int ldk, const float* v, int ldv, void* images, size_t images_bytes, int B, int heads, int Nk, int d,
+                        void* stream) {
   if (!k || !v || !images || B <= 0 || heads <= 0 || Nk <= 0 || (ldk & 3) || (ldv & 3) || (long)B * heads > 65535) return DDPO_EINVAL;
   if ((reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(images)) & 15) return DDPO_EINVAL;
   const size_t need = ddpo_attention_kv_images_bytes(B, heads, Nk, d);
   if (need == 0 || images_bytes < need) return DDPO_EINVAL;
   hipStream_t st = as_stream(stream);
   uint4* img = reinterpret_cast<uint4*>(images);
-  switch (d) {
-    case 8:  return launch_pack_kv<8, 16, 32>(k, ldk, v, ldv, img, B, heads, Nk, st);
-    case 16: return launch_pack_kv<16, 16, 32>(k, ldk, v, ldv, img, B, heads, Nk, st);
-    case 40: return launch_pack_kv<40, 48, 64>(k, ldk, v, ldv, img, B, heads, Nk, st);
-    case 64: return launch_pack_kv<64, 64, 64>(k, ldk, v, ldv, img, B, heads, Nk, st);
-    case 80: return launch_pack_kv<80, 80, 96>(k, ldk, v, ldv, img, B, heads, Nk, st);
-    default: return DDPO_EINVAL;
-  }
+#define CALL(DD, DK, DV) launch_pack_kv<DD, DK, DV, F16P>(k, ldk, v, ldv, img, B, heads, Nk, st)
+  ATTN_BY_D(CALL)
+#undef CALL
+}
+extern "C" int ddpo_attention_pack_kv_bf16x3(const float* k, int ldk, const float* v, int ldv, void* images, size_t images_bytes, int B, int heads,
+                                             int Nk, int d, void* stream) {
+  return pack_kv_impl<false>(k, ldk, v, ldv, images, images_bytes, B, heads, Nk, d, stream);
+}
+extern "C" int ddpo_attention_pack_kv_f16p(const float* k, int ldk, const float* v, int ldv, void* images, size_t images_bytes, int B, int heads,
+                                           int Nk, int d, void* stream) {
+  return pack_kv_impl<true>(k, ldk, v, ldv, images, images_bytes, B, heads, Nk, d, stream);
 }
 
-extern "C" int ddpo_attention_fwd_bf16x3_images(const float* q, int ldq, const void* images, size_t images_bytes, float* o, int ldo, float* lse,
-                                                int B, int heads, int Nq, int Nk, int d, float scale, void* stream) {
+template <bool F16P>
+static int attention_images_impl(const float* q, int ldq, const void* images, size_t images_bytes, float* o, int ldo, float* lse,
+                                 int B, int heads, int Nq, int Nk, int d, float scale, void* stream) {
   if (!q || !images || !o || B <= 0 || heads <= 0 || Nq <= 0 || Nk <= 0) return DDPO_EINVAL;
   if ((ldq & 3) || (ldo & 3) || (long)B * heads > 65535) return DDPO_EINVAL;
   if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(images) | reinterpret_cast<uintptr_t>(o)) & 15) return DDPO_EINVAL;
@@ -749,12 +839,15 @@ extern "C" int ddpo_attention_fwd_bf16x3_images(const float* q, int ldq, const v
   if (need == 0 || images_bytes < need) return DDPO_EINVAL;
   hipStream_t st = as_stream(stream);
   const uint4* img = reinterpret_cast<const uint4*>(images);
-  switch (d) {
-    case 8:  return launch_attn_images<8, 16, 32>(q, ldq, img, o, ldo, lse, B, heads, Nq, Nk, scale, st);
-    case 16: return launch_attn_images<16, 16, 32>(q, ldq, img, o, ldo, lse, B, heads, Nq, Nk, scale, st);
-    case 40: return launch_attn_images<40, 48, 64>(q, ldq, img, o, ldo, lse, B, heads, Nq, Nk, scale, st);
-    case 64: return launch_attn_images<64, 64, 64>(q, ldq, img, o, ldo, lse, B, heads, Nq, Nk, scale, st);
-    case 80: return launch_attn_images<80, 80, 96>(q, ldq, img, o, ldo, lse, B, heads, Nq, Nk, scale, st);
-    default: return DDPO_EINVAL;
-  }
+#define CALL(DD, DK, DV) launch_attn_images<DD, DK, DV, F16P>(q, ldq, img, o, ldo, lse, B, heads, Nq, Nk, scale, st)
+  ATTN_BY_D(CALL)
+#undef CALL
+}
+extern "C" int ddpo_attention_fwd_bf16x3_images(const float* q, int ldq, const void* images, size_t images_bytes, float* o, int ldo, float* lse,
+                                                int B, int heads, int Nq, int Nk, int d, float scale, void* stream) {
+  return attention_images_impl<false>(q, ldq, images, images_bytes, o, ldo, lse, B, heads, Nq, Nk, d, scale, stream);
+}
+extern "C" int ddpo_attention_fwd_f16p_images(const float* q, int ldq, const void* images, size_t images_bytes, float* o, int ldo, float* lse,
+                                              int B, int heads, int Nq, int Nk, int d, float scale, void* stream) {
+  return attention_images_impl<true>(q, ldq, images, images_bytes, o, ldo, lse, B, heads, Nq, Nk, d, scale, stream);
 }

@@ -39,7 +39,7 @@ class GemmDesc(ctypes.Structure):
                 ("w_scale", c_void_p), ("planes_fmt", c_int), ("colsum", c_void_p), ("aux_out", c_void_p)]
 
 
-ABI_VERSION = 10         # must equal ddpo_abi_version() of the loaded library (include/ddpo_hip.h)
+ABI_VERSION = 11         # must equal ddpo_abi_version() of the loaded library (include/ddpo_hip.h)
 
 _SIGS = {
     "ddpo_abi_version": (c_int, []),
@@ -92,6 +92,13 @@ _SIGS = {
     "ddpo_attention_fwd_bf16x3": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int,
                                           c_int, c_int, c_int, c_float, c_void_p, c_size_t, c_void_p]),
     "ddpo_attention_fwd_bf16x3_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "ddpo_attention_fwd_f16p": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int,
+                                        c_int, c_int, c_int, c_float, c_void_p, c_size_t, c_void_p]),
+    "ddpo_attention_pack_kv_f16p": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_void_p]),
+    "ddpo_attention_fwd_f16p_images": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                               c_float, c_void_p]),
+    "ddpo_attention_bwd_f16p": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "ddpo_attention_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "ddpo_attention_bwd_bf16x3": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -241,9 +248,9 @@ W_KBLOCKED = os.environ.get("DDPO_W_KBLOCKED", "1") == "1"
 A_KBLOCKED = os.environ.get("DDPO_A_KBLOCKED", "0") == "1"
 # Data gradients as FORWARD contractions (round 4).  dX of y = conv(x, W) is conv(dY, W') with W'[ky, kx, co, ci] = W[k-1-ky, k-1-kx, ci, co]
 # (stride 2: over the zero-inserted dY), dX of y = x W is dY W^T: pack_weights(bwd=True) registers W' / W^T as one more set of FORWARD weight
-# planes (k-blocked; f16mx planes too where the reduction 9 * Cout / N is >= MX_MIN_K), and conv2d_dgrad / linear_dgrad run the plane-fed /
-# f16mx / tall-tile forward kernels on them with dY split into planes on the way in — instead of the fp32-fed kernel's `w_dgrad` addressing of
-# row-major (K, N) planes, which had none of: LDS-DMA operands, k-blocked weight stream, 256x320 tiles, the f16mx operator.
+# planes (k-blocked bf16 hi / lo), and conv2d_dgrad / linear_dgrad run the plane-fed / tall-tile bf16x3 forward kernels on them with dY split
+# into planes on the way in — instead of the fp32-fed kernel's `w_dgrad` addressing of row-major (K, N) planes, which had none of: LDS-DMA
+# operands, k-blocked weight stream, 256x320 tiles.  (f16mx is NOT used for gradients: _pack_dgrad_planes.)
 # DDPO_DGRAD_FWD=0 restores the round-3 path (bit-different, same bf16x3 arithmetic class).
 DGRAD_FWD = os.environ.get("DDPO_DGRAD_FWD", "1") == "1"
 
@@ -714,21 +721,17 @@ def _pack_dgrad_planes(w, ent):
         mk = lambda *sh: torch.zeros(*sh, dtype=torch.int16, device=w.device)
         dg = ent["dg"] = dict(K=Kd, N=Nd, hi=mk(Nd, Kp), lo=mk(Nd, Kp))
     _check(load().ddpo_pack_weights_bf16_kblocked(_p(wt), Kd, Nd, _p(dg["hi"]), _p(dg["lo"]), _stream()), "ddpo_pack_weights_bf16_kblocked")
-    if _mx() and Kd % 32 == 0 and Kd >= MX_MIN_K:
-        if "mx" not in dg:
-            dg["mx"] = dict(w16=torch.zeros(Kd // 32, Nd, 32, dtype=torch.int16, device=w.device), w8=torch.zeros(Kd // 32, Nd, 64, dtype=torch.uint8, device=w.device),
-                            scale=torch.zeros(Nd, dtype=torch.uint8, device=w.device))
-        m = dg["mx"]
-        _check(load().ddpo_pack_weights_f16mx(_p(wt), Kd, Nd, _p(m["w16"]), _p(m["w8"]), _p(m["scale"]), _stream()), "ddpo_pack_weights_f16mx")
-    else:
-        dg.pop("mx", None)
+    # NO f16mx planes for data gradients, on any datapath: the f16mx ACTIVATION planes carry no scale (f16 + e5m2 at the value's own exponent),
+    # which is right for O(1) activations and wrong for dY — PPO / RWR gradients sit at 1e-7 .. 1e-3, i.e. in f16's subnormal range: measured
+    # on hardware (round 4, full-size SD-1.5 / SD-2.1 train step) ||g - g_ref|| / ||g_ref|| went from 7e-5 to 1e-2 .. 4e-2 with f16mx data
+    # gradients.  The data gradients therefore run bf16x3 (bf16 has fp32's range) on the plane-fed forward kernels.
     return dg
 
 
 def _dgrad_fwd(dy, dg, *, M, conv=None, residual=None, ld_res=None, out=None):
     """dX = the forward contraction of dY with the registered data-gradient planes `dg` (see DGRAD_FWD).  dy: fp32 (rows, K' per tap) or Planes.
-    Long reductions (K' >= 2560: every 3x3 convolution, FF1) run plane-fed — dY split on the way in, f16mx where f16mx planes are registered;
-    short ones stay fp32-fed (the plane-fed loop's fill latency, planes_pay) on the k-blocked weight stream."""
+    Long reductions (K' >= 2560: every 3x3 convolution, FF1) run plane-fed — dY split into bf16 hi / lo planes on the way in (bf16x3 on every
+    datapath: gradients need fp32's exponent range) —; short ones stay fp32-fed (the plane-fed loop's fill latency, planes_pay) on the k-blocked weight stream."""
     Kd, Nd = dg["K"], dg["N"]
     cin = conv["Cin"] if conv else Kd
     rows = conv["B"] * conv["H"] * conv["W"] if conv else M
@@ -742,15 +745,12 @@ def _dgrad_fwd(dy, dg, *, M, conv=None, residual=None, ld_res=None, out=None):
             r1 = min(rows, r0 + step)
             _dgrad_fwd(dy[r0:r1], dg, M=r1 - r0, residual=None if residual is None else residual[r0:r1], ld_res=ld_res, out=out[r0:r1])
         return out
-    mxl = _mx() and "mx" in dg
     buf_ok = cin % 32 == 0 and rows * cin * 4 < lim and Nd * ((Kd + 31) // 32 * 32) * 2 < lim
     pl = dy if isinstance(dy, Planes) else None
-    if pl is not None and ((pl.fmt == 1) != bool(mxl) or not buf_ok):
+    if pl is not None and (pl.fmt != 0 or not buf_ok):
         dy, pl = pl.float(), None
-    if pl is None and buf_ok and PLANES and (mxl or Kd >= 2560 or PLANES_ALL):
-        pl = split_planes(dy, fmt=1 if mxl else 0)
-    if pl is None and mxl:
-        mxl = False                          # not plane-eligible (>= 2 GiB): bf16x3, like the forward of such a layer
+    if pl is None and buf_ok and PLANES and (Kd >= 2560 or PLANES_ALL):
+        pl = split_planes(dy)                # bf16 hi / lo planes, whatever the datapath (see _pack_dgrad_planes)
     d = GemmDesc()
     dev = pl.device if pl is not None else dy.device
     if out is None:
@@ -765,12 +765,7 @@ def _dgrad_fwd(dy, dg, *, M, conv=None, residual=None, ld_res=None, out=None):
         for k in ("ksize", "stride", "pad", "upsample", "B", "H", "W", "Cin", "OH", "OW"):
             setattr(d, k, int(conv[k]))
     ws = _scratch(SPLITK_WS_BYTES, dev, "splitk")
-    if pl is not None and mxl:
-        m = dg["mx"]
-        d.w_scale = m["scale"].data_ptr()
-        _check(load().ddpo_gemm_conv_fwd_f16mx_planes(byref(d), _p(pl.hi), _p(pl.lo), pl.ld, _p(m["w16"]), _p(m["w8"]), _p(ws), SPLITK_WS_BYTES, _stream()),
-               "ddpo_gemm_conv_fwd_f16mx_planes(dgrad)")
-    elif pl is not None:
+    if pl is not None:
         _check(load().ddpo_gemm_conv_fwd_bf16_planes(byref(d), _p(pl.hi), _p(pl.lo), pl.ld, _p(dg["hi"]), _p(dg["lo"]), 0, _p(ws), SPLITK_WS_BYTES, _stream()),
                "ddpo_gemm_conv_fwd_bf16_planes(dgrad)")
     else:
@@ -1017,8 +1012,10 @@ def attention(q, k, v, B, heads, Nq, Nk, d, scale=None, out=None, ldq=None, ldk=
     if current_datapath() != "fp32" and d in (8, 16, 40, 64, 80):
         nb = int(load().ddpo_attention_fwd_bf16x3_ws_bytes(B, heads, Nk, d))      # 0 for short key sequences
         ws = _scratch(nb, q.device, "attn_kv") if nb else None
-        _check(load().ddpo_attention_fwd_bf16x3(_p(q), int(ldq or C), _p(k), int(ldk or C), _p(v), int(ldv or C), _p(out), int(ldo or C),
-                                                _p(lse), B, heads, Nq, Nk, d, sc, _p(ws), nb, _stream()), "ddpo_attention_fwd_bf16x3")
+        # the f16mx datapath's attention is the f16p operator (probabilities as one f16 term, two second-product passes); bf16x3 keeps three
+        fn, name = (load().ddpo_attention_fwd_f16p, "ddpo_attention_fwd_f16p") if _mx() else (load().ddpo_attention_fwd_bf16x3, "ddpo_attention_fwd_bf16x3")
+        _check(fn(_p(q), int(ldq or C), _p(k), int(ldk or C), _p(v), int(ldv or C), _p(out), int(ldo or C),
+                  _p(lse), B, heads, Nq, Nk, d, sc, _p(ws), nb, _stream()), name)
     else:
         _check(load().ddpo_attention_fwd(_p(q), int(ldq or C), _p(k), int(ldk or C), _p(v), int(ldv or C), _p(out), int(ldo or C),
                                          _p(lse), B, heads, Nq, Nk, d, sc, _stream()), "ddpo_attention_fwd")
@@ -1035,20 +1032,22 @@ def attention_kv_images(k, v, B, heads, Nk, d, out=None, ldk=None, ldv=None):
     nb = int(load().ddpo_attention_kv_images_bytes(B, heads, Nk, d))
     if out is None or out.numel() < nb:
         out = torch.empty(nb, dtype=torch.uint8, device=k.device)
-    _check(load().ddpo_attention_pack_kv_bf16x3(_p(k), int(ldk or C), _p(v), int(ldv or C), _p(out), out.numel(), B, heads, Nk, d, _stream()),
-           "ddpo_attention_pack_kv_bf16x3")
+    fn, name = (load().ddpo_attention_pack_kv_f16p, "ddpo_attention_pack_kv_f16p") if _mx() else (load().ddpo_attention_pack_kv_bf16x3, "ddpo_attention_pack_kv_bf16x3")
+    _check(fn(_p(k), int(ldk or C), _p(v), int(ldv or C), _p(out), out.numel(), B, heads, Nk, d, _stream()), name)
     return out
 
 
 def attention_from_images(q, images, B, heads, Nq, Nk, d, scale=None, out=None, ldq=None, ldo=None, return_lse=False):
-    """softmax(q k^T * scale) v with k, v given as attention_kv_images()."""
+    """softmax(q k^T * scale) v with k, v given as attention_kv_images() — packed under the SAME datapath (the f16mx datapath's images hold V as
+    f16 hi / lo with a row of ones, the bf16x3 datapath's as bf16 hi / lo)."""
     C = heads * d
     if out is None:
         out = torch.empty(B * Nq, C, dtype=torch.float32, device=q.device)
     lse = torch.empty(B * heads * Nq, dtype=torch.float32, device=q.device) if return_lse else None
     sc = float(scale if scale is not None else d ** -0.5)
-    _check(load().ddpo_attention_fwd_bf16x3_images(_p(q), int(ldq or C), _p(images), images.numel(), _p(out), int(ldo or C), _p(lse), B, heads,
-                                                   Nq, Nk, d, sc, _stream()), "ddpo_attention_fwd_bf16x3_images")
+    fn, name = (load().ddpo_attention_fwd_f16p_images, "ddpo_attention_fwd_f16p_images") if _mx() else \
+        (load().ddpo_attention_fwd_bf16x3_images, "ddpo_attention_fwd_bf16x3_images")
+    _check(fn(_p(q), int(ldq or C), _p(images), images.numel(), _p(out), int(ldo or C), _p(lse), B, heads, Nq, Nk, d, sc, _stream()), name)
     return (out, lse) if return_lse else out
 
 
@@ -1058,10 +1057,10 @@ def attention_bwd(q, k, v, o, d_o, lse, B, heads, Nq, Nk, d, scale=None):
     dq = torch.empty(B * Nq, C, dtype=torch.float32, device=q.device)
     dk = torch.empty(B * Nk, C, dtype=torch.float32, device=q.device)
     dv = torch.empty(B * Nk, C, dtype=torch.float32, device=q.device)
-    dvec = torch.empty(B * heads * Nq, dtype=torch.float32, device=q.device)
+    dvec = torch.empty(B * heads * (Nq + 1), dtype=torch.float32, device=q.device)        # rowsum(dO * O) + one max-|dO| word per (batch, head) slab
     fn, name = load().ddpo_attention_bwd, "ddpo_attention_bwd"
     if current_datapath() != "fp32" and d in (8, 16, 40, 64, 80):
-        fn, name = load().ddpo_attention_bwd_bf16x3, "ddpo_attention_bwd_bf16x3"
+        fn, name = (load().ddpo_attention_bwd_f16p, "ddpo_attention_bwd_f16p") if _mx() else (load().ddpo_attention_bwd_bf16x3, "ddpo_attention_bwd_bf16x3")
     _check(fn(_p(q), C, _p(k), C, _p(v), C, _p(o), _p(d_o), _p(lse), _p(dvec), _p(dq), _p(dk), _p(dv),
               B, heads, Nq, Nk, d, float(scale if scale is not None else d ** -0.5), _stream()), name)
     return dq, dk, dv

@@ -310,10 +310,33 @@ int ddpo_attention_bwd(const float* q, int ldq, const float* k, int ldk, const f
                        const float* d_o, const float* lse, float* dvec, float* dq, float* dk, float* dv,
                        int B, int heads, int Nq, int Nk, int d, float scale, void* stream);
 
-/* Attention backward on the bf16x3 datapath (same arguments; d in {8, 16, 40, 64, 80}). */
+/* Attention backward on the bf16x3 datapath (same arguments; d in {8, 16, 40, 64, 80}): every product on three bf16 passes. */
 int ddpo_attention_bwd_bf16x3(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o,
                               const float* d_o, const float* lse, float* dvec, float* dq, float* dk, float* dv,
                               int B, int heads, int Nq, int Nk, int d, float scale, void* stream);
+
+/* ---- `f16p` attention operators (ABI v11): the attention of the f16mx datapath.  Same arguments and layouts as the bf16x3 functions of the
+ * same name; the images of ddpo_attention_pack_kv_f16p are only valid for ddpo_attention_fwd_f16p_images (same byte size,
+ * ddpo_attention_kv_images_bytes).  Arithmetic: the scores stay bf16 hi + lo on three MFMA passes; in the second product the probabilities are
+ * ONE f16 term p = exp2(s - m + 14) (round to nearest even) against V split into f16 hi + lo — two passes — and the softmax denominator is the
+ * sum of the same rounded probabilities (a row of ones in V^T where the head dim leaves a spare MFMA row), so O is an exact convex combination
+ * of the values with weights perturbed by <= 2^-12 (csrc/attention_bf16.hip; 1.42 -> 1.29 ms on 4096^2 keys, d = 40, batch 16).
+ * Replaces nn.dot_product_attention of diffusers' FlaxAttentionBlock inside the U-Net call sites of
+ * ddpo/diffusers_patch/pipeline_flax_stable_diffusion.py:219-224 and ddpo/training/policy_gradient.py:87-102. */
+int ddpo_attention_fwd_f16p(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                            float* o, int ldo, float* lse, int B, int heads, int Nq, int Nk, int d, float scale,
+                            void* ws, size_t ws_bytes, void* stream);
+int ddpo_attention_pack_kv_f16p(const float* k, int ldk, const float* v, int ldv, void* images, size_t images_bytes, int B, int heads,
+                                int Nk, int d, void* stream);
+int ddpo_attention_fwd_f16p_images(const float* q, int ldq, const void* images, size_t images_bytes, float* o, int ldo,
+                                   float* lse, int B, int heads, int Nq, int Nk, int d, float scale, void* stream);
+/* Backward of the same operator.  `dvec` is a scratch of B * heads * (Nq + 1) floats: rowsum(dO * O) followed by one word per (batch, head)
+ * slab — the float bits of max |dO| over the slab, from which the kernels take the power of two that brings dO into the f16 range whatever the
+ * loss scale.  Scores: bf16 hi + lo, three passes; dP = dO V^T, dV = P^T dO, dK = dS^T Q, dQ = dS K: a single f16 term (dO, P, dS) against an
+ * f16 hi + lo split, two passes (csrc/attention_bwd_bf16.hip). */
+int ddpo_attention_bwd_f16p(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o,
+                            const float* d_o, const float* lse, float* dvec, float* dq, float* dk, float* dv,
+                            int B, int heads, int Nq, int Nk, int d, float scale, void* stream);
 
 
 /* Small element-wise pieces. */

@@ -158,10 +158,14 @@ def test_unet_and_train_step_bf16(datapath, mode, tol):
     assert float(info["loss"]) == pytest.approx(oinfo["loss"], rel=tol, abs=1e-6)
 
 
+@pytest.mark.parametrize("variant", ["bf16x3", "f16mx"])
 @pytest.mark.parametrize("B,heads,Nq,Nk,d", [(2, 8, 64, 64, 8), (1, 8, 200, 77, 16), (2, 8, 1024, 1024, 40), (2, 8, 1024, 77, 40),
                                              (1, 8, 256, 256, 80), (1, 5, 130, 333, 64), (1, 8, 4096, 4096, 40)])
-def test_attention_bf16x3(datapath, B, heads, Nq, Nk, d):
-    L.DATAPATH = "bf16x3"
+def test_attention_bf16x3(datapath, B, heads, Nq, Nk, d, variant):
+    """variant = the datapath whose attention operator runs: bf16x3 (three passes everywhere) or f16mx (`f16p`: probabilities as ONE f16 term
+    against V f16 hi / lo, denominator summed from the same rounded values — round 4).  Workspace (Nk >= 256: packed images, LDS-DMA) and
+    self-staging kernels."""
+    L.DATAPATH = variant
     g = torch.Generator().manual_seed(Nq + Nk + d)
     C = heads * d
     q, k, v = torch.randn(B * Nq, C, generator=g), torch.randn(B * Nk, C, generator=g), torch.randn(B * Nk, C, generator=g)
@@ -170,7 +174,8 @@ def test_attention_bf16x3(datapath, B, heads, Nq, Nk, d):
     sp = lambda t, n: t.view(B, n, heads, d).permute(0, 2, 1, 3).double()
     s_ = sp(q, Nq) @ sp(k, Nk).transpose(-1, -2) * d ** -0.5
     ref = (torch.softmax(s_, -1) @ sp(v, Nk)).permute(0, 2, 1, 3).reshape(B * Nq, C)
-    assert _rel(out, ref) < 1e-4
+    print(f"\n[attention fwd {variant} d={d} Nq={Nq} Nk={Nk}] out {_rel(out, ref):.1e}")
+    assert _rel(out, ref) < (3e-5 if variant == "bf16x3" else 1e-4)
     assert _rel(lse.view(B, heads, Nq), torch.logsumexp(s_, -1) / math.log(2.0)) < 1e-4
 
 
@@ -231,10 +236,11 @@ def test_linear_wgrad_bf16x3(datapath, M, K, N):
     assert _rel(db, dy.double().sum(0)) < 2e-6
 
 
+@pytest.mark.parametrize("variant", ["bf16x3", "f16mx"])
 @pytest.mark.parametrize("B,heads,Nq,Nk,d", [(2, 8, 64, 64, 8), (1, 8, 200, 77, 16), (2, 8, 256, 256, 40), (2, 8, 1024, 77, 40),
                                              (1, 8, 256, 256, 80), (1, 5, 130, 333, 64), (1, 8, 1024, 1024, 40)])
-def test_attention_bwd_bf16x3(datapath, B, heads, Nq, Nk, d):
-    L.DATAPATH = "bf16x3"
+def test_attention_bwd_bf16x3(datapath, B, heads, Nq, Nk, d, variant):
+    L.DATAPATH = variant
     g = torch.Generator().manual_seed(Nq + Nk + d)
     C = heads * d
     q, k, v = torch.randn(B * Nq, C, generator=g), torch.randn(B * Nk, C, generator=g), torch.randn(B * Nk, C, generator=g)
@@ -245,7 +251,15 @@ def test_attention_bwd_bf16x3(datapath, B, heads, Nq, Nk, d):
     (torch.softmax(s_, -1) @ sp(vd, Nk)).permute(0, 2, 1, 3).reshape(B * Nq, C).backward(do.double())
     o, lse = L.attention(q.to(DEV), k.to(DEV), v.to(DEV), B, heads, Nq, Nk, d, return_lse=True)
     dq, dk, dv = L.attention_bwd(q.to(DEV), k.to(DEV), v.to(DEV), o, do.to(DEV), lse, B, heads, Nq, Nk, d)
-    assert _rel(dq, qd.grad) < 2e-4 and _rel(dk, kd.grad) < 2e-4 and _rel(dv, vd.grad) < 2e-4
+    e = (_rel(dq, qd.grad), _rel(dk, kd.grad), _rel(dv, vd.grad))
+    print(f"\n[attention bwd {variant} d={d} Nq={Nq} Nk={Nk}] dq {e[0]:.1e} dk {e[1]:.1e} dv {e[2]:.1e}")
+    # bf16x3: every product on three passes (2e-4 of the largest gradient element, as in rounds 1-3).  f16p (round 4): single-f16-term
+    # operands (P, dS, dO: 2^-12 per element) on top of the bf16x3 scores — inside 5e-4 (north-star gate 1e-3)
+    tol = 2e-4 if variant == "bf16x3" else 5e-4
+    assert max(e) < tol
+    # gradients are linear in dO: a 1e-6 loss scale must be as accurate as an O(1) one (f16p: the per-slab power-of-two scaling of dO)
+    dq2, dk2, dv2 = L.attention_bwd(q.to(DEV), k.to(DEV), v.to(DEV), o, (do * 1e-6).to(DEV), lse, B, heads, Nq, Nk, d)
+    assert _rel(dq2 * 1e6, qd.grad) < tol and _rel(dk2 * 1e6, kd.grad) < tol and _rel(dv2 * 1e6, vd.grad) < tol
 
 
 @pytest.mark.parametrize("family,ocfg,ctx", [("tiny", "TINY", 64), ("tiny21", "TINY21", 96)])

@@ -124,12 +124,13 @@ def test_time_projection_table_is_bit_identical_to_per_step_time_path(tiny, monk
     assert torch.equal(unet(x, t, c), y0)
 
 
-def test_context_kv_images_are_bit_identical_to_per_step_staging(monkeypatch):
+@pytest.mark.parametrize("datapath", ["bf16x3", "f16mx"])
+def test_context_kv_images_are_bit_identical_to_per_step_staging(monkeypatch, datapath):
     """precompute_context also packs the text K / V once into the attention kernels' per-tile images; every cross-attention of the
     sampling call then runs from them (ddpo_attention_fwd_bf16x3_images) instead of splitting / transposing K and V in every query tile
     of every step.  Same kernels' arithmetic: the U-Net output must not change by a bit (bf16x3 datapath; fp32 keeps k, v).
     Own model instance (head dim 16 at every level): the module fixture's captured graphs must keep their context buffers."""
-    monkeypatch.setattr(L, "DATAPATH", "bf16x3")
+    monkeypatch.setattr(L, "DATAPATH", datapath)             # f16mx: the f16p attention operator and its images (V as f16 hi / lo + ones row)
     unet = UNet2DCondition(UNetConfig.named("tiny21"), DEV)
     unet.params.init_synthetic(3)
     unet.params.pack_bf16()

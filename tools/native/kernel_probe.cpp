@@ -614,7 +614,7 @@ static int probe_ktime(int B) {
 #endif
 
 // ------------------------------------------------------------------------------------------------ attention
-static void run_attn(int B, int heads, int Nq, int Nk, int d, int iters) {
+static void run_attn(int B, int heads, int Nq, int Nk, int d, int iters, bool f16p = false) {
   const int C = heads * d;
   Dev q((int64_t)B * Nq * C, 21, 1.0f), k((int64_t)B * Nk * C, 22, 1.0f), v((int64_t)B * Nk * C, 23, 1.0f);
   float* o = (float*)dalloc((size_t)B * Nq * C * 4);
@@ -623,7 +623,8 @@ static void run_attn(int B, int heads, int Nq, int Nk, int d, int iters) {
   const size_t wsb = bf ? ddpo_attention_fwd_bf16x3_ws_bytes(B, heads, Nk, d) : 0;
   void* ws = wsb ? dalloc(wsb) : nullptr;
   const float ms = time_ms(iters, [&] {
-    if (bf) ABI_OK(ddpo_attention_fwd_bf16x3(q.p, C, k.p, C, v.p, C, o, C, nullptr, B, heads, Nq, Nk, d, scale, ws, wsb, nullptr));
+    if (bf && f16p) ABI_OK(ddpo_attention_fwd_f16p(q.p, C, k.p, C, v.p, C, o, C, nullptr, B, heads, Nq, Nk, d, scale, ws, wsb, nullptr));
+    else if (bf) ABI_OK(ddpo_attention_fwd_bf16x3(q.p, C, k.p, C, v.p, C, o, C, nullptr, B, heads, Nq, Nk, d, scale, ws, wsb, nullptr));
     else ABI_OK(ddpo_attention_fwd(q.p, C, k.p, C, v.p, C, o, C, nullptr, B, heads, Nq, Nk, d, scale, nullptr));
   });
   double max_err = 0.0;
@@ -651,7 +652,7 @@ static void run_attn(int B, int heads, int Nq, int Nk, int d, int iters) {
   }
   const bool ok = max_err < 2e-4;
   if (!ok) ++g_fail;
-  printf("attn B%-3d h%d Nq=%5d Nk=%5d d=%3d %s: %8.3f ms %7.1f TF  max abs err %.1e %s\n", B, heads, Nq, Nk, d, bf ? "bf16x3" : "fp32  ", ms,
+  printf("attn B%-3d h%d Nq=%5d Nk=%5d d=%3d %s: %8.3f ms %7.1f TF  max abs err %.1e %s\n", B, heads, Nq, Nk, d, bf ? (f16p ? "f16p  " : "bf16x3") : "fp32  ", ms,
          4.0 * B * heads * (double)Nq * Nk * d / (ms * 1e-3) / 1e12, max_err, ok ? "" : "FAIL");
   fflush(stdout);
   q.release(); k.release(); v.release();
@@ -661,7 +662,10 @@ static void run_attn(int B, int heads, int Nq, int Nk, int d, int iters) {
 
 static int probe_attn(int B, int iters) {
   const int cases[][3] = {{4096, 4096, 40}, {4096, 77, 40}, {1024, 1024, 80}, {1024, 77, 80}, {256, 256, 160}, {256, 77, 160}, {64, 64, 160}, {64, 77, 160}};
-  for (auto& c : cases) run_attn(B, 8, c[0], c[1], c[2], iters);
+  for (auto& c : cases) {
+    run_attn(B, 8, c[0], c[1], c[2], iters);
+    if (c[2] != 160) run_attn(B, 8, c[0], c[1], c[2], iters, true);      // the f16mx datapath's operator (one f16 probability term, 2 PV passes)
+  }
   return g_fail;
 }
 
