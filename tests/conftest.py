@@ -52,3 +52,13 @@ def _reset_datapath():
     yield
     L.DATAPATH = "fp32"
     L.PACKED.clear()
+
+
+def parity_record(line):
+    """Append one measured-parity line (error margins of a passing test are invisible under `pytest -q`) to $DDPO_PARITY_LOG, if set
+    (tools/r04_final.sh sets it and copies the file into profiles/)."""
+    path = os.environ.get("DDPO_PARITY_LOG")
+    print(line)
+    if path:
+        with open(path, "a") as f:
+            f.write(line.strip() + "\n")

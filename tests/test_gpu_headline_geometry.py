@@ -79,8 +79,9 @@ def test_headline_geometry_sampler_matches_oracle_and_runs_the_tall_tile():
         e_f, e_n = _rel(final.cpu().numpy(), ofinal), _rel(nxt.cpu().numpy(), onxt)
         e_lp = float(np.abs(lps.cpu().numpy() - olps).max() / np.abs(olps).max())
         per_sample = [_rel(final[i].cpu().numpy(), ofinal[i]) for i in range(B)]
-        print(f"[headline geometry] B={B}, {T} steps, graph path: initial noise {e0:.2e}  final latents {e_f:.2e}  trajectory {e_n:.2e}  "
-              f"log-probs rel {e_lp:.2e}  per-sample final {', '.join(f'{v:.1e}' for v in per_sample)}")
+        from conftest import parity_record
+        parity_record(f"[headline geometry] {datapath} B={B}, {T} steps, graph path: initial noise {e0:.2e}  final latents {e_f:.2e}  trajectory {e_n:.2e}  "
+                      f"log-probs rel {e_lp:.2e}  per-sample final {', '.join(f'{v:.1e}' for v in per_sample)}")
         assert e0 < 2e-6
         assert e_f < 1e-3 and e_n < 1e-3 and e_lp < 1e-3                               # north_star tolerance
     finally:

@@ -258,7 +258,8 @@ def test_sampler_sd21_full_size_96x96_graph_path():
         assert final.shape == (1, 4, 96, 96) and np.array_equal(ts.cpu().numpy(), ots)
         e_f, e_n = _rel(final.cpu().numpy(), ofinal), _rel(nxt.cpu().numpy(), onxt)
         e_lp = float(np.abs(lps.cpu().numpy() - olps).max() / np.abs(olps).max())
-        print(f"\n[sd21 96x96 sampler, {T} steps, graph path] final latents {e_f:.2e}  trajectory {e_n:.2e}  log-probs rel {e_lp:.2e}")
+        from conftest import parity_record
+        parity_record(f"\n[sd21 96x96 sampler, {T} steps, graph path] {SHIPPED}: final latents {e_f:.2e}  trajectory {e_n:.2e}  log-probs rel {e_lp:.2e}")
         assert e_f < 1e-3 and e_n < 1e-3 and e_lp < 1e-3
     finally:
         L.DATAPATH = old

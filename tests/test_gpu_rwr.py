@@ -187,7 +187,9 @@ def test_rwr_step_sd15_full_size_shipped_datapath():
     G = unet.grads
     gn_o = math.sqrt(sum(float((v.double() ** 2).sum()) for v in ograds.values()))
     gn = math.sqrt(float((G.flat.double() ** 2).sum()))
-    print(f"\n[rwr sd15 full size] loss {loss:.6f} vs {oloss:.6f}; grad norm {gn:.6e} vs {gn_o:.6e}")
+    from conftest import parity_record
+    num0 = sum(float((G[n].double().cpu() - ograds[n].double()).pow(2).sum()) for n in ograds)
+    parity_record(f"\n[rwr sd15 full size] {L.DATAPATH}: loss {loss:.6f} vs {oloss:.6f}; grad norm {gn:.6e} vs {gn_o:.6e}; ||g-g_ref||/||g_ref|| {math.sqrt(num0) / gn_o:.2e}")
     assert gn == pytest.approx(gn_o, rel=1e-3)
     num = sum(float((G[n].double().cpu() - ograds[n].double()).pow(2).sum()) for n in ograds)
     assert math.sqrt(num) / gn_o < 2e-3

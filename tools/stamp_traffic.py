@@ -8,7 +8,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-dp = sys.argv[1] if len(sys.argv) > 1 else "bf16x3"
+dp = sys.argv[1] if len(sys.argv) > 1 else "f16mx"          # the shipped datapath (ddpo_amd.lib.SHIPPED_DATAPATH)
 src = os.path.join(ROOT, "gpurun_out", "traffic_unet", "traffic_unet.json")
 raw = json.load(open(src))
 if "traffic_bytes_per_launch" not in raw:

@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ddpo_amd import lib as L
 from ddpo_amd.models.unet import UNet2DCondition, UNetConfig
-L.DATAPATH = os.environ.get("DDPO_DATAPATH", "bf16x3")
+L.DATAPATH = L.shipped_datapath()
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 B = 16
 unet = UNet2DCondition(UNetConfig.named("sd15"), "cuda")

@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ddpo_amd import lib as L
 from ddpo_amd.models.unet import UNet2DCondition, UNetConfig
-L.DATAPATH = os.environ.get("DDPO_DATAPATH", "bf16x3")
+L.DATAPATH = L.shipped_datapath()
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 AB = "--ab" in sys.argv
 B = int(args[0]) if args else 16
