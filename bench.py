@@ -648,8 +648,9 @@ def main(argv=None):
                                           "= XLA HIGH, the reference ran TPU DEFAULT = 1 pass); attention (d in 40/64/80): same split; d=160 attention and norms: exact fp32",
                                 "bf16": "conv/GEMM: single-pass bf16 MFMA, fp32 accumulate (= XLA TPU DEFAULT precision)",
                                 "f16mx": "shipped default (lib.SHIPPED_DATAPATH): conv/GEMM layers with a reduction K >= 2560 run a_h*b_h on the f16 MFMA + ONE MX-scaled "
-                                         "8-bit MFMA carrying both cross terms (a_h8*b_l8 + a_l8*b_h8); every other contraction, the attention and all gradients "
-                                         "as under bf16x3; 4.2e-5 rel on an SD-1.5 U-Net forward against float64 (bf16x3 2.0e-5, north-star gate 1e-3)"}[args.datapath],
+                                         "8-bit MFMA carrying both cross terms (a_h8*b_l8 + a_l8*b_h8); attention (d in 8/16/40/64/80) on the f16p operators (scores bf16x3, "
+                                         "probabilities one f16 term against V f16 hi/lo: 2 second-product passes; backward likewise); short reductions and ALL data / weight "
+                                         "gradients as under bf16x3; ~4e-5 rel on an SD-1.5 U-Net forward against float64 (bf16x3 2e-5, north-star gate 1e-3)"}[args.datapath],
                    "parallelism": f"dp{world}",
                    "global_batch": world * B},
         "end_to_end_tflops": None if tflop_per_image is None else value * tflop_per_image,

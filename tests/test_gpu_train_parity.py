@@ -105,8 +105,13 @@ def _check(family, ocfg, pred, hw, b, ts, ctx_dim, T, datapath, dtype, seed):
         from conftest import parity_record
         parity_record(f"\n[train parity] {family} {datapath} hw={hw} b={b} clip={CLIP}: loss {e_loss:.2e}  log-prob abs {e_lp:.2e}  global grad-norm {rel(gn, gn_o):.2e}  "
                       f"worst block norm {worst} {e_groups[worst]:.2e}  ||g-g_ref||/||g_ref|| {e_dir:.2e}  (|g_ref| = {gn_o:.3e})")
-        assert float(info["clipfrac"]) == 0.0 and float(info["approx_kl"]) == pytest.approx(oinfo["approx_kl"], rel=0.2, abs=1e-10)
+        assert float(info["clipfrac"]) == 0.0
         assert e_lp < LP_BUDGET[datapath]               # margin to the clip boundary (7e-5) is never in question
+        # approx_kl = mean((log p - log p_old)^2) / 2 is QUADRATIC in differences of ~3e-5: a log-prob error e moves it by up to (|drift| e + e^2 / 2)
+        # — 20 % agreement where e << drift (every three-pass case, and f16mx at SD size: e = 2e-7), bounded by the budget otherwise (the toy nets
+        # under f16mx: e = 3e-5, as large as the drift itself)
+        kl_slack = float(drift.abs().max()) * e_lp + 0.5 * e_lp * e_lp
+        assert float(info["approx_kl"]) == pytest.approx(oinfo["approx_kl"], rel=0.2, abs=1e-10 + kl_slack)
         assert e_loss < TOL
         assert rel(gn, gn_o) < TOL
         for k, e in e_groups.items():
