@@ -155,7 +155,7 @@ def shipped_datapath():
 # format) or, when the producer wrote fp32 (training forward: the weight gradients read the fp32 tensor), from ddpo_split_planes_f16mx on the
 # way in — the same bits either way, so the sampler and the training forward of a layer always take the same arithmetic.  Everything else
 # (short reductions — where the f16mx kernel measured no gain —, non-eligible layers, data / weight gradients, attention) runs as under bf16x3.
-MX_MIN_K = 2560
+MX_MIN_K = int(os.environ.get("DDPO_MX_MIN_K", "2560"))          # (the env override exists for the routing experiments of tools/; 2560 is what is validated)
 _TLS = threading.local()
 
 
