@@ -18,19 +18,6 @@
 #include "common.h"
 #include <cstdlib>
 
-// Build-time experiment switches of tools/native (never set for libddpo_hip.so): measured in round 4, neither pays
-// (profiles/r04_probe_attn_qb2_prio.log)
-#ifndef DDPO_ATTN_PRIO
-#define DDPO_ATTN_PRIO 0    /* experiment (tools/native `prio` build): 1 = raise the wave priority around the MFMA phases of the LDS-DMA kernel */
-#endif
-#ifndef DDPO_ATTN_QB
-#define DDPO_ATTN_QB 1      /* 32-query blocks per wave of the LDS-DMA kernel (tools/native `qb2` build: 2) */
-#endif
-#if DDPO_ATTN_PRIO
-#define ATTN_PRIO(p) __builtin_amdgcn_s_setprio(p)
-#else
-#define ATTN_PRIO(p) do { } while (0)
-#endif
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -632,7 +619,6 @@ __global__ void __launch_bounds__(256, (QB == 2 ? 2 : (DVP <= 32 ? 4 : (DKP <= 4
     bf16x8 xh[QB][4], xl[QB][4];           // bf16x3: bf16 hi / lo
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
-      ATTN_PRIO(2);
       f32x16 sacc[2];
   #pragma unroll
       for (int j = 0; j < 2; ++j)
@@ -659,7 +645,6 @@ __global__ void __launch_bounds__(256, (QB == 2 ? 2 : (DVP <= 32 ? 4 : (DKP <= 4
       }
       float alpha;
       bool grew;
-      ATTN_PRIO(0);
       if constexpr (F16P) attn_softmax_tile<ONES>(sacc, m_run[qb], l_run[qb], ph[qb], alpha, grew);
       else attn_softmax_tile_x3(sacc, m_run[qb], l_run[qb], xh[qb], xl[qb], alpha, grew);
       if (__any(grew)) {
@@ -672,10 +657,8 @@ __global__ void __launch_bounds__(256, (QB == 2 ? 2 : (DVP <= 32 ? 4 : (DKP <= 4
     // V(tile) (and K(tile + 1)) have landed; my K fragment reads have returned
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    ATTN_PRIO(2);
     if constexpr (F16P) attn_pv_tile<NDT, LDVT, QB>(Vhi, Vlo, li, h, ph, oacc);      // one V^T fragment feeds QB query blocks
     else attn_pv_tile_x3<NDT, LDVT, QB>(Vhi, Vlo, li, h, xh, xl, oacc);
-    ATTN_PRIO(0);
   }
 
 #pragma unroll
@@ -722,9 +705,9 @@ static int launch_attn_images(const float* q, int ldq, const uint4* img, float* 
   // takes the other head sizes (d = 80) and >= 2 GiB image sets.  (Two query blocks per wave on top measured 1.40 ms at 256 VGPRs with spills — not kept.)
   if constexpr ((2 * I::K_BYTES) % 1024 == 0 && (2 * I::VT_BYTES) % 1024 == 0) {
     if ((int64_t)ntiles * I::BYTES < 0x7FFFFFFF) {
-      constexpr int QB = F16P ? DDPO_ATTN_QB : 1;
-      const dim3 gridq((Nq + 128 * QB - 1) / (128 * QB), B * heads);
-      hipLaunchKernelGGL((attn_fwd_bf16_dma_kernel<D, DKP, DVP, QB, F16P>), gridq, dim3(256), 0, st, q, ldq, img, o, ldo, lse, heads, Nq, Nk, ntiles,
+      // (measured and not kept, round 4: two query blocks per wave, s_setprio around the MFMA phases, and a software-pipelined one-barrier loop
+      // with K and V^T double-buffered — 1.23 / 1.23 / 1.31 ms against 1.22: profiles/r04_probe_attn_qb2_prio.log)
+      hipLaunchKernelGGL((attn_fwd_bf16_dma_kernel<D, DKP, DVP, 1, F16P>), grid, dim3(256), 0, st, q, ldq, img, o, ldo, lse, heads, Nq, Nk, ntiles,
                          scale * 1.4426950408889634f);
       DDPO_LAUNCH_CHECK();
       return DDPO_OK;
