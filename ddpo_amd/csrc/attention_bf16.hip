@@ -224,9 +224,42 @@ __device__ __forceinline__ void attn_tile_tail(const f32x16 (&sacc)[2], float& m
   }
 }
 
+// Where the normalised output rows go.  hi == nullptr: fp32 (rows, ld).  hi != nullptr (ABI v12, ddpo_attention_fwd_*_po): the bf16 hi / lo planes
+// of the SAME fp32 values (the split the fp32-fed GEMM loader applies) — the operand format of the plane-fed to_out projection, so that layer
+// never reads an fp32 tensor; ld = plane row stride in elements (0: k-blocked planes (C / 32, rows, 32)), rows = B * Nq.
+struct AttnOut {
+  float* o;
+  uint16_t* hi;
+  uint16_t* lo;
+  int ld;
+  int64_t rows;
+};
+template <int D, int NDT>
+__device__ __forceinline__ void attn_store_o(const AttnOut out, int64_t row, int col0, const f32x16 (&oacc)[NDT], float inv, int h) {
+#pragma unroll
+  for (int n = 0; n < NDT; ++n) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {            // registers 4g..4g+3 are rows 32n + 8g + 4h + {0,1,2,3} of O^T = 4 consecutive channels
+      const int dc = 32 * n + 8 * g + 4 * h;
+      if (dc >= D) continue;
+      const float v0 = oacc[n][4 * g] * inv, v1 = oacc[n][4 * g + 1] * inv, v2 = oacc[n][4 * g + 2] * inv, v3 = oacc[n][4 * g + 3] * inv;
+      if (out.hi) {
+        uint32_t h0, l0, h1, l1;
+        split2(v0, v1, h0, l0);
+        split2(v2, v3, h1, l1);
+        const int64_t off = plane_off(row, col0 + dc, out.ld, out.rows);
+        *reinterpret_cast<uint2*>(out.hi + off) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(out.lo + off) = make_uint2(l0, l1);
+      } else {
+        *reinterpret_cast<float4*>(out.o + row * out.ld + col0 + dc) = make_float4(v0, v1, v2, v3);
+      }
+    }
+  }
+}
+
 template <int D, int DKP, int DVP, bool F16P>     // head dim, padded to 16 (QK^T reduction) and to 32 (rows of O^T)
 __global__ void __launch_bounds__(256) attn_fwd_bf16_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
-                                                            const float* __restrict__ v, int ldv, float* __restrict__ o, int ldo,
+                                                            const float* __restrict__ v, int ldv, const AttnOut out,
                                                             float* __restrict__ lse, int heads, int Nq, int Nk, float scale_log2e) {
   constexpr int KT = 64;                  // keys per tile
   constexpr int LDK = DKP + 8;            // bf16 per K row: (DKP+8)*2 bytes = odd multiple of 16 B -> conflict-free b128 rows
@@ -339,18 +372,7 @@ __global__ void __launch_bounds__(256) attn_fwd_bf16_kernel(const float* __restr
   const float l_tot = attn_row_sum<D, NDT, ONES>(oacc, l_run, li);
   const float inv = 1.0f / l_tot;
   if (lse && h == 0 && q0 + li < Nq) lse[(int64_t)bh * Nq + q0 + li] = m_run + log2f(l_tot) - (F16P ? ATTN_P_SHIFT : 0.f);
-  if (q0 + li < Nq) {
-    float* op = o + ((int64_t)b * Nq + q0 + li) * ldo + hd * D;
-#pragma unroll
-    for (int n = 0; n < NDT; ++n) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {          // registers 4g..4g+3 are rows 32n + 8g + 4h + {0,1,2,3}
-        const int dc = 32 * n + 8 * g + 4 * h;
-        if (dc < D) *reinterpret_cast<float4*>(op + dc) =
-            make_float4(oacc[n][4 * g] * inv, oacc[n][4 * g + 1] * inv, oacc[n][4 * g + 2] * inv, oacc[n][4 * g + 3] * inv);
-      }
-    }
-  }
+  if (q0 + li < Nq) attn_store_o<D, NDT>(out, (int64_t)b * Nq + q0 + li, hd * D, oacc, inv, h);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -410,7 +432,7 @@ __global__ void __launch_bounds__(256) attn_pack_kv_kernel(const float* __restri
 
 template <int D, int DKP, int DVP, bool F16P>
 __global__ void __launch_bounds__(256, (DVP <= 32 ? 4 : (DKP <= 48 ? 3 : 2))) attn_fwd_bf16_pk_kernel(const float* __restrict__ q, int ldq, const uint4* __restrict__ img,
-                                                               float* __restrict__ o, int ldo, float* __restrict__ lse, int heads,
+                                                               const AttnOut out, float* __restrict__ lse, int heads,
                                                                int Nq, int Nk, int ntiles, float scale_log2e) {
   using I = AttnImg<D, DKP, DVP>;
   constexpr int KT = I::KT, LDK = I::LDK, LDVT = I::LDVT;
@@ -508,18 +530,7 @@ __global__ void __launch_bounds__(256, (DVP <= 32 ? 4 : (DKP <= 48 ? 3 : 2))) at
   const float l_tot = attn_row_sum<D, NDT, ONES>(oacc, l_run, li);
   const float inv = 1.0f / l_tot;
   if (lse && h == 0 && q0 + li < Nq) lse[(int64_t)bh * Nq + q0 + li] = m_run + log2f(l_tot) - (F16P ? ATTN_P_SHIFT : 0.f);
-  if (q0 + li < Nq) {
-    float* op = o + ((int64_t)b * Nq + q0 + li) * ldo + hd * D;
-#pragma unroll
-    for (int n = 0; n < NDT; ++n) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int dc = 32 * n + 8 * g + 4 * h;
-        if (dc < D) *reinterpret_cast<float4*>(op + dc) =
-            make_float4(oacc[n][4 * g] * inv, oacc[n][4 * g + 1] * inv, oacc[n][4 * g + 2] * inv, oacc[n][4 * g + 3] * inv);
-      }
-    }
-  }
+  if (q0 + li < Nq) attn_store_o<D, NDT>(out, (int64_t)b * Nq + q0 + li, hd * D, oacc, inv, h);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -543,7 +554,7 @@ typedef unsigned int u32x4_a __attribute__((ext_vector_type(4)));
 // are re-read: both blocks' score accumulators at once do not fit two waves per SIMD).  Per-query arithmetic and order unchanged.
 template <int D, int DKP, int DVP, int QB, bool F16P>
 __global__ void __launch_bounds__(256, (QB == 2 ? 2 : (DVP <= 32 ? 4 : (DKP <= 48 ? 3 : 2)))) attn_fwd_bf16_dma_kernel(const float* __restrict__ q, int ldq, const uint4* __restrict__ img,
-                                                               float* __restrict__ o, int ldo, float* __restrict__ lse, int heads,
+                                                               const AttnOut out, float* __restrict__ lse, int heads,
                                                                int Nq, int Nk, int ntiles, float scale_log2e) {
   using I = AttnImg<D, DKP, DVP>;
   constexpr int KT = I::KT, LDK = I::LDK, LDVT = I::LDVT;
@@ -667,18 +678,7 @@ __global__ void __launch_bounds__(256, (QB == 2 ? 2 : (DVP <= 32 ? 4 : (DKP <= 4
     const float l_tot = attn_row_sum<D, NDT, ONES>(oacc[qb], l_run[qb], li);
     const float inv = 1.0f / l_tot;
     if (lse && h == 0 && qi < Nq) lse[(int64_t)bh * Nq + qi] = m_run[qb] + log2f(l_tot) - (F16P ? ATTN_P_SHIFT : 0.f);
-    if (qi < Nq) {
-      float* op = o + ((int64_t)b * Nq + qi) * ldo + hd * D;
-#pragma unroll
-      for (int n = 0; n < NDT; ++n) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int dc = 32 * n + 8 * g + 4 * h;
-          if (dc < D) *reinterpret_cast<float4*>(op + dc) =
-              make_float4(oacc[qb][n][4 * g] * inv, oacc[qb][n][4 * g + 1] * inv, oacc[qb][n][4 * g + 2] * inv, oacc[qb][n][4 * g + 3] * inv);
-        }
-      }
-    }
+    if (qi < Nq) attn_store_o<D, NDT>(out, (int64_t)b * Nq + qi, hd * D, oacc[qb], inv, h);
   }
 }
 
@@ -695,7 +695,7 @@ static int launch_pack_kv(const float* k, int ldk, const float* v, int ldv, uint
 
 // attention from pre-packed K / V^T images (one image per 64-key tile and (batch, head))
 template <int D, int DKP, int DVP, bool F16P>
-static int launch_attn_images(const float* q, int ldq, const uint4* img, float* o, int ldo, float* lse, int B, int heads, int Nq, int Nk,
+static int launch_attn_images(const float* q, int ldq, const uint4* img, const AttnOut& out, float* lse, int B, int heads, int Nq, int Nk,
                               float scale, hipStream_t st) {
   using I = AttnImg<D, DKP, DVP>;
   dim3 grid((Nq + 127) / 128, B * heads);
@@ -707,20 +707,20 @@ static int launch_attn_images(const float* q, int ldq, const uint4* img, float* 
     if ((int64_t)ntiles * I::BYTES < 0x7FFFFFFF) {
       // (measured and not kept, round 4: two query blocks per wave, s_setprio around the MFMA phases, and a software-pipelined one-barrier loop
       // with K and V^T double-buffered — 1.23 / 1.23 / 1.31 ms against 1.22: profiles/r04_probe_attn_qb2_prio.log)
-      hipLaunchKernelGGL((attn_fwd_bf16_dma_kernel<D, DKP, DVP, 1, F16P>), grid, dim3(256), 0, st, q, ldq, img, o, ldo, lse, heads, Nq, Nk, ntiles,
+      hipLaunchKernelGGL((attn_fwd_bf16_dma_kernel<D, DKP, DVP, 1, F16P>), grid, dim3(256), 0, st, q, ldq, img, out, lse, heads, Nq, Nk, ntiles,
                          scale * 1.4426950408889634f);
       DDPO_LAUNCH_CHECK();
       return DDPO_OK;
     }
   }
-  hipLaunchKernelGGL((attn_fwd_bf16_pk_kernel<D, DKP, DVP, F16P>), grid, dim3(256), 0, st, q, ldq, img, o, ldo, lse, heads, Nq, Nk, ntiles,
+  hipLaunchKernelGGL((attn_fwd_bf16_pk_kernel<D, DKP, DVP, F16P>), grid, dim3(256), 0, st, q, ldq, img, out, lse, heads, Nq, Nk, ntiles,
                      scale * 1.4426950408889634f);
   DDPO_LAUNCH_CHECK();
   return DDPO_OK;
 }
 
 template <int D, int DKP, int DVP, bool F16P>
-static int launch_attn_bf16(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo, float* lse,
+static int launch_attn_bf16(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const AttnOut& out, float* lse,
                             int B, int heads, int Nq, int Nk, float scale, void* ws, size_t ws_bytes, hipStream_t st) {
   using I = AttnImg<D, DKP, DVP>;
   dim3 grid((Nq + 127) / 128, B * heads);
@@ -730,9 +730,9 @@ static int launch_attn_bf16(const float* q, int ldq, const float* k, int ldk, co
     uint4* img = reinterpret_cast<uint4*>(ws);
     const int rc = launch_pack_kv<D, DKP, DVP, F16P>(k, ldk, v, ldv, img, B, heads, Nk, st);
     if (rc != DDPO_OK) return rc;
-    return launch_attn_images<D, DKP, DVP, F16P>(q, ldq, img, o, ldo, lse, B, heads, Nq, Nk, scale, st);
+    return launch_attn_images<D, DKP, DVP, F16P>(q, ldq, img, out, lse, B, heads, Nq, Nk, scale, st);
   }
-  hipLaunchKernelGGL((attn_fwd_bf16_kernel<D, DKP, DVP, F16P>), grid, dim3(256), 0, st, q, ldq, k, ldk, v, ldv, o, ldo, lse, heads, Nq, Nk,
+  hipLaunchKernelGGL((attn_fwd_bf16_kernel<D, DKP, DVP, F16P>), grid, dim3(256), 0, st, q, ldq, k, ldk, v, ldv, out, lse, heads, Nq, Nk,
                      scale * 1.4426950408889634f);
   DDPO_LAUNCH_CHECK();
   return DDPO_OK;
@@ -771,27 +771,54 @@ extern "C" size_t ddpo_attention_fwd_bf16x3_ws_bytes(int B, int heads, int Nk, i
     default: return DDPO_EINVAL; /* other head dims stay on the exact-fp32 kernel */ \
   }
 
+// output descriptor checks shared by the entry points: fp32 rows 16-byte aligned; planes 8-byte aligned, k-blocked (ld == 0) only with whole
+// 32-channel blocks
+static bool attn_out_ok(const AttnOut& out, int heads, int d) {
+  if (out.hi) {
+    if (!out.lo || out.o || (out.ld & 3) || ((reinterpret_cast<uintptr_t>(out.hi) | reinterpret_cast<uintptr_t>(out.lo)) & 7)) return false;
+    return out.ld != 0 || ((heads * d) & 31) == 0;
+  }
+  return out.o && !(out.ld & 3) && !(reinterpret_cast<uintptr_t>(out.o) & 15);
+}
+
 template <bool F16P>
-static int attention_fwd_impl(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
+static int attention_fwd_impl(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const AttnOut& out,
                               float* lse, int B, int heads, int Nq, int Nk, int d, float scale, void* ws, size_t ws_bytes, void* stream) {
-  if (!q || !k || !v || !o || B <= 0 || heads <= 0 || Nq <= 0 || Nk <= 0) return DDPO_EINVAL;
-  if ((ldq & 3) || (ldk & 3) || (ldv & 3) || (ldo & 3) || (long)B * heads > 65535) return DDPO_EINVAL;
-  if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v) |
-       reinterpret_cast<uintptr_t>(o)) & 15) return DDPO_EINVAL;
+  if (!q || !k || !v || B <= 0 || heads <= 0 || Nq <= 0 || Nk <= 0 || d <= 0 || !attn_out_ok(out, heads, d)) return DDPO_EINVAL;
+  if ((ldq & 3) || (ldk & 3) || (ldv & 3) || (long)B * heads > 65535) return DDPO_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v)) & 15) return DDPO_EINVAL;
   hipStream_t st = as_stream(stream);
-#define CALL(DD, DK, DV) launch_attn_bf16<DD, DK, DV, F16P>(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, heads, Nq, Nk, scale, ws, ws_bytes, st)
+#define CALL(DD, DK, DV) launch_attn_bf16<DD, DK, DV, F16P>(q, ldq, k, ldk, v, ldv, out, lse, B, heads, Nq, Nk, scale, ws, ws_bytes, st)
   ATTN_BY_D(CALL)
 #undef CALL
 }
 extern "C" int ddpo_attention_fwd_bf16x3(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
                                          float* lse, int B, int heads, int Nq, int Nk, int d, float scale, void* ws, size_t ws_bytes,
                                          void* stream) {
-  return attention_fwd_impl<false>(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, heads, Nq, Nk, d, scale, ws, ws_bytes, stream);
+  return attention_fwd_impl<false>(q, ldq, k, ldk, v, ldv, AttnOut{o, nullptr, nullptr, ldo, (int64_t)B * Nq}, lse, B, heads, Nq, Nk, d, scale, ws,
+                                   ws_bytes, stream);
 }
 extern "C" int ddpo_attention_fwd_f16p(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo,
                                        float* lse, int B, int heads, int Nq, int Nk, int d, float scale, void* ws, size_t ws_bytes,
                                        void* stream) {
-  return attention_fwd_impl<true>(q, ldq, k, ldk, v, ldv, o, ldo, lse, B, heads, Nq, Nk, d, scale, ws, ws_bytes, stream);
+  return attention_fwd_impl<true>(q, ldq, k, ldk, v, ldv, AttnOut{o, nullptr, nullptr, ldo, (int64_t)B * Nq}, lse, B, heads, Nq, Nk, d, scale, ws,
+                                  ws_bytes, stream);
+}
+/* Plane-emitting forms (ABI v12): the output leaves as bf16 hi / lo planes (o_hi / o_lo, row stride ld_planes elements; 0 = k-blocked
+ * (heads * d / 32, B * Nq, 32)) of exactly the fp32 values the functions above write — no fp32 tensor is written. */
+extern "C" int ddpo_attention_fwd_bf16x3_po(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, uint16_t* o_hi,
+                                            uint16_t* o_lo, int ld_planes, float* lse, int B, int heads, int Nq, int Nk, int d, float scale,
+                                            void* ws, size_t ws_bytes, void* stream) {
+  if (!o_hi) return DDPO_EINVAL;
+  return attention_fwd_impl<false>(q, ldq, k, ldk, v, ldv, AttnOut{nullptr, o_hi, o_lo, ld_planes, (int64_t)B * Nq}, lse, B, heads, Nq, Nk, d, scale,
+                                   ws, ws_bytes, stream);
+}
+extern "C" int ddpo_attention_fwd_f16p_po(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, uint16_t* o_hi,
+                                          uint16_t* o_lo, int ld_planes, float* lse, int B, int heads, int Nq, int Nk, int d, float scale,
+                                          void* ws, size_t ws_bytes, void* stream) {
+  if (!o_hi) return DDPO_EINVAL;
+  return attention_fwd_impl<true>(q, ldq, k, ldk, v, ldv, AttnOut{nullptr, o_hi, o_lo, ld_planes, (int64_t)B * Nq}, lse, B, heads, Nq, Nk, d, scale,
+                                  ws, ws_bytes, stream);
 }
 
 /* K / V of a (batch, head) set packed ONCE into the per-64-key-tile LDS images the attention kernels stream (any Nk), for callers whose
@@ -833,24 +860,38 @@ extern "C" int ddpo_attention_pack_kv_f16p(const float* k, int ldk, const float*
 }
 
 template <bool F16P>
-static int attention_images_impl(const float* q, int ldq, const void* images, size_t images_bytes, float* o, int ldo, float* lse,
+static int attention_images_impl(const float* q, int ldq, const void* images, size_t images_bytes, const AttnOut& out, float* lse,
                                  int B, int heads, int Nq, int Nk, int d, float scale, void* stream) {
-  if (!q || !images || !o || B <= 0 || heads <= 0 || Nq <= 0 || Nk <= 0) return DDPO_EINVAL;
-  if ((ldq & 3) || (ldo & 3) || (long)B * heads > 65535) return DDPO_EINVAL;
-  if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(images) | reinterpret_cast<uintptr_t>(o)) & 15) return DDPO_EINVAL;
+  if (!q || !images || B <= 0 || heads <= 0 || Nq <= 0 || Nk <= 0 || d <= 0 || !attn_out_ok(out, heads, d)) return DDPO_EINVAL;
+  if ((ldq & 3) || (long)B * heads > 65535) return DDPO_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(images)) & 15) return DDPO_EINVAL;
   const size_t need = ddpo_attention_kv_images_bytes(B, heads, Nk, d);
   if (need == 0 || images_bytes < need) return DDPO_EINVAL;
   hipStream_t st = as_stream(stream);
   const uint4* img = reinterpret_cast<const uint4*>(images);
-#define CALL(DD, DK, DV) launch_attn_images<DD, DK, DV, F16P>(q, ldq, img, o, ldo, lse, B, heads, Nq, Nk, scale, st)
+#define CALL(DD, DK, DV) launch_attn_images<DD, DK, DV, F16P>(q, ldq, img, out, lse, B, heads, Nq, Nk, scale, st)
   ATTN_BY_D(CALL)
 #undef CALL
 }
 extern "C" int ddpo_attention_fwd_bf16x3_images(const float* q, int ldq, const void* images, size_t images_bytes, float* o, int ldo, float* lse,
                                                 int B, int heads, int Nq, int Nk, int d, float scale, void* stream) {
-  return attention_images_impl<false>(q, ldq, images, images_bytes, o, ldo, lse, B, heads, Nq, Nk, d, scale, stream);
+  return attention_images_impl<false>(q, ldq, images, images_bytes, AttnOut{o, nullptr, nullptr, ldo, (int64_t)B * Nq}, lse, B, heads, Nq, Nk, d,
+                                      scale, stream);
 }
 extern "C" int ddpo_attention_fwd_f16p_images(const float* q, int ldq, const void* images, size_t images_bytes, float* o, int ldo, float* lse,
                                               int B, int heads, int Nq, int Nk, int d, float scale, void* stream) {
-  return attention_images_impl<true>(q, ldq, images, images_bytes, o, ldo, lse, B, heads, Nq, Nk, d, scale, stream);
+  return attention_images_impl<true>(q, ldq, images, images_bytes, AttnOut{o, nullptr, nullptr, ldo, (int64_t)B * Nq}, lse, B, heads, Nq, Nk, d,
+                                     scale, stream);
+}
+extern "C" int ddpo_attention_fwd_bf16x3_images_po(const float* q, int ldq, const void* images, size_t images_bytes, uint16_t* o_hi, uint16_t* o_lo,
+                                                   int ld_planes, float* lse, int B, int heads, int Nq, int Nk, int d, float scale, void* stream) {
+  if (!o_hi) return DDPO_EINVAL;
+  return attention_images_impl<false>(q, ldq, images, images_bytes, AttnOut{nullptr, o_hi, o_lo, ld_planes, (int64_t)B * Nq}, lse, B, heads, Nq, Nk,
+                                      d, scale, stream);
+}
+extern "C" int ddpo_attention_fwd_f16p_images_po(const float* q, int ldq, const void* images, size_t images_bytes, uint16_t* o_hi, uint16_t* o_lo,
+                                                 int ld_planes, float* lse, int B, int heads, int Nq, int Nk, int d, float scale, void* stream) {
+  if (!o_hi) return DDPO_EINVAL;
+  return attention_images_impl<true>(q, ldq, images, images_bytes, AttnOut{nullptr, o_hi, o_lo, ld_planes, (int64_t)B * Nq}, lse, B, heads, Nq, Nk,
+                                     d, scale, stream);
 }

@@ -83,6 +83,22 @@ __device__ __forceinline__ f32x16 mx_mfma(const i32x8 a, const i32x8 b, const f3
 
 __device__ __forceinline__ int swz_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }   // bytes
 
+// Cache-policy experiments of the buffer-addressed kernels (tools/native `make exp`; the shipped library defines neither macro):
+//   DDPO_A_CPOL   modifier string of the ACTIVATION LDS-DMA loads (" nt": streaming hint, the activation tile is read once per column tile)
+//   DDPO_OUT_NT   1: fp32 outputs leave with nontemporal stores; 2: the bf16 plane outputs too
+#ifndef DDPO_A_CPOL
+#define DDPO_A_CPOL ""
+#endif
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st_out4(float* p, const float4 v) {
+#ifdef DDPO_OUT_NT
+  f32x4_t t = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(t, reinterpret_cast<f32x4_t*>(p));
+#else
+  *reinterpret_cast<float4*>(p) = v;
+#endif
+}
+
 // plane-emitting output stage: 4 consecutive output values -> 4 bf16 hi + 4 bf16 lo (the split the fp32-fed loader would apply)
 __device__ __forceinline__ void store_planes4(const ddpo_gemm_desc& d, int64_t row, int col, const float4 v) {
   if (d.planes_fmt == 1) {                                            // f16mx planes (common.h)
@@ -92,9 +108,90 @@ __device__ __forceinline__ void store_planes4(const ddpo_gemm_desc& d, int64_t r
   uint2 h, l;
   split4(v, h, l);
   const int64_t o = plane_off(row, col, d.ld_planes, d.M);           // ld_planes == 0: k-blocked planes (ncols / 32, M, 32)
+#if defined(DDPO_OUT_NT) && DDPO_OUT_NT >= 2
+  typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+  u32x2_t th = {h.x, h.y}, tl = {l.x, l.y};
+  __builtin_nontemporal_store(th, reinterpret_cast<u32x2_t*>(d.out_hi + o));
+  __builtin_nontemporal_store(tl, reinterpret_cast<u32x2_t*>(d.out_lo + o));
+#else
   *reinterpret_cast<uint2*>(d.out_hi + o) = h;
   *reinterpret_cast<uint2*>(d.out_lo + o) = l;
+#endif
 }
+
+// Vector output stage of the buffer-addressed kernels: one wave moves NIT x 64 float4 of its sub-tile (rows of WTN columns, LPR = WTN / 4
+// float4 per row) from its LDS slice `cw` to the output, 512 B .. 1 KiB contiguous per row.  Round 4: the bias / row-bias / residual
+// operands are FETCHED IN BATCHES in front of their use.  The first form of this loop loaded them inside each of the 16-40 iterations,
+// behind runtime flags — every iteration its own basic blocks with an s_waitcnt vmcnt(0) in front of the add: one exposed L2 / HBM round
+// trip per float4 (40 per wave and tile; the residual read of a 64x64-level projection ran at 2.8 TB/s and cost 30 us of a 92 us launch,
+// profiles/r04_timeline_sampling_step_before_handover.txt).  Now: the bias float4s of the PER distinct column positions of a lane are loaded
+// once (init); the residual — or row bias — of NB iterations is requested back to back (fetch; clamped addresses: no per-lane branches), the
+// caller's LDS transposition runs under the first batch's latency, and only then are they consumed (drain).  Same arithmetic, same order per
+// element: alpha * acc + bias (+ row bias) (+ residual).
+constexpr int epi_gcd(int a, int b) { return b == 0 ? a : epi_gcd(b, a % b); }
+template <int NIT, int LPR, int WTN, int NBMAX = 10>
+struct EpiRows {
+  static constexpr int PER = LPR / epi_gcd(64, LPR);          // the column of iteration `it` depends on it % PER only
+  // iterations per batch (NBMAX: the tall tile, whose second half of the accumulators is still live during its first pass, takes 5)
+  static constexpr int NB = (NIT % 10 == 0 && NBMAX >= 10) ? 10 : (NIT >= 16 && NIT % 8 == 0 && NBMAX >= 8 ? 8 : (NIT % 5 == 0 && NBMAX >= 5 ? 5 : (NIT % 4 == 0 ? 4 : 1)));
+  float4 bv[PER];                                             // bias of this lane's PER column positions
+  float4 ex[NB];                                              // the batch's residual (or, without a residual, row-bias) operands
+  // bias values, once per tile (zeros without a bias: alpha * acc + 0, as the scalar form does)
+  __device__ __forceinline__ void init(const ddpo_gemm_desc& d, int col_base, int lane) {
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int e = j * 64 + lane, rr = e / LPR;
+      const int colc = min(col_base + (e - rr * LPR) * 4, d.N - 4);
+      bv[j] = d.bias ? *reinterpret_cast<const float4*>(d.bias + colc) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  // request the operands of iterations b0 .. b0 + NB - 1 (clamped addresses: no per-lane branches; masked when they are consumed)
+  // (`lane` is laundered through an empty asm in fetch and drain: the index arithmetic of an iteration is otherwise recognised as common to
+  // both calls and to every pass of the tall tile, computed for all NIT iterations up front and spilled — 1.4 KB of scratch per lane)
+  __device__ __forceinline__ void fetch(const ddpo_gemm_desc& d, int b0, int row_base, int col_base, int lane) {
+    if (!d.residual && !d.rowbias) return;
+    asm volatile("" : "+v"(lane));
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int e = (b0 + i) * 64 + lane, rr = e / LPR;
+      const int rowc = min(row_base + rr, d.M - 1), colc = min(col_base + (e - rr * LPR) * 4, d.N - 4);
+      ex[i] = d.residual ? *reinterpret_cast<const float4*>(d.residual + (int64_t)rowc * d.ld_res + colc)
+                         : *reinterpret_cast<const float4*>(d.rowbias + (int64_t)(rowc / d.rows_per_batch) * d.ld_rowbias + colc);
+    }
+  }
+  // alpha * acc + bias (+ row bias) (+ residual) -> fp32 rows and / or planes, iterations b0 .. b0 + NB - 1
+  __device__ __forceinline__ void drain(const ddpo_gemm_desc& d, const float* cw, int b0, int row_base, int col_base, int lane) {
+    const bool both = d.residual && d.rowbias;                // never in the U-Net (time-embedding bias: conv1; residual: conv2): loaded in place
+    asm volatile("" : "+v"(lane));
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int it = b0 + i;
+      const int e = it * 64 + lane, rr = e / LPR, lcol = (e - rr * LPR) * 4;        // float4 index inside the rows: consecutive lanes, consecutive 16 bytes
+      const int row = row_base + rr, col = col_base + lcol;
+      if (row >= d.M || col >= d.N) continue;
+      float4 v = *reinterpret_cast<const float4*>(cw + rr * WTN + lcol);
+      const float4 b4 = bv[it % PER];
+      v.x = d.alpha * v.x + b4.x; v.y = d.alpha * v.y + b4.y; v.z = d.alpha * v.z + b4.z; v.w = d.alpha * v.w + b4.w;
+      if (both) {
+        const float4 rb = *reinterpret_cast<const float4*>(d.rowbias + (int64_t)(row / d.rows_per_batch) * d.ld_rowbias + col);
+        v.x += rb.x; v.y += rb.y; v.z += rb.z; v.w += rb.w;
+      }
+      if (d.residual || d.rowbias) { v.x += ex[i].x; v.y += ex[i].y; v.z += ex[i].z; v.w += ex[i].w; }
+      if (d.out) st_out4(d.out + (int64_t)row * d.ld_out + col, v);
+      if (d.out_hi) store_planes4(d, row, col, v);
+    }
+  }
+  // split-K: raw partial sums of the staged rows
+  __device__ __forceinline__ static void partials(const ddpo_gemm_desc& d, const float* cw, float* pp, int row_base, int col_base, int lane) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int e = it * 64 + lane, rr = e / LPR, lcol = (e - rr * LPR) * 4;
+      const int row = row_base + rr, col = col_base + lcol;
+      if (row >= d.M || col >= d.N) continue;
+      *reinterpret_cast<float4*>(pp + (int64_t)row * d.N + col) = *reinterpret_cast<const float4*>(cw + rr * WTN + lcol);
+    }
+  }
+};
 
 // AFFINE: no upsampling / zero-insert in the gather, so the source address of tap (ky,kx) is rowptr + (ky*W + kx)*ld + ci
 // and all per-k-tile work is a mask test and one 64-bit add per row (the generic path recomputes coordinates).
@@ -402,7 +499,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
 // swz_off() is applied to the SOURCE chunk each lane fetches.  Same tiles, same k order, same three MFMA passes as the
 // register-staged path: results are bit-identical to it.
 template <int BM, int BN, int NPASS, int ABL = 0, int WM = 2, int WN = 2, bool DEEP = true, int APL = 0>     // ABL: timing ablations (tools/ablate_gemm.py; wrong results)
-__global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const ddpo_gemm_desc d, const uint16_t* __restrict__ w_hi,
+__global__ void __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 64 ? 3 : 1)) gemm_conv_bf16_buf_kernel(const ddpo_gemm_desc d, const uint16_t* __restrict__ w_hi,
                                                                        const uint16_t* __restrict__ w_lo, int ldw, int tiles_m,
                                                                        int tiles_n, int nblk, int kt_per_split,
                                                                        float* __restrict__ part) {
@@ -607,7 +704,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
       const uint32_t la = lds_a + stage * STAGE, lw = lds_w + stage * STAGE;
 #pragma unroll
       for (int i = 0; i < NA; ++i)
-        asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+        asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen" DDPO_A_CPOL " lds"
                      :: "s"(la + i * (PAIRS * 1024)), "v"(avoff[i]), "s"(rs_a), "s"(so_a) : "memory");
 #pragma unroll
       for (int i = 0; i < NB; ++i)
@@ -698,7 +795,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
         const uint32_t so_a = (uint32_t)(cib >> 5) * a_kt_b, la = lds_a3 + stage * A_STAGE;
 #pragma unroll
         for (int i = 0; i < NA; ++i)
-          asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+          asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen" DDPO_A_CPOL " lds"
                        :: "s"(la + i * (PAIRS * 1024)), "v"(avoff[i]), "s"(rs_a), "s"(so_a) : "memory");
         cib += BK;
         if (cib >= cin) {
@@ -955,38 +1052,26 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
       __syncthreads();
       float* cw = reinterpret_cast<float*>(smem) + wid * (32 * WTN);
       float* pp = part ? part + (int64_t)blockIdx.y * d.M * d.N : nullptr;
+      using Epi = EpiRows<NIT, LPR, WTN, 5>;
+      Epi ep;
+      const int colb = n0 + wn * WTN;
 #pragma unroll
       for (int ih = 0; ih < TM; ++ih) {
+        const int rowb = m0 + wm * WTM + ih * 32;
+        // the first pass stages BEFORE it requests anything (all 160 accumulators are still live: no room for the operands); the later
+        // passes request first, into the registers the previous pass freed, and stage under that latency
+        if (ih > 0 && !pp) ep.fetch(d, 0, rowb, colb, lane);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
           for (int r = 0; r < 16; ++r)
             cw[((r & 3) + 8 * (r >> 2) + 4 * khalf) * WTN + j * 32 + (lane & 31)] = acc[ih][j][r];
+        if (pp) { Epi::partials(d, cw, pp, rowb, colb, lane); continue; }
+        if (ih == 0) { ep.init(d, colb, lane); ep.fetch(d, 0, rowb, colb, lane); }
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-          const int e = it * 64 + lane;
-          const int rr = e / LPR, lcol = (e - rr * LPR) * 4;
-          const int row = m0 + wm * WTM + ih * 32 + rr;
-          const int col = n0 + wn * WTN + lcol;
-          if (row >= d.M || col >= d.N) continue;
-          float4 v = *reinterpret_cast<const float4*>(cw + rr * WTN + lcol);
-          if (pp) {
-            *reinterpret_cast<float4*>(pp + (int64_t)row * d.N + col) = v;
-            continue;
-          }
-          float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (d.bias) bv = *reinterpret_cast<const float4*>(d.bias + col);
-          v.x = d.alpha * v.x + bv.x; v.y = d.alpha * v.y + bv.y; v.z = d.alpha * v.z + bv.z; v.w = d.alpha * v.w + bv.w;
-          if (d.rowbias) {
-            const float4 rb = *reinterpret_cast<const float4*>(d.rowbias + (int64_t)(row / d.rows_per_batch) * d.ld_rowbias + col);
-            v.x += rb.x; v.y += rb.y; v.z += rb.z; v.w += rb.w;
-          }
-          if (d.residual) {
-            const float4 rs = *reinterpret_cast<const float4*>(d.residual + (int64_t)row * d.ld_res + col);
-            v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w;
-          }
-          if (d.out) *reinterpret_cast<float4*>(d.out + (int64_t)row * d.ld_out + col) = v;
-          if (d.out_hi) store_planes4(d, row, col, v);
+        for (int b0 = 0; b0 < NIT; b0 += Epi::NB) {
+          if (b0) ep.fetch(d, b0, rowb, colb, lane);
+          ep.drain(d, cw, b0, rowb, colb, lane);
         }
       }
       DBG_T(3);
@@ -999,6 +1084,11 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
     static_assert((WTM * LPR) % 64 == 0, "wave sub-tile must be a whole number of 1 KiB rows");
     __syncthreads();                             // all waves are done with the operand tiles
     float* cw = reinterpret_cast<float*>(smem) + wid * (WTM * WTN);
+    using Epi = EpiRows<NIT, LPR, WTN>;
+    Epi ep;
+    const int rowb = m0 + wm * WTM, colb = n0 + wn * WTN;
+    const bool plain = !part && !(BN == 128 && WN == 2 && WM == 2 && d.epilogue == 1);
+    if (plain) { ep.init(d, colb, lane); ep.fetch(d, 0, rowb, colb, lane); }           // in flight under the transposition below
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1027,39 +1117,19 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_conv_bf16_buf_kernel(const 
           *reinterpret_cast<float4*>(pa) = make_float4(a.x + ba.x, a.y + ba.y, a.z + ba.z, a.w + ba.w);
           *reinterpret_cast<float4*>(pa + (d.N >> 1)) = make_float4(g.x + bg.x, g.y + bg.y, g.z + bg.z, g.w + bg.w);
         }
-        if (d.out) *reinterpret_cast<float4*>(d.out + (int64_t)row * d.ld_out + q * 32 + gc) = o;
+        if (d.out) st_out4(d.out + (int64_t)row * d.ld_out + q * 32 + gc, o);
         if (d.out_hi) store_planes4(d, row, q * 32 + gc, o);
       }
       DBG_T(3);
       return;
     }
-    {
-      float* pp = part ? part + (int64_t)blockIdx.y * d.M * d.N : nullptr;
+    if (part) {
+      Epi::partials(d, cw, part + (int64_t)blockIdx.y * d.M * d.N, rowb, colb, lane);
+    } else {
 #pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        const int e = it * 64 + lane;            // float4 index inside the sub-tile: consecutive lanes, consecutive 16 bytes
-        const int rr = e / LPR, lcol = (e - rr * LPR) * 4;
-        const int row = m0 + wm * WTM + rr;
-        const int col = n0 + wn * WTN + lcol;
-        if (row >= d.M || col >= d.N) continue;
-        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (!part && d.bias) bv = *reinterpret_cast<const float4*>(d.bias + col);
-        float4 v = *reinterpret_cast<const float4*>(cw + rr * WTN + lcol);
-        if (part) {
-          *reinterpret_cast<float4*>(pp + (int64_t)row * d.N + col) = v;
-          continue;
-        }
-        v.x = d.alpha * v.x + bv.x; v.y = d.alpha * v.y + bv.y; v.z = d.alpha * v.z + bv.z; v.w = d.alpha * v.w + bv.w;
-        if (d.rowbias) {
-          const float4 rb = *reinterpret_cast<const float4*>(d.rowbias + (int64_t)(row / d.rows_per_batch) * d.ld_rowbias + col);
-          v.x += rb.x; v.y += rb.y; v.z += rb.z; v.w += rb.w;
-        }
-        if (d.residual) {
-          const float4 rs = *reinterpret_cast<const float4*>(d.residual + (int64_t)row * d.ld_res + col);
-          v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w;
-        }
-        if (d.out) *reinterpret_cast<float4*>(d.out + (int64_t)row * d.ld_out + col) = v;
-        if (d.out_hi) store_planes4(d, row, col, v);
+      for (int b0 = 0; b0 < NIT; b0 += Epi::NB) {
+        if (b0) ep.fetch(d, b0, rowb, colb, lane);
+        ep.drain(d, cw, b0, rowb, colb, lane);
       }
     }
     DBG_T(3);

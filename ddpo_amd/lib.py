@@ -39,7 +39,7 @@ class GemmDesc(ctypes.Structure):
                 ("w_scale", c_void_p), ("planes_fmt", c_int), ("colsum", c_void_p), ("aux_out", c_void_p)]
 
 
-ABI_VERSION = 11         # must equal ddpo_abi_version() of the loaded library (include/ddpo_hip.h)
+ABI_VERSION = 12         # must equal ddpo_abi_version() of the loaded library (include/ddpo_hip.h)
 
 _SIGS = {
     "ddpo_abi_version": (c_int, []),
@@ -97,6 +97,11 @@ _SIGS = {
     "ddpo_attention_pack_kv_f16p": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_void_p]),
     "ddpo_attention_fwd_f16p_images": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                                c_float, c_void_p]),
+    # ABI v12: plane-emitting attention forwards (o_hi, o_lo, ld_planes replace o, ldo)
+    **{f"ddpo_attention_fwd_{v}_po": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,
+                                              c_int, c_int, c_int, c_float, c_void_p, c_size_t, c_void_p]) for v in ("bf16x3", "f16p")},
+    **{f"ddpo_attention_fwd_{v}_images_po": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
+                                                     c_int, c_int, c_float, c_void_p]) for v in ("bf16x3", "f16p")},
     "ddpo_attention_bwd_f16p": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "ddpo_attention_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -1003,12 +1008,31 @@ def linear(x, w, bias=None, **kw):
     return gemm_conv(x, w, M=M, N=N, K=K, bias=bias, **kw)
 
 
-def attention(q, k, v, B, heads, Nq, Nk, d, scale=None, out=None, ldq=None, ldk=None, ldv=None, ldo=None, return_lse=False):
+def attention_planes_ok(d):
+    """True when the attention for head dim `d` runs on the 16-bit MFMA kernels under the current datapath — the ones whose output stage can
+    emit bf16 hi / lo planes (`planes_out=True`)."""
+    return current_datapath() != "fp32" and _x3() and d in (8, 16, 40, 64, 80)
+
+
+def attention(q, k, v, B, heads, Nq, Nk, d, scale=None, out=None, ldq=None, ldk=None, ldv=None, ldo=None, return_lse=False, planes_out=False):
+    """planes_out (check attention_planes_ok first): the result comes back as bf16 hi / lo `Planes` of exactly the fp32 values (ABI v12,
+    ddpo_attention_fwd_*_po) — the operand of a plane-fed to_out projection; no fp32 tensor is written."""
     C = heads * d
+    sc = float(scale if scale is not None else d ** -0.5)
+    if planes_out:
+        if not attention_planes_ok(d) or out is not None or return_lse:
+            raise DdpoHipError("plane-emitting attention needs the bf16x3 / f16mx datapath and a supported head dim (attention_planes_ok)")
+        opl = Planes(B * Nq, C, q.device)
+        nb = int(load().ddpo_attention_fwd_bf16x3_ws_bytes(B, heads, Nk, d))
+        ws = _scratch(nb, q.device, "attn_kv") if nb else None
+        fn, name = (load().ddpo_attention_fwd_f16p_po, "ddpo_attention_fwd_f16p_po") if _mx() else \
+            (load().ddpo_attention_fwd_bf16x3_po, "ddpo_attention_fwd_bf16x3_po")
+        _check(fn(_p(q), int(ldq or C), _p(k), int(ldk or C), _p(v), int(ldv or C), _p(opl.hi), _p(opl.lo), opl.ld,
+                  None, B, heads, Nq, Nk, d, sc, _p(ws), nb, _stream()), name)
+        return opl
     if out is None:
         out = torch.empty(B * Nq, C, dtype=torch.float32, device=q.device)
     lse = torch.empty(B * heads * Nq, dtype=torch.float32, device=q.device) if return_lse else None
-    sc = float(scale if scale is not None else d ** -0.5)
     if current_datapath() != "fp32" and d in (8, 16, 40, 64, 80):
         nb = int(load().ddpo_attention_fwd_bf16x3_ws_bytes(B, heads, Nk, d))      # 0 for short key sequences
         ws = _scratch(nb, q.device, "attn_kv") if nb else None
@@ -1037,10 +1061,19 @@ def attention_kv_images(k, v, B, heads, Nk, d, out=None, ldk=None, ldv=None):
     return out
 
 
-def attention_from_images(q, images, B, heads, Nq, Nk, d, scale=None, out=None, ldq=None, ldo=None, return_lse=False):
+def attention_from_images(q, images, B, heads, Nq, Nk, d, scale=None, out=None, ldq=None, ldo=None, return_lse=False, planes_out=False):
     """softmax(q k^T * scale) v with k, v given as attention_kv_images() — packed under the SAME datapath (the f16mx datapath's images hold V as
-    f16 hi / lo with a row of ones, the bf16x3 datapath's as bf16 hi / lo)."""
+    f16 hi / lo with a row of ones, the bf16x3 datapath's as bf16 hi / lo).  planes_out: as in attention()."""
     C = heads * d
+    if planes_out:
+        if out is not None or return_lse:
+            raise DdpoHipError("plane-emitting attention writes planes only")
+        opl = Planes(B * Nq, C, q.device)
+        fn, name = (load().ddpo_attention_fwd_f16p_images_po, "ddpo_attention_fwd_f16p_images_po") if _mx() else \
+            (load().ddpo_attention_fwd_bf16x3_images_po, "ddpo_attention_fwd_bf16x3_images_po")
+        _check(fn(_p(q), int(ldq or C), _p(images), images.numel(), _p(opl.hi), _p(opl.lo), opl.ld, None, B, heads, Nq, Nk, d,
+                  float(scale if scale is not None else d ** -0.5), _stream()), name)
+        return opl
     if out is None:
         out = torch.empty(B * Nq, C, dtype=torch.float32, device=q.device)
     lse = torch.empty(B * heads * Nq, dtype=torch.float32, device=q.device) if return_lse else None

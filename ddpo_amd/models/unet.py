@@ -183,6 +183,10 @@ def unet_param_shapes(cfg: UNetConfig):
 
 # skip concatenations of the sampling forward are formed in place by the producers (UNet2DCondition.forward); DDPO_SKIP_INPLACE=0: copies
 SKIP_INPLACE = os.environ.get("DDPO_SKIP_INPLACE", "1") == "1"
+# sampling: the second feed-forward GEMM hands its result to proj_out as planes (see _transformer); 0 restores the fp32 hand-over (A/B switch)
+H3_PLANES = os.environ.get("DDPO_H3_PLANES", "1") == "1"
+# sampling: the attention kernels hand their result to to_out as planes (see _attention); 0 restores the fp32 hand-over (A/B switch)
+ATTN_PLANES = os.environ.get("DDPO_ATTN_PLANES", "1") == "1"
 
 
 class Act:
@@ -299,20 +303,25 @@ class UNet2DCondition:
 
     # -------------------------------------------------------------------------------- attention
     def _attention(self, name, x, B, N, C, heads, ctx, ctx_len, rec=None):
+        """Returns the attention output in front of to_out: fp32 (rows, C), or — sampling, where to_out is faster plane-fed (the 64x64 level:
+        103 -> 62 us per launch in the model, profiles/r04_timeline_sampling_step.txt) — the bf16 hi / lo planes the attention kernel's output
+        stage writes instead (the same values, so the block's result does not change by a bit)."""
         P = self.params
         q = L.linear(x, P[name + ".to_q.kernel"])
+        po = bool(rec is None and ATTN_PLANES and L.PLANES_OUT and L.attention_planes_ok(C // heads) and
+                  L.planes_pay(P[name + ".to_out_0.kernel"], C, B * N) == 1)
         cached = self._ctx_kv.get((name, ctx.shape[0])) if (ctx is not None and rec is None and self._ctx_kv_active) else None
         if cached is not None:                     # text-context K / V were projected once for this sampling call
             k, v = cached[0], cached[1]
             if len(cached) > 2 and cached[2] is not None:      # ... and packed once into the attention kernels' K / V^T images
-                return L.attention_from_images(q, cached[2], B, heads, N, ctx_len, C // heads)
+                return L.attention_from_images(q, cached[2], B, heads, N, ctx_len, C // heads, planes_out=po)
         else:
             kv_src = x if ctx is None else ctx
             k = L.linear(kv_src, P[name + ".to_k.kernel"])
             v = L.linear(kv_src, P[name + ".to_v.kernel"])
         Nk = N if ctx is None else ctx_len
         if rec is None:
-            return L.attention(q, k, v, B, heads, N, Nk, C // heads)
+            return L.attention(q, k, v, B, heads, N, Nk, C // heads, planes_out=po)
         o, lse = L.attention(q, k, v, B, heads, N, Nk, C // heads, return_lse=True)
         rec.update(q=q, k=k, v=v, o=o, lse=lse, Nk=Nk)
         return o
@@ -347,6 +356,11 @@ class UNet2DCondition:
         F = P[tb + ".ff.net_2.kernel"].shape[0]
         pl_ff2 = inf and L.PLANES_OUT and L.planes_pay(P[tb + ".ff.net_2.kernel"], F, B * N)       # GEGLU output stage -> planes -> plane-fed FF2
         pl_out = inf and emit_planes and L.planes_out_ok(P[name + ".proj_out.kernel"], C, B * N, C)
+        # sampling: h3 is read by proj_out only — FF2's output stage writes it as planes ONLY where proj_out is faster plane-fed (the 64x64 level:
+        # 103 -> 62 us per launch in the model, profiles/r04_timeline_sampling_step.txt), and no fp32 copy exists
+        pl_h3 = L.planes_pay(P[name + ".proj_out.kernel"], C, B * N) if inf and L.PLANES_OUT and H3_PLANES else 0
+        if pl_h3 and not L.planes_out_ok(P[tb + ".ff.net_2.kernel"], F, B * N, C):
+            pl_h3 = 0
         hn, st = L.groupnorm(x.t, B, N, P[name + ".norm.scale"], P[name + ".norm.bias"], cfg.norm_groups, 1e-5, False, return_stats=True,
                              planes=pl_in)
         if cfg.use_linear_projection:
@@ -373,7 +387,8 @@ class UNet2DCondition:
         if gg is None:
             f = L.linear(l3, P[tb + ".ff.net_0.proj.kernel"], P[tb + ".ff.net_0.proj.bias"])
             gg = L.geglu(f)
-        h3 = L.linear(gg, P[tb + ".ff.net_2.kernel"], P[tb + ".ff.net_2.bias"], residual=h2)
+        h3 = L.linear(gg, P[tb + ".ff.net_2.kernel"], P[tb + ".ff.net_2.bias"], residual=h2,
+                      **(dict(planes_out="only", planes_fmt=pl_h3) if pl_h3 else {}))
         po = dict(planes_out="both", planes_fmt=emit_planes) if pl_out else {}
         if dest is not None:
             po.update(out=dest, ld_out=int(dest.stride(0)))

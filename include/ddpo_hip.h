@@ -339,6 +339,25 @@ int ddpo_attention_bwd_f16p(const float* q, int ldq, const float* k, int ldk, co
                             int B, int heads, int Nq, int Nk, int d, float scale, void* stream);
 
 
+/* ---- Plane-emitting attention forwards (ABI v12).  Same arithmetic and arguments as the function of the same name without `_po`, except that
+ * the normalised output leaves as bf16 hi / lo PLANES (o_hi / o_lo: (B * Nq, heads * d) bf16 each, row stride ld_planes elements, 8-byte
+ * aligned; ld_planes == 0: k-blocked (heads * d / 32, B * Nq, 32), heads * d % 32 == 0) holding exactly the split hi = bf16(x), lo = bf16(x - hi)
+ * of the fp32 value the plain function writes — the activation format of ddpo_gemm_conv_fwd_bf16_planes, so the to_out projection behind the
+ * attention (diffusers FlaxAttentionBlock: proj_attn / to_out_0) reads planes by LDS-DMA and no fp32 tensor is written or re-split: in the
+ * sampling forward at the 64x64 level that projection drops from 103 to 62 us per launch (profiles/r04_timeline_sampling_step.txt).
+ * lse may be NULL.  Sampling path only (the training forward keeps the fp32 output its backward reads). */
+int ddpo_attention_fwd_bf16x3_po(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, uint16_t* o_hi, uint16_t* o_lo,
+                                 int ld_planes, float* lse, int B, int heads, int Nq, int Nk, int d, float scale, void* ws, size_t ws_bytes,
+                                 void* stream);
+int ddpo_attention_fwd_f16p_po(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, uint16_t* o_hi, uint16_t* o_lo,
+                               int ld_planes, float* lse, int B, int heads, int Nq, int Nk, int d, float scale, void* ws, size_t ws_bytes,
+                               void* stream);
+int ddpo_attention_fwd_bf16x3_images_po(const float* q, int ldq, const void* images, size_t images_bytes, uint16_t* o_hi, uint16_t* o_lo,
+                                        int ld_planes, float* lse, int B, int heads, int Nq, int Nk, int d, float scale, void* stream);
+int ddpo_attention_fwd_f16p_images_po(const float* q, int ldq, const void* images, size_t images_bytes, uint16_t* o_hi, uint16_t* o_lo,
+                                      int ld_planes, float* lse, int B, int heads, int Nq, int Nk, int d, float scale, void* stream);
+
+
 /* Small element-wise pieces. */
 int ddpo_geglu_fwd(const float* x, float* y, int64_t rows, int F, void* stream);      /* y = x[:, :F] * gelu_tanh(x[:, F:]) */
 int ddpo_silu_fwd(const float* x, float* y, int64_t n, void* stream);

@@ -179,6 +179,39 @@ def test_attention_bf16x3(datapath, B, heads, Nq, Nk, d, variant):
     assert _rel(lse.view(B, heads, Nq), torch.logsumexp(s_, -1) / math.log(2.0)) < 1e-4
 
 
+@pytest.mark.parametrize("variant", ["bf16x3", "f16mx"])
+@pytest.mark.parametrize("B,heads,Nq,Nk,d", [(2, 8, 64, 64, 8), (1, 8, 200, 77, 16), (2, 8, 1024, 1024, 40), (2, 8, 1024, 77, 40),
+                                             (1, 8, 256, 256, 80), (1, 5, 130, 333, 64)])
+def test_attention_plane_emitting_output_is_the_split_of_the_fp32_output(datapath, B, heads, Nq, Nk, d, variant, monkeypatch):
+    """ABI v12 (ddpo_attention_fwd_*_po / *_images_po): the attention kernels write their result as bf16 hi / lo planes for a plane-fed to_out
+    projection.  The planes must be EXACTLY the split (hi = bf16(x), lo = bf16(x - hi)) of the fp32 tensor the plain entry points write — all
+    three kernels (self-staging, packed images, LDS-DMA), workspace and image forms, row-major and k-blocked plane storage."""
+    L.DATAPATH = variant
+    g = torch.Generator().manual_seed(Nq + Nk + d)
+    C = heads * d
+    q, k, v = (torch.randn(B * n, C, generator=g).to(DEV) for n in (Nq, Nk, Nk))
+    assert L.attention_planes_ok(d)
+    out = L.attention(q, k, v, B, heads, Nq, Nk, d)
+    img = L.attention_kv_images(k, v, B, heads, Nk, d)
+    assert torch.equal(L.attention_from_images(q, img, B, heads, Nq, Nk, d), out)
+    for kblocked in ([False, True] if C % 32 == 0 else [False]):
+        monkeypatch.setattr(L, "A_KBLOCKED", kblocked)
+        want = L.split_planes(out)
+        for got in (L.attention(q, k, v, B, heads, Nq, Nk, d, planes_out=True), L.attention_from_images(q, img, B, heads, Nq, Nk, d, planes_out=True)):
+            assert got.kblocked == kblocked and got.fmt == 0
+            assert torch.equal(got.hi, want.hi) and torch.equal(got.lo, want.lo)
+    # argument checks of the new entry points: no planes, misaligned planes, k-blocked planes without whole 32-channel blocks
+    lib = L.load()
+    fn = lib.ddpo_attention_fwd_f16p_po if variant == "f16mx" else lib.ddpo_attention_fwd_bf16x3_po
+    pl = L.Planes(B * Nq, C, DEV)
+    args = lambda hi, lo, ld: (L._p(q), C, L._p(k), C, L._p(v), C, hi, lo, ld, None, B, heads, Nq, Nk, d, float(d ** -0.5), None, 0, L._stream())
+    assert fn(*args(None, L._p(pl.lo), C)) == -1
+    assert fn(*args(L._p(pl.hi), None, C)) == -1
+    assert fn(*args(pl.hi.data_ptr() + 2, L._p(pl.lo), C)) == -1
+    if C % 32:
+        assert fn(*args(L._p(pl.hi), L._p(pl.lo), 0)) == -1
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cout,ks", [(2, 8, 8, 64, 64, 3), (2, 8, 8, 96, 128, 3), (2, 8, 8, 64, 128, 1), (1, 32, 32, 320, 320, 3),
                                                (3, 6, 10, 64, 64, 3), (2, 16, 16, 640, 320, 3),
                                                (4, 64, 64, 320, 320, 3)])          # last: 16384 pixels, N = 320, K = 2880 -> the wide 128x320 tile

@@ -347,3 +347,64 @@ def test_skip_concat_in_place_is_bit_identical_to_copies(family, ctx_dim, datapa
     # the training forward keeps contiguous tensors and the same bits
     monkeypatch.setattr(U, "SKIP_INPLACE", True)
     assert torch.equal(unet.forward(x, t, c, tape=[]), out[True][0])
+
+
+@pytest.mark.parametrize("family,ctx_dim,datapath", [("tiny", 64, "bf16x3"), ("tiny21", 96, "bf16x3"), ("tiny", 64, "f16mx")])
+def test_plane_handover_behind_attention_and_ff2_is_bit_identical(family, ctx_dim, datapath, monkeypatch):
+    """Round 4: in the sampling forward the attention kernels hand their result to to_out, and the second feed-forward GEMM hands h3 to
+    proj_out, as bf16 hi / lo planes wherever the consumer is faster plane-fed (lib.planes_pay: the 64x64 level of SD) — no fp32 tensor in
+    between.  The planes are the exact split the fp32-fed loader applies and the plane-fed kernels are bit-identical to the fp32-fed ones, so
+    the U-Net output must not move by a bit (DDPO_PLANES_ALL semantics make the tiny models take the path), eagerly, with the cached
+    text-context images and under graph replay; and the path must actually have been taken."""
+    from ddpo_amd.models import unet as U
+    monkeypatch.setattr(L, "DATAPATH", datapath)
+    monkeypatch.setattr(L, "PLANES_ALL", True)
+    if datapath == "f16mx":
+        monkeypatch.setattr(L, "MX_MIN_K", 256)
+    unet = UNet2DCondition(UNetConfig.named(family), DEV)
+    unet.params.init_synthetic(2)
+    unet.params.pack_bf16(bwd=False)
+    g = torch.Generator().manual_seed(13)
+    x1 = torch.randn(3, 4, 16, 16, generator=g).to(DEV)
+    x = torch.cat([x1, x1])
+    t = torch.full((6,), 481, dtype=torch.int32, device=DEV)
+    c = torch.randn(6, 77, ctx_dim, generator=g).to(DEV)
+    seen = {"attn": 0, "img": 0, "h3": 0}
+    real_attn, real_img, real_gc = L.attention, L.attention_from_images, L.gemm_conv
+
+    def attn(*a, **kw):
+        seen["attn"] += bool(kw.get("planes_out"))
+        return real_attn(*a, **kw)
+
+    def img(*a, **kw):
+        seen["img"] += bool(kw.get("planes_out"))
+        return real_img(*a, **kw)
+
+    def gc(*a, **kw):
+        seen["h3"] += kw.get("planes_out") == "only"
+        return real_gc(*a, **kw)
+
+    monkeypatch.setattr(L, "attention", attn)
+    monkeypatch.setattr(L, "attention_from_images", img)
+    monkeypatch.setattr(L, "gemm_conv", gc)
+    out = {}
+    for on in (False, True):
+        monkeypatch.setattr(U, "ATTN_PLANES", on)
+        monkeypatch.setattr(U, "H3_PLANES", on)
+        res = [unet(x, t, c).clone(), unet(x, t, c, cfg_dup=True).clone()]
+        unet.precompute_context(c)                           # cross-attention from the packed text-context images
+        try:
+            res.append(unet(x, t, c).clone())
+            res.append(unet.forward_graphed(x, t, c, cfg_dup=True).clone())
+        finally:
+            unet.release_context()
+        unet._graphs.clear()
+        out[on] = res
+        if not on:
+            assert seen == {"attn": 0, "img": 0, "h3": 0}
+    assert seen["attn"] > 0 and seen["img"] > 0 and seen["h3"] > 0, seen
+    for a, b in zip(out[False], out[True]):
+        assert torch.equal(a, b)
+    # the training forward never takes the hand-over (its backward reads the fp32 tensors) and keeps the same bits
+    n = dict(seen)
+    assert torch.equal(unet.forward(x, t, c, tape=[]), out[True][0]) and seen == n

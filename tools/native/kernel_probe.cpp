@@ -13,6 +13,7 @@
 //                                               planes, accuracy against fp64
 //   kernel_probe wgrad [batch=16] [iters=10]    bf16x3 weight gradients: wide 128x320 tile vs the 128x128 kernel, fp32 and plane operands
 //   kernel_probe attn [batch=16] [iters=10]     bf16x3 / fp32 flash-attention shapes of the same forward
+//   kernel_probe stream                         plain copy of 21 ... 336 MB: what the memory system gives the bytes of a short-reduction layer
 //   kernel_probe ppo                            scoring-mode log-prob + PPO-clip + grouped micro-batches vs a host loop
 //
 // Build: make -C tools/native   (hipcc --offload-arch=gfx950; links ../../ddpo_amd/libddpo_hip.so)
@@ -769,6 +770,30 @@ static int probe_ppo() {
   return ok ? 0 : 1;
 }
 
+// ------------------------------------------------------------------------------------------------ streaming yardstick
+// What the memory system gives a kernel that only moves the bytes of a short-reduction layer: read `mb` MB, write `mb` MB (float4, grid-stride),
+// timed over 3 / 10 / 50 back-to-back launches (3 launches fit the 256 MB Infinity Cache, 50 are steady state) — the yardstick for
+// M=65536,K=320,N=320 (84 MB in, 84 MB out).
+__global__ void __launch_bounds__(256) stream_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+static int probe_stream() {
+  for (int mb : {21, 84, 168, 336}) {
+    const int64_t n4 = (int64_t)mb * (1 << 20) / 16;
+    float4 *src = (float4*)dalloc((size_t)n4 * 16), *dst = (float4*)dalloc((size_t)n4 * 16);
+    for (int grid : {2048, 16384}) {
+      printf("stream copy %4d MB in + %4d MB out, grid %5d:", mb, mb, grid);
+      for (int it : {3, 10, 50}) {
+        const float ms = time_ms(it, [&] { hipLaunchKernelGGL(stream_copy_kernel, dim3(grid), dim3(256), 0, 0, src, dst, n4); });
+        printf("  %2d launches %7.1f us (%5.2f TB/s)", it, ms * 1e3, 2.0 * mb * 1.048576e-3 / ms * 1e-3 * 1e3);
+      }
+      printf("\n");
+    }
+    HIP_OK(hipFree(src)); HIP_OK(hipFree(dst));
+  }
+  return 0;
+}
+
 int main(int argc, char** argv) {
   const std::string mode = argc > 1 ? argv[1] : "gemm";
   const int B = argc > 2 ? atoi(argv[2]) : 16, iters = argc > 3 ? atoi(argv[3]) : 10;
@@ -785,6 +810,7 @@ int main(int argc, char** argv) {
   else if (mode == "wgrad") rc = probe_wgrad(B, iters);
   else if (mode == "attn") rc = probe_attn(B, iters);
   else if (mode == "ppo") rc = probe_ppo();
+  else if (mode == "stream") rc = probe_stream();
 #ifdef PROBE_TIMING
   else if (mode == "ktime") rc = probe_ktime(B);
 #endif
