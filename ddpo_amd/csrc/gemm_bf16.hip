@@ -120,24 +120,31 @@ __device__ __forceinline__ void store_planes4(const ddpo_gemm_desc& d, int64_t r
 }
 
 // Vector output stage of the buffer-addressed kernels: one wave moves NIT x 64 float4 of its sub-tile (rows of WTN columns, LPR = WTN / 4
-// float4 per row) from its LDS slice `cw` to the output, 512 B .. 1 KiB contiguous per row.  Round 4: the bias / row-bias / residual
-// operands are FETCHED IN BATCHES in front of their use.  The first form of this loop loaded them inside each of the 16-40 iterations,
-// behind runtime flags — every iteration its own basic blocks with an s_waitcnt vmcnt(0) in front of the add: one exposed L2 / HBM round
-// trip per float4 (40 per wave and tile; the residual read of a 64x64-level projection ran at 2.8 TB/s and cost 30 us of a 92 us launch,
-// profiles/r04_timeline_sampling_step_before_handover.txt).  Now: the bias float4s of the PER distinct column positions of a lane are loaded
-// once (init); the residual — or row bias — of NB iterations is requested back to back (fetch; clamped addresses: no per-lane branches), the
-// caller's LDS transposition runs under the first batch's latency, and only then are they consumed (drain).  Same arithmetic, same order per
-// element: alpha * acc + bias (+ row bias) (+ residual).
+// float4 per row) from its LDS slice `cw` to the output, 512 B .. 1 KiB contiguous per row.  Round 4: TWO PHASES.  The first form of this
+// loop loaded bias / row bias / residual inside each of its 16-40 iterations, behind runtime flags — every iteration its own basic blocks with
+// an s_waitcnt vmcnt(0) in front of the add, i.e. one exposed L2 / HBM round trip per float4, AND (vmcnt counts stores too, in order) a drain of
+// the previous iteration's stores: the residual read of a 64x64-level projection ran at 2.8 TB/s and cost 30 us of a 92 us launch
+// (profiles/r04_timeline_sampling_step_before_handover.txt).  Now
+//   combine: the operands of NB iterations are requested back to back (clamped addresses: no per-lane branches; the bias float4s of a lane's
+//            PER distinct column positions once per tile), the caller's LDS transposition runs under the first batch's latency, and
+//            alpha * acc + bias (+ row bias) (+ residual) — same arithmetic, same order per element — is written BACK to the same LDS slot
+//            (same lane reads and writes it: wave-private, in-order LDS access, no barrier).  No store is in flight in this phase, so its
+//            waits only ever cover loads.  Skipped when there is nothing to combine (alpha == 1, no bias / row bias / residual: q, k, v).
+//   emit:    LDS -> fp32 rows and / or planes; no loads, so no vmcnt wait: the stores of all iterations stream.
 constexpr int epi_gcd(int a, int b) { return b == 0 ? a : epi_gcd(b, a % b); }
 template <int NIT, int LPR, int WTN, int NBMAX = 10>
 struct EpiRows {
   static constexpr int PER = LPR / epi_gcd(64, LPR);          // the column of iteration `it` depends on it % PER only
   // iterations per batch (NBMAX: the tall tile, whose second half of the accumulators is still live during its first pass, takes 5)
   static constexpr int NB = (NIT % 10 == 0 && NBMAX >= 10) ? 10 : (NIT >= 16 && NIT % 8 == 0 && NBMAX >= 8 ? 8 : (NIT % 5 == 0 && NBMAX >= 5 ? 5 : (NIT % 4 == 0 ? 4 : 1)));
+  static constexpr int LB = NIT % 5 == 0 ? 5 : (NIT % 4 == 0 ? 4 : 1);     // LDS reads in flight in the emit phase
   float4 bv[PER];                                             // bias of this lane's PER column positions
   float4 ex[NB];                                              // the batch's residual (or, without a residual, row-bias) operands
+  bool any;                                                   // there is something to combine
   // bias values, once per tile (zeros without a bias: alpha * acc + 0, as the scalar form does)
   __device__ __forceinline__ void init(const ddpo_gemm_desc& d, int col_base, int lane) {
+    any = d.bias || d.rowbias || d.residual || d.alpha != 1.0f;
+    if (!any) return;
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
       const int e = j * 64 + lane, rr = e / LPR;
@@ -145,9 +152,9 @@ struct EpiRows {
       bv[j] = d.bias ? *reinterpret_cast<const float4*>(d.bias + colc) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
-  // request the operands of iterations b0 .. b0 + NB - 1 (clamped addresses: no per-lane branches; masked when they are consumed)
-  // (`lane` is laundered through an empty asm in fetch and drain: the index arithmetic of an iteration is otherwise recognised as common to
-  // both calls and to every pass of the tall tile, computed for all NIT iterations up front and spilled — 1.4 KB of scratch per lane)
+  // request the operands of iterations b0 .. b0 + NB - 1
+  // (`lane` is laundered through an empty asm in every phase: the index arithmetic of an iteration is otherwise recognised as common to all of
+  // them and to every pass of the tall tile, computed for all NIT iterations up front and spilled — 1.4 KB of scratch per lane)
   __device__ __forceinline__ void fetch(const ddpo_gemm_desc& d, int b0, int row_base, int col_base, int lane) {
     if (!d.residual && !d.rowbias) return;
     asm volatile("" : "+v"(lane));
@@ -159,26 +166,54 @@ struct EpiRows {
                          : *reinterpret_cast<const float4*>(d.rowbias + (int64_t)(rowc / d.rows_per_batch) * d.ld_rowbias + colc);
     }
   }
-  // alpha * acc + bias (+ row bias) (+ residual) -> fp32 rows and / or planes, iterations b0 .. b0 + NB - 1
-  __device__ __forceinline__ void drain(const ddpo_gemm_desc& d, const float* cw, int b0, int row_base, int col_base, int lane) {
+  // alpha * acc + bias (+ row bias) (+ residual), iterations b0 .. b0 + NB - 1, back into the LDS slot
+  __device__ __forceinline__ void combine(const ddpo_gemm_desc& d, float* cw, int b0, int row_base, int col_base, int lane) {
     const bool both = d.residual && d.rowbias;                // never in the U-Net (time-embedding bias: conv1; residual: conv2): loaded in place
     asm volatile("" : "+v"(lane));
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int it = b0 + i;
       const int e = it * 64 + lane, rr = e / LPR, lcol = (e - rr * LPR) * 4;        // float4 index inside the rows: consecutive lanes, consecutive 16 bytes
-      const int row = row_base + rr, col = col_base + lcol;
-      if (row >= d.M || col >= d.N) continue;
       float4 v = *reinterpret_cast<const float4*>(cw + rr * WTN + lcol);
       const float4 b4 = bv[it % PER];
       v.x = d.alpha * v.x + b4.x; v.y = d.alpha * v.y + b4.y; v.z = d.alpha * v.z + b4.z; v.w = d.alpha * v.w + b4.w;
       if (both) {
-        const float4 rb = *reinterpret_cast<const float4*>(d.rowbias + (int64_t)(row / d.rows_per_batch) * d.ld_rowbias + col);
+        const int rowc = min(row_base + rr, d.M - 1), colc = min(col_base + lcol, d.N - 4);
+        const float4 rb = *reinterpret_cast<const float4*>(d.rowbias + (int64_t)(rowc / d.rows_per_batch) * d.ld_rowbias + colc);
         v.x += rb.x; v.y += rb.y; v.z += rb.z; v.w += rb.w;
       }
       if (d.residual || d.rowbias) { v.x += ex[i].x; v.y += ex[i].y; v.z += ex[i].z; v.w += ex[i].w; }
-      if (d.out) st_out4(d.out + (int64_t)row * d.ld_out + col, v);
-      if (d.out_hi) store_planes4(d, row, col, v);
+      *reinterpret_cast<float4*>(cw + rr * WTN + lcol) = v;
+    }
+  }
+  // the whole combine phase of one set of staged rows (the first batch was requested by the caller in front of its LDS transposition)
+  __device__ __forceinline__ void combine_all(const ddpo_gemm_desc& d, float* cw, int row_base, int col_base, int lane) {
+    if (!any) return;
+#pragma unroll
+    for (int b0 = 0; b0 < NIT; b0 += NB) {
+      if (b0) fetch(d, b0, row_base, col_base, lane);
+      combine(d, cw, b0, row_base, col_base, lane);
+    }
+  }
+  // LDS -> fp32 rows and / or planes
+  __device__ __forceinline__ static void emit(const ddpo_gemm_desc& d, const float* cw, int row_base, int col_base, int lane) {
+#pragma unroll
+    for (int b0 = 0; b0 < NIT; b0 += LB) {
+      asm volatile("" : "+v"(lane));
+      float4 v[LB];
+#pragma unroll
+      for (int i = 0; i < LB; ++i) {
+        const int e = (b0 + i) * 64 + lane, rr = e / LPR;
+        v[i] = *reinterpret_cast<const float4*>(cw + rr * WTN + (e - rr * LPR) * 4);
+      }
+#pragma unroll
+      for (int i = 0; i < LB; ++i) {
+        const int e = (b0 + i) * 64 + lane, rr = e / LPR;
+        const int row = row_base + rr, col = col_base + (e - rr * LPR) * 4;
+        if (row >= d.M || col >= d.N) continue;
+        if (d.out) st_out4(d.out + (int64_t)row * d.ld_out + col, v[i]);
+        if (d.out_hi) store_planes4(d, row, col, v[i]);
+      }
     }
   }
   // split-K: raw partial sums of the staged rows
@@ -1055,25 +1090,29 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 64 ? 3 : 1)) g
       using Epi = EpiRows<NIT, LPR, WTN, 5>;
       Epi ep;
       const int colb = n0 + wn * WTN;
-#pragma unroll
-      for (int ih = 0; ih < TM; ++ih) {
+      static_assert(TM == 2, "the tall tile's output stage is written for two 32-row passes per wave");
+      // (the passes are spelled out: left as a loop the optimizer declined to unroll it, and the dynamically indexed accumulators went to scratch)
+      auto pass = [&](auto IH) {
+        constexpr int ih = decltype(IH)::value;
         const int rowb = m0 + wm * WTM + ih * 32;
-        // the first pass stages BEFORE it requests anything (all 160 accumulators are still live: no room for the operands); the later
-        // passes request first, into the registers the previous pass freed, and stage under that latency
+        // the first pass stages BEFORE it requests anything (all 160 accumulators are still live: no room for the operands); the second
+        // requests first, into the registers the first freed, and stages under that latency
         if (ih > 0 && !pp) ep.fetch(d, 0, rowb, colb, lane);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
           for (int r = 0; r < 16; ++r)
             cw[((r & 3) + 8 * (r >> 2) + 4 * khalf) * WTN + j * 32 + (lane & 31)] = acc[ih][j][r];
-        if (pp) { Epi::partials(d, cw, pp, rowb, colb, lane); continue; }
-        if (ih == 0) { ep.init(d, colb, lane); ep.fetch(d, 0, rowb, colb, lane); }
-#pragma unroll
-        for (int b0 = 0; b0 < NIT; b0 += Epi::NB) {
-          if (b0) ep.fetch(d, b0, rowb, colb, lane);
-          ep.drain(d, cw, b0, rowb, colb, lane);
+        if (pp) {
+          Epi::partials(d, cw, pp, rowb, colb, lane);
+        } else {
+          if (ih == 0) { ep.init(d, colb, lane); ep.fetch(d, 0, rowb, colb, lane); }
+          ep.combine_all(d, cw, rowb, colb, lane);
+          Epi::emit(d, cw, rowb, colb, lane);
         }
-      }
+      };
+      pass(std::integral_constant<int, 0>{});
+      pass(std::integral_constant<int, 1>{});
       DBG_T(3);
       return;
     }
@@ -1126,11 +1165,8 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 64 ? 3 : 1)) g
     if (part) {
       Epi::partials(d, cw, part + (int64_t)blockIdx.y * d.M * d.N, rowb, colb, lane);
     } else {
-#pragma unroll
-      for (int b0 = 0; b0 < NIT; b0 += Epi::NB) {
-        if (b0) ep.fetch(d, b0, rowb, colb, lane);
-        ep.drain(d, cw, b0, rowb, colb, lane);
-      }
+      ep.combine_all(d, cw, rowb, colb, lane);
+      Epi::emit(d, cw, rowb, colb, lane);
     }
     DBG_T(3);
     return;
