@@ -15,6 +15,8 @@ fi
 timeout 300 python __graft_entry__.py smoke > gpurun_out/r04_smoke.log 2>&1; echo "smoke exit $?" >> gpurun_out/r04_smoke.log; tail -3 gpurun_out/r04_smoke.log
 # PMC traffic first: bench.py quotes it only when it was taken on the current kernel sources
 N=2 timeout 900 bash tools/pmc_unet_traffic.sh > gpurun_out/r04_pmc_traffic.log 2>&1; tail -12 gpurun_out/r04_pmc_traffic.log | cut -c1-200
+# stamp it into profiles/roofline_traffic.json ON THE BOX so the bench line below carries it (re-run tools/stamp_traffic.py locally afterwards: adds the git commit)
+python tools/stamp_traffic.py f16mx > /dev/null 2>&1 && cp profiles/roofline_traffic.json gpurun_out/roofline_traffic_stamped.json
 timeout 900 python bench.py > gpurun_out/r04_bench_final.log 2>&1; echo "exit $?" >> gpurun_out/r04_bench_final.log; tail -2 gpurun_out/r04_bench_final.log | cut -c1-1500
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_s5 -o bench -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-train-extra --no-alt-datapath-extra > $R/gpurun_out/prof_s5.log 2>&1
@@ -22,6 +24,7 @@ timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_t5 -o bench -
 cd $R
 python tools/rocpd_summary.py $(find gpurun_out/prof_s5 -name "*.db" | head -1) gpurun_out/r04_final_sampling_kernel_stats.md "round 4 final: sampling, shipped datapath (f16mx), bench.py --steps 1 --warmup 0 (includes the graph capture's warm-up forwards)"
 python tools/rocpd_summary.py $(find gpurun_out/prof_t5 -name "*.db" | head -1) gpurun_out/r04_final_train_kernel_stats.md "round 4 final: train, shipped datapath (f16mx), bench.py --mode train --steps 1 --warmup 0"
+python tools/rocpd_timeline.py $(find gpurun_out/prof_s5 -name "*.db" | head -1) gpurun_out/r04_final_timeline_sampling_step.txt      # per-launch view of the last step
 find gpurun_out/prof_s5 gpurun_out/prof_t5 -name "*.db" -delete
 head -24 gpurun_out/r04_final_sampling_kernel_stats.md | cut -c1-170
 timeout 400 python bench.py --mode train --steps 12 --warmup 2 --no-cpu-baseline --no-roofline > gpurun_out/r04_bench_train_final.log 2>&1; tail -1 gpurun_out/r04_bench_train_final.log | cut -c1-400
