@@ -271,3 +271,35 @@ def test_f16mx_routing_is_a_property_of_the_layer(monkeypatch):
         assert L.mx_layer(conv)
     import bench
     assert bench.parse(["--datapath", "f16mx"]).datapath == "f16mx"
+
+
+def test_plane_handover_routing_predicates(monkeypatch):
+    """Host-side conditions of round 4's plane hand-over (models/unet.py `_attention` / `_transformer`): the attention hands planes to to_out, and
+    FF2 hands planes to proj_out, only where the plane-fed consumer is the faster one (planes_pay == 1: the 64x64 level), only on the 16-bit MFMA
+    attention kernels, and FF2 can only emit planes from a buffer-addressed kernel (planes_out_ok)."""
+    import torch
+    from ddpo_amd import lib as L
+    monkeypatch.setattr(L, "PLANES", True)
+    monkeypatch.setattr(L, "PLANES_OUT", True)
+    monkeypatch.setattr(L, "PLANES_ALL", False)
+    entries = {}
+
+    def reg(K, N):
+        w = torch.zeros(1)
+        entries[w.data_ptr()] = dict(fwd=(None, None, K), bwd=None, K=K, N=N)
+        return w
+    monkeypatch.setattr(L, "PACKED", entries)
+    to_out_64, to_out_32, ff2 = reg(320, 320), reg(640, 640), reg(1280, 320)
+    for dp, ok in (("fp32", False), ("bf16", False), ("bf16x3", True), ("f16mx", True)):
+        monkeypatch.setattr(L, "DATAPATH", dp)
+        assert L.attention_planes_ok(40) == ok and L.attention_planes_ok(80) == ok
+        assert not L.attention_planes_ok(160)                                   # d = 160 (SD-2.1's lowest level) stays on the exact-fp32 kernel
+    monkeypatch.setattr(L, "DATAPATH", "f16mx")
+    assert L.planes_pay(to_out_64, 320, 65536) == 1 and L.planes_pay(to_out_32, 640, 16384) == 0      # 64x64 level only
+    assert L.planes_out_ok(ff2, 1280, 65536, 320) and not L.planes_out_ok(ff2, 1280, 65536, 322)      # N % 4
+    assert not L.planes_out_ok(torch.zeros(1), 1280, 65536, 320)                                      # weight planes not registered
+    monkeypatch.setattr(L, "PLANES_OUT", False)
+    assert not L.planes_out_ok(ff2, 1280, 65536, 320)
+    # the switches of the model default to on and are plain module attributes (the GPU test toggles them)
+    from ddpo_amd.models import unet as U
+    assert isinstance(U.ATTN_PLANES, bool) and isinstance(U.H3_PLANES, bool)
