@@ -10,11 +10,48 @@
     if (e__ != hipSuccess) return DDPO_ELAUNCH;               \
   } while (0)
 
+// Butterfly reductions over the 64 lanes: v += partner(lane ^ 32), ^16, ^8, ^4, ^2, ^1 — the association order every "bit-reproducible"
+// statement in this tree rests on.  Shipped form: six `ds_bpermute_b32` (the LDS crossbar).  -DDDPO_EXP_DPP_REDUCE (experiment build only:
+// tools/native/build_variant_lib.sh; never defined for libddpo_hip.so) fetches the SAME partners without the LDS pipe — a + b is commutative, so
+// the bits cannot change as long as the partner is the same lane: ^32 / ^16 through the gfx950 lane swaps (v_permlane32_swap / v_permlane16_swap of
+// two copies: the sum of the two results is v[i] + v[i ^ 32] resp. v[i ^ 16] in every lane), ^8 = row_ror:8, ^4 = row_shl:4 into banks 0, 2 +
+// row_shr:4 into banks 1, 3, ^2 / ^1 = quad_perm.  `tools/native/kernel_probe reduce` checks the two forms against each other bit for bit
+// (it carries its own copy of both) — run it before building a library with the macro.  State at the end of round 4 (profiles/r04_probe_reduce.log):
+// the four DPP steps read exactly lane ^ {8, 4, 2, 1} on hardware and a reduction's latency drops from 192 to 63 ns; the two lane swaps returned
+// [lo, lo] twice because both operands were the same value (one register) — the copy below is the fix, NOT yet re-run on hardware.
+#ifdef DDPO_EXP_DPP_REDUCE
+typedef unsigned int ddpo_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float lane_xor_dpp(float v, int o) {          // the value of lane (i ^ o), o in {1, 2, 4, 8} (compile-time)
+  const int x = __builtin_bit_cast(int, v);
+  int t;
+  if (o == 1) t = __builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, true);                 // quad_perm [1, 0, 3, 2]
+  else if (o == 2) t = __builtin_amdgcn_mov_dpp(x, 0x4E, 0xF, 0xF, true);            // quad_perm [2, 3, 0, 1]
+  else if (o == 8) t = __builtin_amdgcn_mov_dpp(x, 0x128, 0xF, 0xF, true);           // row_ror:8
+  else {
+    t = __builtin_amdgcn_update_dpp(x, x, 0x104, 0xF, 0x5, false);                   // row_shl:4 -> banks 0, 2 (lane i reads i + 4)
+    t = __builtin_amdgcn_update_dpp(t, x, 0x114, 0xF, 0xA, false);                   // row_shr:4 -> banks 1, 3 (lane i reads i - 4)
+  }
+  return __builtin_bit_cast(float, t);
+}
+__device__ __forceinline__ unsigned lane_swap_copy(unsigned a) { asm volatile("" : "+v"(a)); return a; }      // a distinct REGISTER for the swap's second operand
+__device__ __forceinline__ float wave_sum(float v) {
+  ddpo_u32x2 r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), lane_swap_copy(__builtin_bit_cast(unsigned, v)), false, false);
+  v = __builtin_bit_cast(float, r.x) + __builtin_bit_cast(float, r.y);
+  r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), lane_swap_copy(__builtin_bit_cast(unsigned, v)), false, false);
+  v = __builtin_bit_cast(float, r.x) + __builtin_bit_cast(float, r.y);
+  v += lane_xor_dpp(v, 8);
+  v += lane_xor_dpp(v, 4);
+  v += lane_xor_dpp(v, 2);
+  v += lane_xor_dpp(v, 1);
+  return v;
+}
+#else
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+#endif
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
