@@ -77,10 +77,23 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
 
+// gelu(x, approximate=tanh) = 0.5 x (1 + tanh u), u = sqrt(2/pi) (x + 0.044715 x^3).  Shipped form: libm's tanhf (~40 instructions with its
+// range reduction and branches) — 32 evaluations per lane in the fused GEGLU output stage of FF1, i.e. ~4.7 us of VALU per 128 x 128 tile next
+// to 3.2 us of MFMA at K = 320 (ISA count, round 4): about half of FF1's 383 us at the 64x64 level.  -DDDPO_EXP_FAST_GELU (experiment build only,
+// tools/native/build_variant_lib.sh; NOT validated on hardware yet: `kernel_probe gelu` measures both forms against float64): the identity
+// 0.5 (1 + tanh u) = sigmoid(2u) = 1 / (1 + 2^(-2 log2(e) u)) on v_exp_f32 + v_rcp_f32 (~6 instructions, ~2e-7 relative; saturates correctly:
+// 2^(+big) = inf -> 1 / inf = 0, 2^(-big) = 0 -> 1).
+#ifdef DDPO_EXP_FAST_GELU
+__device__ __forceinline__ float sigmoid_2u_fast(float u) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * u)); }
+#endif
 __device__ __forceinline__ float gelu_tanh_f(float x) {
   const float k0 = 0.7978845608028654f, k1 = 0.044715f;
   float u = k0 * (x + k1 * x * x * x);
+#ifdef DDPO_EXP_FAST_GELU
+  return x * sigmoid_2u_fast(u);
+#else
   return 0.5f * x * (1.f + tanhf(u));
+#endif
 }
 
 // ---- fp32 -> bf16 hi / lo split of the bf16x3 datapath (x ~= hi + lo, both bf16, round-to-nearest-even conversions)

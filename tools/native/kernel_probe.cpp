@@ -13,6 +13,7 @@
 //                                               planes, accuracy against fp64
 //   kernel_probe wgrad [batch=16] [iters=10]    bf16x3 weight gradients: wide 128x320 tile vs the 128x128 kernel, fp32 and plane operands
 //   kernel_probe attn [batch=16] [iters=10]     bf16x3 / fp32 flash-attention shapes of the same forward
+//   kernel_probe gelu                           gelu(tanh): libm tanhf form vs the v_exp / v_rcp sigmoid form of -DDDPO_EXP_FAST_GELU against float64, and their VALU cost
 //   kernel_probe reduce                         wave butterfly: ds_bpermute form vs the DPP / lane-swap form of -DDDPO_EXP_DPP_REDUCE, bit for bit + latency
 //   kernel_probe stream                         plain copy of 21 ... 336 MB: what the memory system gives the bytes of a short-reduction layer
 //   kernel_probe ppo                            scoring-mode log-prob + PPO-clip + grouped micro-batches vs a host loop
@@ -915,6 +916,74 @@ static int probe_reduce() {
   return (bad || wrong_sum) ? 1 : 0;
 }
 
+// ------------------------------------------------------------------------------------------------ gelu forms
+// gelu(x, approximate=tanh): libm tanhf (shipped) vs the v_exp_f32 / v_rcp_f32 sigmoid form of -DDDPO_EXP_FAST_GELU (csrc/common.h; both copied
+// here), against float64 on a dense sweep of [-12, 12] plus large / special arguments; then the VALU cost of 32 evaluations per lane.
+__device__ __forceinline__ float gelu_ref_f(float x) {
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  const float u = k0 * (x + k1 * x * x * x);
+  return 0.5f * x * (1.f + tanhf(u));
+}
+__device__ __forceinline__ float gelu_fast_f(float x) {
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  const float u = k0 * (x + k1 * x * x * x);
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * u));
+}
+__global__ void gelu_check_kernel(const float* __restrict__ x, float* __restrict__ a, float* __restrict__ b, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) { a[i] = gelu_ref_f(x[i]); b[i] = gelu_fast_f(x[i]); }
+}
+template <bool FAST>
+__global__ void __launch_bounds__(256) gelu_cost_kernel(const float* __restrict__ x, float* __restrict__ y, int reps) {
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = x[(blockIdx.x * blockDim.x + threadIdx.x) * 8 + j];
+  for (int r = 0; r < reps; ++r)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (FAST ? gelu_fast_f(v[j]) : gelu_ref_f(v[j])) + 0.25f;           // 8 independent chains per lane: throughput, not latency
+  float s_ = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s_ += v[j];
+  y[blockIdx.x * blockDim.x + threadIdx.x] = s_;
+}
+static int probe_gelu() {
+  const int64_t n = 1 << 22;
+  std::vector<float> h(n);
+  for (int64_t i = 0; i < n - 16; ++i) h[i] = -12.0f + 24.0f * (float)i / (float)(n - 16);
+  const float sp[16] = {0.f, -0.f, 1e-30f, -1e-30f, 1e-6f, -1e-6f, 20.f, -20.f, 100.f, -100.f, 1e10f, -1e10f, 3e38f, -3e38f, INFINITY, -INFINITY};
+  for (int j = 0; j < 16; ++j) h[n - 16 + j] = sp[j];
+  float *x = (float*)dalloc(n * 4), *a = (float*)dalloc(n * 4), *b = (float*)dalloc(n * 4);
+  HIP_OK(hipMemcpy(x, h.data(), n * 4, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(gelu_check_kernel, dim3(1024), dim3(256), 0, 0, x, a, b, n);
+  std::vector<float> ha(n), hb(n);
+  HIP_OK(hipMemcpy(ha.data(), a, n * 4, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(hb.data(), b, n * 4, hipMemcpyDeviceToHost));
+  double ea = 0, eb = 0, ra = 0, rb = 0;                // max absolute error, and max error relative to max(|gelu|, 1e-3)
+  int bad_special = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    const double xd = h[i];
+    double ref;
+    if (std::isinf(xd)) ref = xd > 0 ? INFINITY : 0.0;  // gelu(-inf) = -inf * 0 is NaN in both forms' arithmetic; the model never produces it
+    else ref = 0.5 * xd * (1.0 + std::tanh(0.7978845608028654 * (xd + 0.044715 * xd * xd * xd)));
+    if (i >= n - 16) {
+      const bool oka = (std::isinf(ref) ? ha[i] == ref : std::fabs(ha[i] - ref) <= 1e-6 * std::max(1.0, std::fabs(ref))) || (std::isinf(xd) && xd < 0);
+      const bool okb = (std::isinf(ref) ? hb[i] == ref : std::fabs(hb[i] - ref) <= 1e-6 * std::max(1.0, std::fabs(ref))) || (std::isinf(xd) && xd < 0);
+      if (!oka || !okb) { ++bad_special; printf("gelu: special x = %g: tanhf form %g, fast form %g, float64 %g\n", xd, ha[i], hb[i], ref); }
+      continue;
+    }
+    const double den = std::max(std::fabs(ref), 1e-3);
+    ea = std::max(ea, std::fabs(ha[i] - ref)); eb = std::max(eb, std::fabs(hb[i] - ref));
+    ra = std::max(ra, std::fabs(ha[i] - ref) / den); rb = std::max(rb, std::fabs(hb[i] - ref) / den);
+  }
+  printf("gelu: against float64 on [-12, 12] (%lld points): tanhf form max abs %.2e rel %.2e | v_exp / v_rcp form max abs %.2e rel %.2e | specials wrong: %d\n",
+         (long long)(n - 16), ea, ra, eb, rb, bad_special);
+  const int reps = 200, blocks = 1024;
+  const float t0 = time_ms(5, [&] { hipLaunchKernelGGL(gelu_cost_kernel<false>, dim3(blocks), dim3(256), 0, 0, x, a, reps); });
+  const float t1 = time_ms(5, [&] { hipLaunchKernelGGL(gelu_cost_kernel<true>, dim3(blocks), dim3(256), 0, 0, x, b, reps); });
+  printf("gelu: %d x 8 evaluations per lane, 1024 workgroups: tanhf form %.1f us, v_exp / v_rcp form %.1f us (x%.2f)\n", reps, t0 * 1e3, t1 * 1e3, t0 / t1);
+  HIP_OK(hipFree(x)); HIP_OK(hipFree(a)); HIP_OK(hipFree(b));
+  return (rb > 2e-6 || bad_special) ? 1 : 0;
+}
+
 int main(int argc, char** argv) {
   const std::string mode = argc > 1 ? argv[1] : "gemm";
   const int B = argc > 2 ? atoi(argv[2]) : 16, iters = argc > 3 ? atoi(argv[3]) : 10;
@@ -933,6 +1002,7 @@ int main(int argc, char** argv) {
   else if (mode == "ppo") rc = probe_ppo();
   else if (mode == "stream") rc = probe_stream();
   else if (mode == "reduce") rc = probe_reduce();
+  else if (mode == "gelu") rc = probe_gelu();
 #ifdef PROBE_TIMING
   else if (mode == "ktime") rc = probe_ktime(B);
 #endif
