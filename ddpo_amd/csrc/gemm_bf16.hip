@@ -119,6 +119,29 @@ __device__ __forceinline__ void store_planes4(const ddpo_gemm_desc& d, int64_t r
 #endif
 }
 
+// -DDDPO_EXP_EPI_SGPR (experiment build only, tools/native/build_variant_lib.sh; NOT validated on hardware): the descriptor is a by-value kernel
+// argument, and under the SGPR pressure of these kernels the compiler re-MATERIALISES its fields from the kernarg segment wherever they are used —
+// in the emit phase of the output stage five to six `s_load_dword(x2)` + `s_waitcnt lgkmcnt(0)` per iteration (out, out_hi, out_lo, ld_planes,
+// planes_fmt, ld_out: ISA of the tall tile, round 4), i.e. scalar-cache round trips on the critical path of every one of the 16-40 iterations
+// of every tile.  The experiment's emit works on local copies laundered through an empty asm: opaque values that have to stay in registers (an
+// SGPR, or a VGPR lane: one v_readlane).  A register-allocation hint only — the arithmetic cannot change; the shipped build's code is untouched
+// (everything below sits under the macro).
+#ifdef DDPO_EXP_EPI_SGPR
+#define EPI_PIN(x) asm volatile("" : "+s"(x))
+__device__ __forceinline__ void store_planes4_pinned(uint16_t* __restrict__ out_hi, uint16_t* __restrict__ out_lo, int ld_planes, int planes_fmt, int M,
+                                                     int64_t row, int col, const float4 v) {
+  if (planes_fmt == 1) {
+    mx_store4(out_hi, out_lo, row, col, ld_planes, M, v);
+    return;
+  }
+  uint2 h, l;
+  split4(v, h, l);
+  const int64_t o = plane_off(row, col, ld_planes, M);
+  *reinterpret_cast<uint2*>(out_hi + o) = h;
+  *reinterpret_cast<uint2*>(out_lo + o) = l;
+}
+#endif
+
 // Vector output stage of the buffer-addressed kernels: one wave moves NIT x 64 float4 of its sub-tile (rows of WTN columns, LPR = WTN / 4
 // float4 per row) from its LDS slice `cw` to the output, 512 B .. 1 KiB contiguous per row.  Round 4: TWO PHASES.  The first form of this
 // loop loaded bias / row bias / residual inside each of its 16-40 iterations, behind runtime flags — every iteration its own basic blocks with
@@ -197,6 +220,31 @@ struct EpiRows {
   }
   // LDS -> fp32 rows and / or planes
   __device__ __forceinline__ static void emit(const ddpo_gemm_desc& d, const float* cw, int row_base, int col_base, int lane) {
+#ifdef DDPO_EXP_EPI_SGPR
+    float* out = d.out;
+    uint16_t *out_hi = d.out_hi, *out_lo = d.out_lo;
+    int ld_out = d.ld_out, ld_planes = d.ld_planes, planes_fmt = d.planes_fmt, M = d.M, N = d.N;
+    EPI_PIN(out); EPI_PIN(out_hi); EPI_PIN(out_lo); EPI_PIN(ld_out); EPI_PIN(ld_planes); EPI_PIN(planes_fmt); EPI_PIN(M); EPI_PIN(N);
+#pragma unroll
+    for (int b0 = 0; b0 < NIT; b0 += LB) {
+      asm volatile("" : "+v"(lane));
+      float4 v[LB];
+#pragma unroll
+      for (int i = 0; i < LB; ++i) {
+        const int e = (b0 + i) * 64 + lane, rr = e / LPR;
+        v[i] = *reinterpret_cast<const float4*>(cw + rr * WTN + (e - rr * LPR) * 4);
+      }
+#pragma unroll
+      for (int i = 0; i < LB; ++i) {
+        const int e = (b0 + i) * 64 + lane, rr = e / LPR;
+        const int row = row_base + rr, col = col_base + (e - rr * LPR) * 4;
+        if (row >= M || col >= N) continue;
+        if (out) st_out4(out + (int64_t)row * ld_out + col, v[i]);
+        if (out_hi) store_planes4_pinned(out_hi, out_lo, ld_planes, planes_fmt, M, row, col, v[i]);
+      }
+    }
+    return;
+#endif
 #pragma unroll
     for (int b0 = 0; b0 < NIT; b0 += LB) {
       asm volatile("" : "+v"(lane));
