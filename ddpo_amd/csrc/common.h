@@ -45,12 +45,16 @@ __device__ __forceinline__ float wave_sum(float v) {
   v += lane_xor_dpp(v, 1);
   return v;
 }
+__device__ __forceinline__ uint32_t lane_xor1_u32(uint32_t x) {         // neighbour exchange of the lane-paired 16-byte plane stores (norm.hip)
+  return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);
+}
 #else
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+__device__ __forceinline__ uint32_t lane_xor1_u32(uint32_t x) { return __shfl_xor(x, 1, 64); }
 #endif
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll

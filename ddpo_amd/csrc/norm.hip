@@ -140,7 +140,7 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__
         // 16-byte plane stores: lanes 2j / 2j+1 hold adjacent channel quads of one row (C % 8 == 0); the even lane collects
         // both hi halves and writes 8 channels of the hi plane, the odd lane both lo halves and writes the lo plane
         const bool odd = threadIdx.x & 1;
-        const uint32_t rx = __shfl_xor(odd ? h.x : l.x, 1, 64), ry = __shfl_xor(odd ? h.y : l.y, 1, 64);
+        const uint32_t rx = lane_xor1_u32(odd ? h.x : l.x), ry = lane_xor1_u32(odd ? h.y : l.y);
         if (!odd) *reinterpret_cast<uint4*>(y_hi + plane_off(row, c, ldy, (int64_t)B * HW)) = make_uint4(h.x, h.y, rx, ry);
         else *reinterpret_cast<uint4*>(y_lo + plane_off(row, c - 4, ldy, (int64_t)B * HW)) = make_uint4(rx, ry, l.x, l.y);
       } else {
@@ -271,7 +271,7 @@ __device__ __forceinline__ void ln_row(const float4 (&v)[NV], int lane, int C4, 
         split4(o, h, l);
         if (pair) {           // lane-paired 16-byte stores (see gn_apply_kernel); C % 8 == 0 keeps both lanes of a pair inside the row
           const bool odd = lane & 1;
-          const uint32_t rx = __shfl_xor(odd ? h.x : l.x, 1, 64), ry = __shfl_xor(odd ? h.y : l.y, 1, 64);
+          const uint32_t rx = lane_xor1_u32(odd ? h.x : l.x), ry = lane_xor1_u32(odd ? h.y : l.y);
           if (!odd) *reinterpret_cast<uint4*>(y_hi + plane_off(row, c4 << 2, ldy, rows)) = make_uint4(h.x, h.y, rx, ry);
           else *reinterpret_cast<uint4*>(y_lo + plane_off(row, (c4 << 2) - 4, ldy, rows)) = make_uint4(rx, ry, l.x, l.y);
         } else {
