@@ -67,6 +67,10 @@ def parse(argv=None):
                          "(train_fuse_default: 16 at 64x64 latents, fewer for larger latents; DDPO_TRAIN_FUSE overrides); 1 = unfused")
     ap.add_argument("--backend", default=os.environ.get("DDPO_DIST_BACKEND"), help="nccl (= RCCL, default on GPUs) | gloo (CPU tests of --mode comm)")
     ap.add_argument("--comm-mib", type=float, default=None, help="--mode comm: buffer size in MiB (default: the flat fp32 gradient, 3.44 GB)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="CPU rehearsal of an N-rank launch (needs --backend gloo): self-launch, rank environment, per-rank sampling keys, barrier / "
+                         "max-over-ranks timing, the gradient all-reduce and the mode's JSON line with value = null and \"dry_run\": true — "
+                         "NO engine work runs and nothing is measured (tests/test_bench_launch_cpu.py)")
     ap.add_argument("--no-graph", action="store_true", help="launch the U-Net kernels eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -103,7 +107,7 @@ def maybe_self_launch(args, argv):
         return
     if args.gpus == 1:
         return
-    on_cpu = args.mode == "comm" and (args.backend == "gloo")
+    on_cpu = (args.mode == "comm" or args.dry_run) and (args.backend == "gloo")
     if not on_cpu:
         have = torch.cuda.device_count() if torch.cuda.is_available() else 0
         if have < args.gpus:
@@ -189,7 +193,7 @@ class Comm:
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.dist = None
         self.backend = None
-        on_gpu = torch.cuda.is_available() and not (args.mode == "comm" and args.backend == "gloo")
+        on_gpu = torch.cuda.is_available() and not ((args.mode == "comm" or args.dry_run) and args.backend == "gloo")
         self.dev = torch.device("cuda", self.local_rank) if on_gpu else torch.device("cpu")
         if on_gpu:
             torch.cuda.set_device(self.local_rank)
@@ -447,14 +451,7 @@ def bench_train(args, comm):
     res = measure_train(args, comm, L, unet, sched, state, emb, neg, args.steps, args.warmup)
     ar = time_allreduce(comm, unet.params.flat.numel()) if comm.dist is not None else None
     if comm.rank == 0:
-        print(json.dumps({"metric": f"PPO train sample-timesteps/sec (train_cfg, {args.resolution}^2)", "value": res["value"], "unit": "sample-timesteps/sec",
-                          "n_gpus": comm.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
-                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.datapath, "data": "synthetic",
-                          "config": {"workload": f"train_step, {args.model}, train_batch_size {args.train_batch_size}/GPU, train_cfg, "
-                                                 f"{res['micro_steps_per_launch']} micro-step(s) per U-Net forward/backward, optimizer update every {res['optimizer_update_every_micro_steps']} micro-steps",
-                                     "parallelism": f"dp{comm.world}"},
-                          "end_to_end_tflops": res["end_to_end_tflops"], "roofline": res["roofline"],
-                          "rccl_ranks": comm.world if comm.dist is not None else None, "allreduce": ar}), flush=True)
+        print(json.dumps(train_line(args, comm, res, ar)), flush=True)
     comm.close()
 
 
@@ -498,16 +495,75 @@ def bench_epoch(args, comm):
     assert torch.isfinite(img).all()
     ar = time_allreduce(comm, unet.params.flat.numel()) if comm.dist is not None else None
     if comm.rank == 0:
-        n_upd = B // b
-        print(json.dumps({"metric": "DDPO epochs/sec per job (8 images sampled + 200 PPO micro-steps + 4 AdamW updates per GPU)",
-                          "value": args.steps / dt, "unit": "epochs/sec", "n_gpus": comm.world, "steps": args.steps, "warmup": args.warmup,
-                          "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                          "dtype": args.datapath, "data": "synthetic",
-                          "config": {"workload": f"{args.model} {args.resolution}^2: {B} images x {T} DDIM steps + VAE decode, then {B // b} mini-batches x {T} "
-                                                 f"PPO micro-steps (train_cfg, {fuse} fused per launch), {n_upd} optimizer updates each with one "
-                                                 f"all-reduce of the flat gradient", "parallelism": f"dp{comm.world}", "global_batch": comm.world * B},
-                          "images_per_sec": comm.world * B * args.steps / dt, "sample_timesteps_per_sec": comm.world * B * T * args.steps / dt,
-                          "rccl_ranks": comm.world if comm.dist is not None else None, "allreduce": ar}), flush=True)
+        print(json.dumps(epoch_line(args, comm, dt, fuse, ar)), flush=True)
+    comm.close()
+
+
+def epoch_line(args, comm, dt, fuse, ar):
+    """The `--mode epoch` JSON line (dt = max-over-ranks seconds of the timed epochs; None in a dry run)."""
+    T, B, b = args.n_inference_steps, args.sample_batch_size, args.train_batch_size
+    n_upd = B // b
+    per = (lambda x: None) if dt is None else (lambda x: x / dt)
+    return {"metric": "DDPO epochs/sec per job (8 images sampled + 200 PPO micro-steps + 4 AdamW updates per GPU)",
+            "value": per(args.steps), "unit": "epochs/sec", "n_gpus": comm.world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": None if dt is None else dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.datapath, "data": "synthetic",
+            "config": {"workload": f"{args.model} {args.resolution}^2: {B} images x {T} DDIM steps + VAE decode, then {B // b} mini-batches x {T} "
+                                   f"PPO micro-steps (train_cfg, {fuse} fused per launch), {n_upd} optimizer updates each with one "
+                                   f"all-reduce of the flat gradient", "parallelism": f"dp{comm.world}", "global_batch": comm.world * B},
+            "images_per_sec": per(comm.world * B * args.steps), "sample_timesteps_per_sec": per(comm.world * B * T * args.steps),
+            "rccl_ranks": comm.world if comm.dist is not None else None, "allreduce": ar}
+
+
+def train_line(args, comm, res, ar):
+    """The `--mode train` JSON line."""
+    return {"metric": f"PPO train sample-timesteps/sec (train_cfg, {args.resolution}^2)", "value": res["value"], "unit": "sample-timesteps/sec",
+            "n_gpus": comm.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.datapath, "data": "synthetic",
+            "config": {"workload": f"train_step, {args.model}, train_batch_size {args.train_batch_size}/GPU, train_cfg, "
+                                   f"{res['micro_steps_per_launch']} micro-step(s) per U-Net forward/backward, optimizer update every {res['optimizer_update_every_micro_steps']} micro-steps",
+                       "parallelism": f"dp{comm.world}"},
+            "end_to_end_tflops": res["end_to_end_tflops"], "roofline": res["roofline"],
+            "rccl_ranks": comm.world if comm.dist is not None else None, "allreduce": ar}
+
+
+def dry_run(args, comm):
+    """`--dry-run --backend gloo`: everything of an N-rank bench EXCEPT the engine — so that the first launch on an 8-GPU node does not
+    spend its run on a rank-environment or JSON bug.  Checks: one key per rank from the reference key tree (pairwise distinct over ranks),
+    barrier + max-over-ranks, the all-reduce of a gradient-shaped buffer; rank 0 prints the mode's line with value = null."""
+    from ddpo_amd.utils import prng
+    from ddpo_amd.training import distributed as D
+    if comm.dev.type != "cpu":
+        raise SystemExit("bench.py --dry-run is the CPU rehearsal: pass --backend gloo")
+    _, sample_rng = prng.split(prng.PRNGKey(0))
+    sample_rng, sample_seed = prng.split(sample_rng)
+    key = np.asarray(prng.split(sample_seed, comm.world)[comm.rank], dtype=np.uint32)
+    keys = torch.from_numpy(key.astype(np.int64)).reshape(1, -1)
+    if comm.dist is not None:
+        allk = [torch.zeros_like(keys) for _ in range(comm.world)]
+        comm.dist.all_gather(allk, keys)
+        keys = torch.cat(allk)
+    assert len({tuple(r.tolist()) for r in keys}) == comm.world, "ranks must sample from pairwise distinct keys"
+    comm.sync()
+    t0 = time.perf_counter()
+    comm.sync()
+    dt = comm.max_over_ranks(time.perf_counter() - t0)
+    assert dt >= 0.0
+    numel = int((args.comm_mib or 1.0) * (1 << 20) // 4)
+    ar = time_allreduce(comm, numel, reps=1)
+    if comm.rank == 0:
+        T, b = args.n_inference_steps, args.train_batch_size
+        if args.mode == "epoch":
+            line = epoch_line(args, comm, None, max(1, min(args.train_fuse, T)), ar)
+        elif args.mode == "train":
+            fuse = max(1, min(args.train_fuse, T))
+            line = train_line(args, comm, {"value": None, "ms_per_step": None, "micro_steps_per_launch": fuse,
+                                           "optimizer_update_every_micro_steps": T, "end_to_end_tflops": None, "roofline": None}, ar)
+        else:
+            line = sample_line(args, comm, None, None, None, ar, {}, None)
+        line["dry_run"] = True
+        line["data"] = "none (dry run: no engine work, nothing measured)"
+        print(json.dumps(line), flush=True)
     comm.close()
 
 
@@ -515,11 +571,13 @@ def main(argv=None):
     argv = sys.argv[1:] if argv is None else list(argv)
     args = parse(argv)
     maybe_self_launch(args, argv)
-    if args.mode != "comm" and not torch.cuda.is_available():
+    if args.mode != "comm" and not args.dry_run and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the DDPO engine has no CPU path)")
     comm = Comm(args)
     if args.mode == "comm":
         return bench_comm(args, comm)
+    if args.dry_run:
+        return dry_run(args, comm)
     if args.mode == "train":
         return bench_train(args, comm)
     if args.mode == "epoch":
@@ -631,11 +689,18 @@ def main(argv=None):
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args)
+    print(json.dumps(sample_line(args, comm, value, dt, roofline, ar, extra, cpu)), flush=True)
+    comm.close()
+
+
+def sample_line(args, comm, value, dt, roofline, ar, extra, cpu):
+    """The headline JSON line (value = whole-job images/sec, dt = max-over-ranks seconds of the timed steps; both None in a dry run)."""
+    world, B = comm.world, args.sample_batch_size
     key = (args.model, args.resolution)
     tflop_per_image = args.n_inference_steps * 2 * UNET_FWD_TFLOP[key] + VAE_TFLOP[key] if key in UNET_FWD_TFLOP else None
     out = {
         "metric": f"sampled images/sec ({args.resolution}^2, {args.n_inference_steps} DDIM steps)", "value": value, "unit": "images/sec", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": None if dt is None else dt / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": {"fp32": "f32", "bf16x3": "f32 (bf16x3-split MFMA)", "bf16": "bf16 products, f32 accumulate",
                                                                  "f16mx": "f32 (f16mx: f16 MFMA + MX-fp8 cross terms on the long-reduction conv/GEMM layers, bf16x3-split MFMA elsewhere)"}[args.datapath],
         "data": "synthetic",
@@ -653,12 +718,11 @@ def main(argv=None):
                                          "gradients as under bf16x3; ~4e-5 rel on an SD-1.5 U-Net forward against float64 (bf16x3 2e-5, north-star gate 1e-3)"}[args.datapath],
                    "parallelism": f"dp{world}",
                    "global_batch": world * B},
-        "end_to_end_tflops": None if tflop_per_image is None else value * tflop_per_image,
+        "end_to_end_tflops": None if (tflop_per_image is None or value is None) else value * tflop_per_image,
         "roofline": roofline, "cpu_baseline": cpu,
         "rccl_ranks": world if comm.dist is not None else None, "allreduce": ar, "extra": extra,
     }
-    print(json.dumps(out), flush=True)
-    comm.close()
+    return out
 
 
 if __name__ == "__main__":

@@ -257,53 +257,9 @@ __device__ __forceinline__ void attn_store_o(const AttnOut out, int64_t row, int
   }
 }
 
-// -DDDPO_EXP_ATTN_PLANE_LDS (experiment build only, tools/native/build_variant_lib.sh; NOT validated on hardware): the plane-emitting tail above
-// stores 8 bytes per lane and plane to 32 different rows per instruction (10 store instructions per wave at d = 40, 320 cache-line accesses): a
-// 4096^2 self-attention launch takes 1032 us with it against 991 us with the fp32 tail (profiles/r04_ab_epilogue_handover.log), which eats most
-// of what the plane-fed to_out projection gains.  Here the wave's 32 x D block of each plane goes through a wave-private slice of the (idle) K / V
-// LDS and leaves as 16-byte chunks, consecutive lanes on consecutive chunks of a row (D / 8 chunks per row and plane): ~80 line accesses.
-// Same values (the split happens before the staging): tests/test_gpu_bf16.py::test_attention_plane_emitting_output_... must stay green as is.
-#ifdef DDPO_EXP_ATTN_PLANE_LDS
-template <int D, int NDT>
-__device__ __forceinline__ void attn_store_planes_lds(const AttnOut out, char* smem, int wid, int64_t row0, int nvalid, int col0,
-                                                      const f32x16 (&oacc)[NDT], float inv, int li, int h) {
-  static_assert(D % 8 == 0, "16-byte chunks of a head's row");
-  uint16_t* sh = reinterpret_cast<uint16_t*>(smem + wid * (128 * D));      // this wave: [hi | lo][32 rows][D] bf16 = 128 * D bytes
-  uint16_t* sl = sh + 32 * D;
-#pragma unroll
-  for (int n = 0; n < NDT; ++n) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int dc = 32 * n + 8 * g + 4 * h;
-      if (dc >= D) continue;
-      uint32_t h0, l0, h1, l1;
-      split2(oacc[n][4 * g] * inv, oacc[n][4 * g + 1] * inv, h0, l0);
-      split2(oacc[n][4 * g + 2] * inv, oacc[n][4 * g + 3] * inv, h1, l1);
-      *reinterpret_cast<uint2*>(sh + li * D + dc) = make_uint2(h0, h1);
-      *reinterpret_cast<uint2*>(sl + li * D + dc) = make_uint2(l0, l1);
-    }
-  }
-  // (wave-private slice, in-order LDS access within the wave: no barrier between the writes above and the reads below)
-  constexpr int CPR = D / 8, NCH = 32 * CPR;
-  const int lane = li + 32 * h;
-#pragma unroll
-  for (int k0 = 0; k0 < NCH; k0 += 64) {
-    const int k = k0 + lane;
-    const int row = k / CPR, c8 = k - row * CPR;
-    if (k < NCH && row < nvalid) {
-      const uint4 vh = *reinterpret_cast<const uint4*>(sh + row * D + c8 * 8);
-      const uint4 vl = *reinterpret_cast<const uint4*>(sl + row * D + c8 * 8);
-      const int64_t off = plane_off(row0 + row, col0 + c8 * 8, out.ld, out.rows);
-      *reinterpret_cast<uint4*>(out.hi + off) = vh;
-      *reinterpret_cast<uint4*>(out.lo + off) = vl;
-    }
-  }
-}
-// uniform: planes requested, 16-byte aligned, rows a multiple of 8 elements
-__device__ __forceinline__ bool attn_planes_lds_ok(const AttnOut& out) {
-  return out.hi && ((reinterpret_cast<uintptr_t>(out.hi) | reinterpret_cast<uintptr_t>(out.lo)) & 15) == 0 && (out.ld & 7) == 0;
-}
-#endif
+// (Round 5: an LDS-staged variant of the plane-emitting tail above — the wave's 32 x D block of each plane through a wave-private slice of the
+// idle K / V LDS, leaving as 16-byte chunks, ~80 instead of 320 cache-line accesses per wave — produced the same values and the same step time:
+// 3.905 vs 3.906 images/s interleaved on one box, profiles/r05_first_call.log.  Deleted.)
 
 template <int D, int DKP, int DVP, bool F16P>     // head dim, padded to 16 (QK^T reduction) and to 32 (rows of O^T)
 __global__ void __launch_bounds__(256) attn_fwd_bf16_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
@@ -420,13 +376,6 @@ __global__ void __launch_bounds__(256) attn_fwd_bf16_kernel(const float* __restr
   const float l_tot = attn_row_sum<D, NDT, ONES>(oacc, l_run, li);
   const float inv = 1.0f / l_tot;
   if (lse && h == 0 && q0 + li < Nq) lse[(int64_t)bh * Nq + q0 + li] = m_run + log2f(l_tot) - (F16P ? ATTN_P_SHIFT : 0.f);
-#ifdef DDPO_EXP_ATTN_PLANE_LDS
-  if (attn_planes_lds_ok(out)) {
-    __syncthreads();                       // every wave is done with the K / V tiles
-    attn_store_planes_lds<D, NDT>(out, smem, wid, (int64_t)b * Nq + q0, Nq - q0, hd * D, oacc, inv, li, h);
-    return;
-  }
-#endif
   if (q0 + li < Nq) attn_store_o<D, NDT>(out, (int64_t)b * Nq + q0 + li, hd * D, oacc, inv, h);
 }
 
@@ -585,13 +534,6 @@ __global__ void __launch_bounds__(256, (DVP <= 32 ? 4 : (DKP <= 48 ? 3 : 2))) at
   const float l_tot = attn_row_sum<D, NDT, ONES>(oacc, l_run, li);
   const float inv = 1.0f / l_tot;
   if (lse && h == 0 && q0 + li < Nq) lse[(int64_t)bh * Nq + q0 + li] = m_run + log2f(l_tot) - (F16P ? ATTN_P_SHIFT : 0.f);
-#ifdef DDPO_EXP_ATTN_PLANE_LDS
-  if (attn_planes_lds_ok(out)) {
-    __syncthreads();                       // every wave is done with the K / V tiles
-    attn_store_planes_lds<D, NDT>(out, smem, wid, (int64_t)b * Nq + q0, Nq - q0, hd * D, oacc, inv, li, h);
-    return;
-  }
-#endif
   if (q0 + li < Nq) attn_store_o<D, NDT>(out, (int64_t)b * Nq + q0 + li, hd * D, oacc, inv, h);
 }
 
@@ -734,22 +676,12 @@ __global__ void __launch_bounds__(256, (QB == 2 ? 2 : (DVP <= 32 ? 4 : (DKP <= 4
     else attn_pv_tile_x3<NDT, LDVT, QB>(Vhi, Vlo, li, h, xh, xl, oacc);
   }
 
-#ifdef DDPO_EXP_ATTN_PLANE_LDS
-  const bool via_lds = attn_planes_lds_ok(out);
-  if (via_lds) __syncthreads();            // every wave is done with the K / V regions
-#endif
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
     const int qi = q0 + 32 * qb + li;
     const float l_tot = attn_row_sum<D, NDT, ONES>(oacc[qb], l_run[qb], li);
     const float inv = 1.0f / l_tot;
     if (lse && h == 0 && qi < Nq) lse[(int64_t)bh * Nq + qi] = m_run[qb] + log2f(l_tot) - (F16P ? ATTN_P_SHIFT : 0.f);
-#ifdef DDPO_EXP_ATTN_PLANE_LDS
-    if (via_lds) {                         // (QB == 1 in every shipped instantiation: one staging pass per wave)
-      attn_store_planes_lds<D, NDT>(out, smem, wid, (int64_t)b * Nq + q0 + 32 * qb, Nq - (q0 + 32 * qb), hd * D, oacc[qb], inv, li, h);
-      continue;
-    }
-#endif
     if (qi < Nq) attn_store_o<D, NDT>(out, (int64_t)b * Nq + qi, hd * D, oacc[qb], inv, h);
   }
 }

@@ -344,11 +344,7 @@ extern "C" int ddpo_layernorm_bwd(const float* x, const float* dy, const float* 
 __device__ __forceinline__ void gelu_tanh_fwd_bwd(float x, float& g, float& dg) {
   const float k0 = 0.7978845608028654f, k1 = 0.044715f;
   const float u = k0 * (x + k1 * x * x * x);
-#ifdef DDPO_EXP_FAST_GELU
-  const float th = 2.0f * sigmoid_2u_fast(u) - 1.0f;             // experiment build only (common.h)
-#else
-  const float th = tanhf(u);
-#endif
+  const float th = 2.0f * sigmoid_2u_fast(u) - 1.0f;             // tanh u = 2 sigmoid(2u) - 1 (common.h)
   g = 0.5f * x * (1.f + th);
   dg = 0.5f * (1.f + th) + 0.5f * x * (1.f - th * th) * k0 * (1.f + 3.f * k1 * x * x);
 }

@@ -11,51 +11,15 @@
   } while (0)
 
 // Butterfly reductions over the 64 lanes: v += partner(lane ^ 32), ^16, ^8, ^4, ^2, ^1 — the association order every "bit-reproducible"
-// statement in this tree rests on.  Shipped form: six `ds_bpermute_b32` (the LDS crossbar).  -DDDPO_EXP_DPP_REDUCE (experiment build only:
-// tools/native/build_variant_lib.sh; never defined for libddpo_hip.so) fetches the SAME partners without the LDS pipe — a + b is commutative, so
-// the bits cannot change as long as the partner is the same lane: ^32 / ^16 through the gfx950 lane swaps (v_permlane32_swap / v_permlane16_swap of
-// two copies: the sum of the two results is v[i] + v[i ^ 32] resp. v[i ^ 16] in every lane), ^8 = row_ror:8, ^4 = row_shl:4 into banks 0, 2 +
-// row_shr:4 into banks 1, 3, ^2 / ^1 = quad_perm.  `tools/native/kernel_probe reduce` checks the two forms against each other bit for bit
-// (it carries its own copy of both) — run it before building a library with the macro.  State at the end of round 4 (profiles/r04_probe_reduce.log):
-// the four DPP steps read exactly lane ^ {8, 4, 2, 1} on hardware and a reduction's latency drops from 192 to 63 ns; the two lane swaps returned
-// [lo, lo] twice because both operands were the same value (one register) — the copy below is the fix, NOT yet re-run on hardware.
-#ifdef DDPO_EXP_DPP_REDUCE
-typedef unsigned int ddpo_u32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float lane_xor_dpp(float v, int o) {          // the value of lane (i ^ o), o in {1, 2, 4, 8} (compile-time)
-  const int x = __builtin_bit_cast(int, v);
-  int t;
-  if (o == 1) t = __builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, true);                 // quad_perm [1, 0, 3, 2]
-  else if (o == 2) t = __builtin_amdgcn_mov_dpp(x, 0x4E, 0xF, 0xF, true);            // quad_perm [2, 3, 0, 1]
-  else if (o == 8) t = __builtin_amdgcn_mov_dpp(x, 0x128, 0xF, 0xF, true);           // row_ror:8
-  else {
-    t = __builtin_amdgcn_update_dpp(x, x, 0x104, 0xF, 0x5, false);                   // row_shl:4 -> banks 0, 2 (lane i reads i + 4)
-    t = __builtin_amdgcn_update_dpp(t, x, 0x114, 0xF, 0xA, false);                   // row_shr:4 -> banks 1, 3 (lane i reads i - 4)
-  }
-  return __builtin_bit_cast(float, t);
-}
-__device__ __forceinline__ unsigned lane_swap_copy(unsigned a) { asm volatile("" : "+v"(a)); return a; }      // a distinct REGISTER for the swap's second operand
-__device__ __forceinline__ float wave_sum(float v) {
-  ddpo_u32x2 r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), lane_swap_copy(__builtin_bit_cast(unsigned, v)), false, false);
-  v = __builtin_bit_cast(float, r.x) + __builtin_bit_cast(float, r.y);
-  r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), lane_swap_copy(__builtin_bit_cast(unsigned, v)), false, false);
-  v = __builtin_bit_cast(float, r.x) + __builtin_bit_cast(float, r.y);
-  v += lane_xor_dpp(v, 8);
-  v += lane_xor_dpp(v, 4);
-  v += lane_xor_dpp(v, 2);
-  v += lane_xor_dpp(v, 1);
-  return v;
-}
-__device__ __forceinline__ uint32_t lane_xor1_u32(uint32_t x) {         // neighbour exchange of the lane-paired 16-byte plane stores (norm.hip)
-  return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);
-}
-#else
+// statement in this tree rests on — as six `ds_bpermute_b32` (the LDS crossbar).  (Round 5: a DPP / v_permlane{32,16}_swap form was 3x faster per
+// reduction, 193 -> 64 ns, but its two lane-swap steps did not return lane ^ 32 / ^ 16 on hardware in either of its two spellings — 67 % of the
+// lanes differed from this butterfly, profiles/r05_first_call.log — and the norms it would have served are 3 % of the sampling step: deleted.)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
 __device__ __forceinline__ uint32_t lane_xor1_u32(uint32_t x) { return __shfl_xor(x, 1, 64); }
-#endif
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -81,24 +45,18 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
 
-// gelu(x, approximate=tanh) = 0.5 x (1 + tanh u), u = sqrt(2/pi) (x + 0.044715 x^3).  Shipped form: libm's tanhf (~40 instructions with its
-// range reduction and branches) — 32 evaluations per lane in the fused GEGLU output stage of FF1, i.e. ~4.7 us of VALU per 128 x 128 tile next
-// to 3.2 us of MFMA at K = 320 (ISA count, round 4): about half of FF1's 383 us at the 64x64 level.  -DDDPO_EXP_FAST_GELU (experiment build only,
-// tools/native/build_variant_lib.sh; NOT validated on hardware yet: `kernel_probe gelu` measures both forms against float64): the identity
+// gelu(x, approximate=tanh) = 0.5 x (1 + tanh u), u = sqrt(2/pi) (x + 0.044715 x^3), evaluated through the identity
 // 0.5 (1 + tanh u) = sigmoid(2u) = 1 / (1 + 2^(-2 log2(e) u)) on v_exp_f32 + v_rcp_f32 (~6 instructions; saturates correctly: 2^(+big) = inf ->
-// 1 / inf = 0, 2^(-big) = 0 -> 1).  It is also the MORE accurate form for negative x, where 1 + tanh(u) cancels: float32 emulation against
-// float64 on [-12, 12], error relative to max(|gelu|, 1e-3): 1.5e-6 (sigmoid form, exact exp2 / reciprocal) vs 1.5e-4 (tanh form).
-#ifdef DDPO_EXP_FAST_GELU
+// 1 / inf = 0, 2^(-big) = 0 -> 1).  Rounds 1-4 called libm's tanhf (~40 instructions with its range reduction and branches): 32 evaluations per
+// lane in the fused GEGLU output stage of FF1 were 1786 VALU instructions per lane and 128 x 128 tile against 918 now.  Measured on MI355X
+// (round 5, `kernel_probe gelu`, profiles/r05_first_call.log): against float64 on [-12, 12] max abs error 5.2e-7 (tanhf form 4.3e-7), error
+// relative to max(|gelu|, 1e-3) 1.3e-6 (tanhf form 7.7e-5: 1 + tanh(u) cancels for negative x), 2.57x faster per evaluation; sampling +1.0 %
+// interleaved on one box.
 __device__ __forceinline__ float sigmoid_2u_fast(float u) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * u)); }
-#endif
 __device__ __forceinline__ float gelu_tanh_f(float x) {
   const float k0 = 0.7978845608028654f, k1 = 0.044715f;
   float u = k0 * (x + k1 * x * x * x);
-#ifdef DDPO_EXP_FAST_GELU
   return x * sigmoid_2u_fast(u);
-#else
-  return 0.5f * x * (1.f + tanhf(u));
-#endif
 }
 
 // ---- fp32 -> bf16 hi / lo split of the bf16x3 datapath (x ~= hi + lo, both bf16, round-to-nearest-even conversions)

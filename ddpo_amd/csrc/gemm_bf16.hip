@@ -83,20 +83,8 @@ __device__ __forceinline__ f32x16 mx_mfma(const i32x8 a, const i32x8 b, const f3
 
 __device__ __forceinline__ int swz_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }   // bytes
 
-// Cache-policy experiments of the buffer-addressed kernels (tools/native `make exp`; the shipped library defines neither macro):
-//   DDPO_A_CPOL   modifier string of the ACTIVATION LDS-DMA loads (" nt": streaming hint, the activation tile is read once per column tile)
-//   DDPO_OUT_NT   1: fp32 outputs leave with nontemporal stores; 2: the bf16 plane outputs too
-#ifndef DDPO_A_CPOL
-#define DDPO_A_CPOL ""
-#endif
-typedef float f32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void st_out4(float* p, const float4 v) {
-#ifdef DDPO_OUT_NT
-  f32x4_t t = {v.x, v.y, v.z, v.w};
-  __builtin_nontemporal_store(t, reinterpret_cast<f32x4_t*>(p));
-#else
   *reinterpret_cast<float4*>(p) = v;
-#endif
 }
 
 // plane-emitting output stage: 4 consecutive output values -> 4 bf16 hi + 4 bf16 lo (the split the fp32-fed loader would apply)
@@ -108,39 +96,9 @@ __device__ __forceinline__ void store_planes4(const ddpo_gemm_desc& d, int64_t r
   uint2 h, l;
   split4(v, h, l);
   const int64_t o = plane_off(row, col, d.ld_planes, d.M);           // ld_planes == 0: k-blocked planes (ncols / 32, M, 32)
-#if defined(DDPO_OUT_NT) && DDPO_OUT_NT >= 2
-  typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
-  u32x2_t th = {h.x, h.y}, tl = {l.x, l.y};
-  __builtin_nontemporal_store(th, reinterpret_cast<u32x2_t*>(d.out_hi + o));
-  __builtin_nontemporal_store(tl, reinterpret_cast<u32x2_t*>(d.out_lo + o));
-#else
   *reinterpret_cast<uint2*>(d.out_hi + o) = h;
   *reinterpret_cast<uint2*>(d.out_lo + o) = l;
-#endif
 }
-
-// -DDDPO_EXP_EPI_SGPR (experiment build only, tools/native/build_variant_lib.sh; NOT validated on hardware): the descriptor is a by-value kernel
-// argument, and under the SGPR pressure of these kernels the compiler re-MATERIALISES its fields from the kernarg segment wherever they are used —
-// in the emit phase of the output stage five to six `s_load_dword(x2)` + `s_waitcnt lgkmcnt(0)` per iteration (out, out_hi, out_lo, ld_planes,
-// planes_fmt, ld_out: ISA of the tall tile, round 4), i.e. scalar-cache round trips on the critical path of every one of the 16-40 iterations
-// of every tile.  The experiment's emit works on local copies laundered through an empty asm: opaque values that have to stay in registers (an
-// SGPR, or a VGPR lane: one v_readlane).  A register-allocation hint only — the arithmetic cannot change; the shipped build's code is untouched
-// (everything below sits under the macro).
-#ifdef DDPO_EXP_EPI_SGPR
-#define EPI_PIN(x) asm volatile("" : "+s"(x))
-__device__ __forceinline__ void store_planes4_pinned(uint16_t* __restrict__ out_hi, uint16_t* __restrict__ out_lo, int ld_planes, int planes_fmt, int M,
-                                                     int64_t row, int col, const float4 v) {
-  if (planes_fmt == 1) {
-    mx_store4(out_hi, out_lo, row, col, ld_planes, M, v);
-    return;
-  }
-  uint2 h, l;
-  split4(v, h, l);
-  const int64_t o = plane_off(row, col, ld_planes, M);
-  *reinterpret_cast<uint2*>(out_hi + o) = h;
-  *reinterpret_cast<uint2*>(out_lo + o) = l;
-}
-#endif
 
 // Vector output stage of the buffer-addressed kernels: one wave moves NIT x 64 float4 of its sub-tile (rows of WTN columns, LPR = WTN / 4
 // float4 per row) from its LDS slice `cw` to the output, 512 B .. 1 KiB contiguous per row.  Round 4: TWO PHASES.  The first form of this
@@ -220,31 +178,6 @@ struct EpiRows {
   }
   // LDS -> fp32 rows and / or planes
   __device__ __forceinline__ static void emit(const ddpo_gemm_desc& d, const float* cw, int row_base, int col_base, int lane) {
-#ifdef DDPO_EXP_EPI_SGPR
-    float* out = d.out;
-    uint16_t *out_hi = d.out_hi, *out_lo = d.out_lo;
-    int ld_out = d.ld_out, ld_planes = d.ld_planes, planes_fmt = d.planes_fmt, M = d.M, N = d.N;
-    EPI_PIN(out); EPI_PIN(out_hi); EPI_PIN(out_lo); EPI_PIN(ld_out); EPI_PIN(ld_planes); EPI_PIN(planes_fmt); EPI_PIN(M); EPI_PIN(N);
-#pragma unroll
-    for (int b0 = 0; b0 < NIT; b0 += LB) {
-      asm volatile("" : "+v"(lane));
-      float4 v[LB];
-#pragma unroll
-      for (int i = 0; i < LB; ++i) {
-        const int e = (b0 + i) * 64 + lane, rr = e / LPR;
-        v[i] = *reinterpret_cast<const float4*>(cw + rr * WTN + (e - rr * LPR) * 4);
-      }
-#pragma unroll
-      for (int i = 0; i < LB; ++i) {
-        const int e = (b0 + i) * 64 + lane, rr = e / LPR;
-        const int row = row_base + rr, col = col_base + (e - rr * LPR) * 4;
-        if (row >= M || col >= N) continue;
-        if (out) st_out4(out + (int64_t)row * ld_out + col, v[i]);
-        if (out_hi) store_planes4_pinned(out_hi, out_lo, ld_planes, planes_fmt, M, row, col, v[i]);
-      }
-    }
-    return;
-#endif
 #pragma unroll
     for (int b0 = 0; b0 < NIT; b0 += LB) {
       asm volatile("" : "+v"(lane));
@@ -787,7 +720,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 64 ? 3 : 1)) g
       const uint32_t la = lds_a + stage * STAGE, lw = lds_w + stage * STAGE;
 #pragma unroll
       for (int i = 0; i < NA; ++i)
-        asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen" DDPO_A_CPOL " lds"
+        asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                      :: "s"(la + i * (PAIRS * 1024)), "v"(avoff[i]), "s"(rs_a), "s"(so_a) : "memory");
 #pragma unroll
       for (int i = 0; i < NB; ++i)
@@ -878,7 +811,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 64 ? 3 : 1)) g
         const uint32_t so_a = (uint32_t)(cib >> 5) * a_kt_b, la = lds_a3 + stage * A_STAGE;
 #pragma unroll
         for (int i = 0; i < NA; ++i)
-          asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen" DDPO_A_CPOL " lds"
+          asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                        :: "s"(la + i * (PAIRS * 1024)), "v"(avoff[i]), "s"(rs_a), "s"(so_a) : "memory");
         cib += BK;
         if (cib >= cin) {

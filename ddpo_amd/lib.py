@@ -743,11 +743,15 @@ def _dgrad_fwd(dy, dg, *, M, conv=None, residual=None, ld_res=None, out=None):
     lim = 0x7FFFFFFF
     if conv is None and rows * cin * 4 >= lim and not isinstance(dy, Planes):
         # a dense dY of >= 2 GiB (FF1's (M, 8C) gradient at training batch sizes) would leave the buffer-addressed kernels: run it in row chunks
-        n = -(-rows * cin * 4 // (lim - 4 * cin))
-        step = (-(-rows // n) + 255) // 256 * 256
-        out = torch.empty(M, Nd, dtype=torch.float32, device=dy.device)
+        # (the chunk is rounded DOWN to whole 256-row tiles so that it stays below the limit and can never re-enter this branch)
+        step = (lim - 1) // (cin * 4) // 256 * 256
+        if step <= 0:
+            raise DdpoHipError(f"_dgrad_fwd: one 256-row chunk of a {cin}-wide dY does not fit the buffer-addressed kernels")
+        if out is None:
+            out = torch.empty(M, Nd, dtype=torch.float32, device=dy.device)
         for r0 in range(0, rows, step):
             r1 = min(rows, r0 + step)
+            assert (r1 - r0) * cin * 4 < lim
             _dgrad_fwd(dy[r0:r1], dg, M=r1 - r0, residual=None if residual is None else residual[r0:r1], ld_res=ld_res, out=out[r0:r1])
         return out
     buf_ok = cin % 32 == 0 and rows * cin * 4 < lim and Nd * ((Kd + 31) // 32 * 32) * 2 < lim
@@ -1051,6 +1055,8 @@ def attention_kv_images(k, v, B, heads, Nk, d, out=None, ldk=None, ldv=None):
     stay constant over many attention calls (the text context over the DDIM steps).  Returns None where the datapath / head dim has no
     image kernel (the caller keeps k, v)."""
     if current_datapath() == "fp32" or d not in (8, 16, 40, 64, 80):
+        if out is not None:
+            out._ddpo_kv_fmt = None          # a buffer packed earlier under another datapath no longer matches k, v
         return None
     C = heads * d
     nb = int(load().ddpo_attention_kv_images_bytes(B, heads, Nk, d))
@@ -1058,13 +1064,31 @@ def attention_kv_images(k, v, B, heads, Nk, d, out=None, ldk=None, ldv=None):
         out = torch.empty(nb, dtype=torch.uint8, device=k.device)
     fn, name = (load().ddpo_attention_pack_kv_f16p, "ddpo_attention_pack_kv_f16p") if _mx() else (load().ddpo_attention_pack_kv_bf16x3, "ddpo_attention_pack_kv_bf16x3")
     _check(fn(_p(k), int(ldk or C), _p(v), int(ldv or C), _p(out), out.numel(), B, heads, Nk, d, _stream()), name)
+    out._ddpo_kv_fmt = kv_images_fmt()       # the two packings have the same size and incompatible contents: the images carry their format
     return out
+
+
+def kv_images_fmt():
+    """Packing of attention_kv_images() under the current datapath: "f16p" (f16mx datapath: V as f16 hi / lo with a row of ones), "bf16x3"
+    (bf16 hi / lo), or None on the fp32 datapath (no image kernels)."""
+    if current_datapath() == "fp32":
+        return None
+    return "f16p" if _mx() else "bf16x3"
+
+
+def kv_images_valid(images):
+    """True when `images` were packed by attention_kv_images() under the packing the CURRENT datapath's kernels read."""
+    fmt = kv_images_fmt()
+    return images is not None and fmt is not None and getattr(images, "_ddpo_kv_fmt", None) == fmt
 
 
 def attention_from_images(q, images, B, heads, Nq, Nk, d, scale=None, out=None, ldq=None, ldo=None, return_lse=False, planes_out=False):
     """softmax(q k^T * scale) v with k, v given as attention_kv_images() — packed under the SAME datapath (the f16mx datapath's images hold V as
     f16 hi / lo with a row of ones, the bf16x3 datapath's as bf16 hi / lo).  planes_out: as in attention()."""
     C = heads * d
+    if not kv_images_valid(images):
+        raise DdpoHipError(f"attention_from_images: images packed as {getattr(images, '_ddpo_kv_fmt', None)!r}, the current datapath "
+                           f"({current_datapath()}) reads {kv_images_fmt()!r} — repack with attention_kv_images()")
     if planes_out:
         if out is not None or return_lse:
             raise DdpoHipError("plane-emitting attention writes planes only")

@@ -313,7 +313,7 @@ class UNet2DCondition:
         cached = self._ctx_kv.get((name, ctx.shape[0])) if (ctx is not None and rec is None and self._ctx_kv_active) else None
         if cached is not None:                     # text-context K / V were projected once for this sampling call
             k, v = cached[0], cached[1]
-            if len(cached) > 2 and cached[2] is not None:      # ... and packed once into the attention kernels' K / V^T images
+            if len(cached) > 2 and L.kv_images_valid(cached[2]):      # ... and packed once into the attention kernels' K / V^T images (under THIS datapath)
                 return L.attention_from_images(q, cached[2], B, heads, N, ctx_len, C // heads, planes_out=po)
         else:
             kv_src = x if ctx is None else ctx
@@ -636,13 +636,16 @@ class UNet2DCondition:
             wk, wv = self.params[name + ".to_k.kernel"], self.params[name + ".to_v.kernel"]
             ent = self._ctx_kv.get((name, B * Lc))
             heads = self._heads_of(name)
+            nb = 0
+            if L.current_datapath() != "fp32" and (wk.shape[1] // heads) in (8, 16, 40, 64, 80) and os.environ.get("DDPO_CTX_IMAGES", "1") != "0":
+                nb = int(L.load().ddpo_attention_kv_images_bytes(B, heads, Lc, wk.shape[1] // heads))
             if ent is None:
                 kbuf = torch.empty(B * Lc, wk.shape[1], dtype=torch.float32, device=self.device)
                 vbuf = torch.empty(B * Lc, wv.shape[1], dtype=torch.float32, device=self.device)
-                nb = 0
-                if L.current_datapath() != "fp32" and (wk.shape[1] // heads) in (8, 16, 40, 64, 80) and os.environ.get("DDPO_CTX_IMAGES", "1") != "0":
-                    nb = int(L.load().ddpo_attention_kv_images_bytes(B, heads, Lc, wk.shape[1] // heads))
                 ent = (kbuf, vbuf, torch.empty(nb, dtype=torch.uint8, device=self.device) if nb else None)
+                self._ctx_kv[(name, B * Lc)] = ent
+            elif ent[2] is None and nb:            # first projected on the fp32 datapath (no image kernels): the image buffer is added now
+                ent = (ent[0], ent[1], torch.empty(nb, dtype=torch.uint8, device=self.device))
                 self._ctx_kv[(name, B * Lc)] = ent
             L.linear(ctx, wk, out=ent[0])
             L.linear(ctx, wv, out=ent[1])

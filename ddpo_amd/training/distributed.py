@@ -82,6 +82,15 @@ def allgather_strings(strings):
     return [s for part in out for s in part]
 
 
+def broadcast_object(obj, src=0):
+    """Rank `src`'s (picklable) object on every rank; the object itself without a process group."""
+    if not _through_backend():
+        return obj
+    box = [obj]
+    dist.broadcast_object_list(box, src=src)
+    return box[0]
+
+
 def pmean_info(info):
     """Mean over ranks of a dict of scalars (device tensors or floats) with ONE small all-reduce."""
     keys = sorted(info)

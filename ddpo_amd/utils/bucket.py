@@ -91,15 +91,17 @@ def decode_jpeg(buf):
 
 # ------------------------------------------------------------------------------------------------ writer / reader
 class LocalWriter:
-    """add_batch(batch, mask) appends the masked rows field by field; every `split_size` rows a shard `<rank>_<i>.npz` is closed."""
+    """add_batch(batch, mask) appends the masked rows field by field; every `split_size` rows a shard `<rank>_<run_id>_<i>.npz` is closed.
 
-    def __init__(self, savepath, split_size=1000, rank=0):
+    Nothing that exists in `savepath` is touched before close(): shard names carry the run id (the reference's RemoteWriter uses timestamped
+    names and never deletes), close() replaces this rank's manifest atomically and only THEN removes this rank's shards the new manifest does
+    not list — a sampling run that crashes, or was started by mistake, leaves the previous dataset readable.  `run_id` must be the same on
+    every rank of one sampling run (pipeline/sample.py broadcasts rank 0's); LocalReader refuses manifests whose ids differ."""
+
+    def __init__(self, savepath, split_size=1000, rank=0, run_id=None):
         self.savepath, self.split_size, self.rank = savepath, int(split_size), int(rank)
+        self.run_id = str(run_id) if run_id is not None else new_run_id()
         os.makedirs(savepath, exist_ok=True)
-        # shards of an EARLIER run of this rank into the same directory (fewer shards now, another split_size) must not survive next to the
-        # new ones; other ranks' files are theirs to clean.  The manifest written by close() is what LocalReader trusts.
-        for stale in glob.glob(os.path.join(savepath, f"{self.rank}_*.npz")) + glob.glob(os.path.join(savepath, f"manifest_{self.rank}.json")):
-            os.remove(stale)
         self._encode, self._rows, self._shard, self._total = {}, [], 0, 0
         self._files = []
 
@@ -134,20 +136,35 @@ class LocalWriter:
             arr = np.empty(len(vals), dtype=object)
             arr[:] = vals
             cols[k] = arr
-        name = f"{self.rank}_{self._shard:05d}.npz"
+        name = f"{self.rank}_{self.run_id}_{self._shard:05d}.npz"
         np.savez(os.path.join(self.savepath, name), **cols)
         self._files.append({"file": name, "rows": len(self._rows)})
         self._rows, self._shard = [], self._shard + 1
 
     def close(self, metadata=None, world=1):
-        """Flush, write this rank's manifest (its shard files and row counts; `world` = number of ranks writing into this directory) and, on
-        rank 0, metadata.json."""
+        """Flush, replace this rank's manifest (its shard files and row counts, the run id; `world` = number of ranks writing into this
+        directory) atomically, remove this rank's shards of earlier runs (those the new manifest does not list) and, on rank 0, write
+        metadata.json."""
         self._flush()
-        with open(os.path.join(self.savepath, f"manifest_{self.rank}.json"), "w") as f:
-            json.dump({"rank": self.rank, "world": int(world), "n_samples": self._total, "shards": self._files}, f, indent=2)
+        path = os.path.join(self.savepath, f"manifest_{self.rank}.json")
+        with open(path + ".tmp", "w") as f:
+            json.dump({"rank": self.rank, "world": int(world), "run_id": self.run_id, "n_samples": self._total, "shards": self._files}, f, indent=2)
+        os.replace(path + ".tmp", path)
+        keep = {sh["file"] for sh in self._files}
+        for old in glob.glob(os.path.join(self.savepath, f"{self.rank}_*.npz")):
+            if os.path.basename(old) not in keep:
+                os.remove(old)
         if metadata is not None and self.rank == 0:
-            with open(os.path.join(self.savepath, "metadata.json"), "w") as f:
+            with open(os.path.join(self.savepath, "metadata.json.tmp"), "w") as f:
                 json.dump(metadata, f, indent=2, default=str)
+            os.replace(os.path.join(self.savepath, "metadata.json.tmp"), os.path.join(self.savepath, "metadata.json"))
+
+
+def new_run_id():
+    """Identifier of one sampling run (timestamp + random suffix): part of every shard name and manifest of the run."""
+    import time
+    import uuid
+    return time.strftime("%Y%m%d-%H%M%S") + "-" + uuid.uuid4().hex[:8]
 
 
 class LocalReader:
@@ -165,6 +182,11 @@ class LocalReader:
             ranks = sorted(int(m["rank"]) for m in metas if int(m["rank"]) < world)
             if ranks != list(range(world)):
                 raise FileNotFoundError(f"'{loadpath}': manifests of ranks {ranks} found, the sampling run had {world} ranks")
+            # every rank of ONE run carries the same run id: a stale rank-0 manifest next to newer shards of the other ranks (or the other way
+            # round: a run that died before every rank closed) is refused instead of being read as a mixture of two runs
+            ids = {int(m["rank"]): m.get("run_id") for m in metas if int(m["rank"]) < world}
+            if len(set(ids.values())) != 1:
+                raise FileNotFoundError(f"'{loadpath}': the ranks' manifests belong to different sampling runs (run ids {ids})")
             files = [os.path.join(loadpath, sh["file"]) for m in sorted(metas, key=lambda m: int(m["rank"])) if int(m["rank"]) < world for sh in m["shards"]]
             missing = [f for f in files if not os.path.exists(f)]
             if missing:

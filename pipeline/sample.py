@@ -62,7 +62,8 @@ def main(argv=None):
 
     # ----------------------------------- bucket -----------------------------------#
     savepath = args.savepath.replace("gs://", "logs/")
-    writer = bucket.LocalWriter(savepath, split_size=args.local_size, rank=worker_id)
+    run_id = D.broadcast_object(bucket.new_run_id())          # one id per sampling run: rank 0's, in every rank's shard names and manifest
+    writer = bucket.LocalWriter(savepath, split_size=args.local_size, rank=worker_id, run_id=run_id)
     writer.configure("images", encode_fn=encode_jpeg, decode_fn=bucket.decode_jpeg)
     writer.configure("inference_prompts")
     writer.configure("training_prompts")

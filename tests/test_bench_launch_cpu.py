@@ -49,3 +49,34 @@ def test_world_size_must_match_gpus():
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--mode", "comm", "--backend", "gloo"], capture_output=True, text=True,
                        env=_env(WORLD_SIZE="4", RANK="0", LOCAL_RANK="0"), timeout=120)
     assert r.returncode != 0 and "must agree" in (r.stderr + r.stdout)
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("mode", ["sample", "epoch", "train"])
+def test_eight_rank_launch_rehearsal_builds_the_rank_environment_and_the_json_line(mode):
+    """the 8-GPU commands the driver will run (`bench.py --gpus 8`, `--mode epoch`, `--mode train`) rehearsed on CPU:
+    `--dry-run --backend gloo` self-launches 8 ranks through torch.distributed.run exactly like the real run, builds the process group,
+    derives one sampling key per rank from the reference key tree (pairwise distinct), runs barrier / max-over-ranks and the gradient
+    all-reduce, and rank 0 prints the mode's JSON line with `rccl_ranks` filled — value null and `dry_run: true`, because no engine
+    work runs and nothing is measured."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--mode", mode, "--backend", "gloo", "--dry-run", "--comm-mib", "1",
+                        "--steps", "2", "--warmup", "1"], capture_output=True, text=True, env=_env(), timeout=580)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["dry_run"] is True and d["value"] is None and d["ms_per_step"] is None
+    assert d["n_gpus"] == 8 and d["rccl_ranks"] == 8 and d["config"]["parallelism"] == "dp8" and d["scaling"] == "weak"
+    assert d["allreduce"]["ranks"] == 8 and d["allreduce"]["sum_correct"] is True
+    for k in ("metric", "unit", "steps", "warmup", "higher_is_better", "vs_baseline", "dtype", "data", "config"):
+        assert k in d
+    if mode == "sample":
+        assert d["metric"] == "sampled images/sec (512^2, 50 DDIM steps)" and d["config"]["global_batch"] == 64
+        assert "BASELINE configs[1]" in d["config"]["workload"] and "roofline" in d and "cpu_baseline" in d
+    if mode == "epoch":
+        assert d["config"]["global_batch"] == 64 and "4 optimizer updates" in d["config"]["workload"]
+
+
+def test_dry_run_is_refused_without_the_cpu_backend():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-run"], capture_output=True, text=True, env=_env(), timeout=120)
+    assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -121,3 +121,31 @@ def test_output_stage_emits_f16mx_planes_of_the_result():
     out, (p16, p8) = L.gemm_conv_f16mx(L.split_planes_f16mx(x), L.pack_weights_f16mx(w), M=M, planes_out=True)
     q16, q8 = L.split_planes_f16mx(out)
     assert torch.equal(p16, q16) and torch.equal(p8, q8)
+
+
+def test_operands_beyond_the_f16_range_saturate_instead_of_overflowing():
+    """every f16 split of the f16mx datapath (activation planes: common.h mx_split4; the attention's V / dO / K / Q images:
+    split2h in attention_bf16.hip / attention_bwd_bf16.hip) clamps to +-65504 (60000 in the backward) before the conversion, so an
+    activation beyond the f16 range degrades to a saturated value — never to inf, and never to the NaN an inf - inf low part would be."""
+    old = L.DATAPATH
+    L.DATAPATH = "f16mx"
+    try:
+        x = torch.tensor([[7.0e4, -3.0e5, 65504.0, 1.0e30] * 8], device="cuda").repeat(16, 1).contiguous()       # (16, 32)
+        p16, p8 = L.split_planes_f16mx(x)
+        h = p16.view(torch.float16).float()
+        assert torch.isfinite(h).all() and float(h.abs().max()) == 65504.0
+        assert torch.isfinite(p8.view(torch.float8_e5m2).float()).all()
+        torch.manual_seed(3)
+        B, heads, Nq, Nk, d = 1, 2, 64, 96, 40
+        q = torch.randn(B * Nq, heads * d, device="cuda")
+        k = torch.randn(B * Nk, heads * d, device="cuda")
+        v = torch.randn(B * Nk, heads * d, device="cuda")
+        v[::7] *= 1.0e6                                                   # far beyond the f16 range
+        out = L.attention(q, k, v, B, heads, Nq, Nk, d)
+        assert torch.isfinite(out).all()
+        ref = torch.softmax((q.view(Nq, heads, d).transpose(0, 1) @ k.view(Nk, heads, d).transpose(0, 1).transpose(1, 2)) * d ** -0.5, -1) @ \
+            v.clamp(-65504.0, 65504.0).view(Nk, heads, d).transpose(0, 1)
+        ref = ref.transpose(0, 1).reshape(Nq, heads * d)
+        assert float((out - ref).abs().max() / ref.abs().max()) < 1e-3   # = the attention of the SATURATED values
+    finally:
+        L.DATAPATH = old

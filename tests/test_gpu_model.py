@@ -94,6 +94,42 @@ def test_sampler_matches_oracle_config1(tiny):
     assert np.abs(img - oimg).max() < 5e-3
 
 
+@pytest.mark.parametrize("datapath", [SHIPPED] + (["fp32"] if __import__("os").environ.get("DDPO_TRAJ_FP32") == "1" else []))
+def test_sampler_50_steps_matches_oracle(tiny, datapath):
+    """The reference's scan length (num_inference_steps 50, /root/reference/ddpo/diffusers_patch/pipeline_flax_stable_diffusion.py:204-270,
+    config/base.py) on the toy net: the whole stochastic trajectory, every step's log-prob and the final latents against the oracle
+    — error compounding over the full 50 steps on the shipped datapath, graph path (DDPO_TRAJ_FP32=1 adds the exact-fp32 datapath;
+    measured round 5, profiles/r05_parity_trajectory_50_steps.log: fp32 2e-6 flat, f16mx 3.6e-5 at step 1 -> 6.6e-5 at step 50, log-probs 1.2e-7)."""
+    op, unet, _, _ = tiny
+    old = L.DATAPATH
+    L.DATAPATH = datapath
+    try:
+        if datapath != "fp32":
+            unet.params.pack_bf16(bwd=False)
+        sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", set_alpha_to_one=False, steps_offset=1)
+        pipe = StableDiffusionPipeline(unet, None, sched)
+        state = sched.create_state(device=DEV)
+        g = torch.Generator().manual_seed(13)
+        emb = torch.randn(2, 77, 64, generator=g)
+        neg = torch.randn(1, 77, 64, generator=g).expand(2, -1, -1).contiguous()
+        key = OP.PRNGKey(5)
+        T = 50
+        final, lat, nxt, lps, ts = pipe(emb.to(DEV), neg.to(DEV), {"unet": unet.params, "scheduler": state}, key, T,
+                                        height=128, width=128, guidance_scale=5.0, eta=1.0, jit=True)
+        dd = DDIMOracle()
+        ofinal, olat, onxt, olps, ots = oracle_sample(op, OU.TINY, dd, dd.create_state(), emb, neg, key, T, 128, 128, 5.0, 1.0)
+        assert np.array_equal(ts.cpu().numpy(), ots)
+        e_step = [_rel(nxt[:, i].cpu().numpy(), onxt[:, i]) for i in range(T)]
+        e_lp = float(np.abs(lps.cpu().numpy() - olps).max() / np.abs(olps).max())
+        from conftest import parity_record
+        parity_record(f"[tiny sampler, 50 steps, graph path] {datapath}: latent rel err at steps 1/10/25/50 "
+                      f"{e_step[0]:.1e} {e_step[9]:.1e} {e_step[24]:.1e} {e_step[49]:.1e} (max {max(e_step):.1e})  log-probs rel {e_lp:.1e}")
+        assert max(e_step) < 1e-3 and e_lp < 1e-3 and _rel(final.cpu().numpy(), ofinal) < 1e-3
+    finally:
+        L.DATAPATH = old
+        L.PACKED.clear()
+
+
 def test_time_projection_table_is_bit_identical_to_per_step_time_path(tiny, monkeypatch):
     """precompute_timesteps / select_timestep: the sampler runs the time path (embedding MLP + every ResBlock's time_emb_proj) once
     per call for all T steps; trajectories and log-probs must not change by a bit, eagerly and under HIP-graph replay."""

@@ -25,7 +25,7 @@ pytestmark = pytest.mark.gpu
 from ddpo_amd import lib as L
 from ddpo_amd.models.unet import UNet2DCondition, UNetConfig
 from ddpo_amd.diffusers_patch.scheduling_ddim import DDIMScheduler
-from ddpo_amd.training.policy_gradient import AccumulatingTrainState, AdamWConfig, train_step
+from ddpo_amd.training.policy_gradient import AccumulatingTrainState, AdamWConfig, train_step, train_steps_fused
 from oracle import ppo as OPPO, prng as OP, unet as OU
 from oracle.ddim import DDIMOracle
 
@@ -38,8 +38,10 @@ SHIPPED = os.environ.get("DDPO_PARITY_DATAPATH") or L.SHIPPED_DATAPATH
 LP_BUDGET = {"fp32": 2e-5, "bf16x3": 2e-5, "f16mx": 5e-5}
 
 
-def _oracle_step(op, cfg, dd, ost, lat, ts, emb, unc, adv, drift, guidance, eta, dtype):
-    """Oracle forward with autograd, a REAL transition sampled from it, the PPO loss on that transition, backward."""
+def _oracle_step(op, cfg, dd, ost, lat, ts, emb, unc, adv, drift, guidance, eta, dtype, fuse=1):
+    """Oracle forward with autograd, a REAL transition sampled from it, the PPO loss on that transition, backward.
+    fuse > 1: the rows are `fuse` consecutive micro-batches of b = rows / fuse samples that see the same parameters — each with its own mean
+    loss, gradients summed (the reference's AccumulatingTrainState over `fuse` train_step calls without an update in between)."""
     leaves = OrderedDict((k, v.detach().clone().to(dtype).requires_grad_(True)) for k, v in op.items())
     eps_c = OU.unet_forward(leaves, cfg, lat.to(dtype), ts, emb.to(dtype))
     eps_u = OU.unet_forward(leaves, cfg, lat.to(dtype), ts, unc.to(dtype))
@@ -51,10 +53,17 @@ def _oracle_step(op, cfg, dd, ost, lat, ts, emb, unc, adv, drift, guidance, eta,
         nxt.append(n_i); old.append(lp_i)
     batch = {"latents": lat, "next_latents": torch.from_numpy(np.concatenate(nxt)), "ts": ts,
              "log_probs": torch.from_numpy(np.concatenate(old)) + drift, "advantages": adv, "prompt_embeds": emb, "uncond_embeds": unc}
-    loss, info, logp = OPPO.loss_and_info_torch(dd, ost, eps_c, eps_u, batch, guidance, eta, CLIP, True, dtype)
-    loss.backward()
+    b = lat.shape[0] // fuse
+    total, infos, logps = 0.0, [], []
+    for j in range(fuse):
+        sl = slice(j * b, (j + 1) * b)
+        loss, info, logp = OPPO.loss_and_info_torch(dd, ost, eps_c[sl], eps_u[sl], {k: v[sl] for k, v in batch.items()}, guidance, eta, CLIP, True, dtype)
+        total = total + loss
+        infos.append({k: float(v.detach()) for k, v in info.items()}); logps.append(logp.detach())
+    total.backward()
     grads = OrderedDict((k, v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaves.items())
-    return batch, grads, {k: float(v.detach()) for k, v in info.items()}, logp.detach()
+    info = {k: float(np.mean([i[k] for i in infos])) for k in infos[0]}            # per-micro-batch infos, averaged for the comparison
+    return batch, grads, info, torch.cat(logps), infos
 
 
 def _groups(named):
@@ -64,7 +73,8 @@ def _groups(named):
     return OrderedDict((k, math.sqrt(sum(float((t.double() ** 2).sum()) for t in v))) for k, v in out.items())
 
 
-def _check(family, ocfg, pred, hw, b, ts, ctx_dim, T, datapath, dtype, seed):
+def _check(family, ocfg, pred, hw, b, ts, ctx_dim, T, datapath, dtype, seed, fuse=1):
+    """b samples per micro-batch; fuse > 1: `fuse` micro-batches (rows = b * fuse) through ONE train_steps_fused launch."""
     old = L.DATAPATH
     L.DATAPATH = datapath
     try:
@@ -74,22 +84,33 @@ def _check(family, ocfg, pred, hw, b, ts, ctx_dim, T, datapath, dtype, seed):
         if datapath != "fp32":
             unet.params.pack_bf16()
         g = torch.Generator().manual_seed(100 + seed)
-        lat = torch.randn(b, 4, hw, hw, generator=g)
-        emb = torch.randn(b, 77, ctx_dim, generator=g)
-        unc = torch.randn(1, 77, ctx_dim, generator=g).expand(b, -1, -1).contiguous()
+        n = b * fuse
+        lat = torch.randn(n, 4, hw, hw, generator=g)
+        emb = torch.randn(n, 77, ctx_dim, generator=g)
+        unc = torch.randn(1, 77, ctx_dim, generator=g).expand(n, -1, -1).contiguous()
         ts = torch.tensor(ts, dtype=torch.int32)
-        adv = torch.tensor([0.7, -1.1][:b])
-        drift = torch.tensor([3e-5, -2e-5][:b])          # |log p - log p_old| stays inside the 1e-4 clip range, as before the first update
+        assert ts.shape[0] == n
+        adv = torch.tensor([0.7, -1.1, 0.4, -0.3][:n])
+        drift = torch.tensor([3e-5, -2e-5, 1e-5, -3e-5][:n])          # |log p - log p_old| stays inside the 1e-4 clip range, as before the first update
         dd = DDIMOracle(prediction_type=pred)
         ost = dd.set_timesteps(dd.create_state(), T)
-        batch, ograds, oinfo, ologp = _oracle_step(op, ocfg, dd, ost, lat, ts, emb, unc, adv, drift, 5.0, 1.0, dtype)
+        batch, ograds, oinfo, ologp, oinfos = _oracle_step(op, ocfg, dd, ost, lat, ts, emb, unc, adv, drift, 5.0, 1.0, dtype, fuse)
         assert oinfo["clipfrac"] == 0.0 and abs(float(ologp.abs().max())) < 20.0        # a realistic transition: |log p| is O(1)
 
         sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", set_alpha_to_one=False, steps_offset=1,
                               prediction_type=pred)
         st = sched.set_timesteps(sched.create_state(device=DEV), T)
         state = AccumulatingTrainState(unet, AdamWConfig())
-        state, info = train_step(state, {k: v.to(DEV) for k, v in batch.items()}, st, sched, True, 5.0, 1.0, CLIP, do_opt_update=False, jit=False)
+        dbatch = {k: v.to(DEV) for k, v in batch.items()}
+        if fuse == 1:
+            state, info = train_step(state, dbatch, st, sched, True, 5.0, 1.0, CLIP, do_opt_update=False, jit=False)
+        else:
+            state, infos = train_steps_fused(state, [{k: v[j * b:(j + 1) * b].contiguous() for k, v in dbatch.items()} for j in range(fuse)],
+                                             st, sched, True, 5.0, 1.0, CLIP, do_opt_update=False, jit=False)
+            for j in range(fuse):                       # every micro-batch keeps its OWN mean loss
+                assert abs(float(infos[j]["loss"]) - oinfos[j]["loss"]) / (abs(oinfos[j]["loss"]) + 1e-30) < TOL, (j, float(infos[j]["loss"]), oinfos[j]["loss"])
+            info = {k: torch.stack([torch.as_tensor(i[k], dtype=torch.float32).reshape(()) for i in infos]).mean() for k in ("approx_kl", "clipfrac", "loss")}
+            info["log_prob"] = torch.cat([i["log_prob"] for i in infos])
         torch.cuda.synchronize()
 
         rel = lambda a, r: abs(a - r) / (abs(r) + 1e-30)
@@ -103,7 +124,7 @@ def _check(family, ocfg, pred, hw, b, ts, ctx_dim, T, datapath, dtype, seed):
         e_groups = {k: rel(gg[k], og[k]) for k in og}
         worst = max(e_groups, key=e_groups.get)
         from conftest import parity_record
-        parity_record(f"\n[train parity] {family} {datapath} hw={hw} b={b} clip={CLIP}: loss {e_loss:.2e}  log-prob abs {e_lp:.2e}  global grad-norm {rel(gn, gn_o):.2e}  "
+        parity_record(f"\n[train parity] {family} {datapath} hw={hw} b={b}{f' x {fuse} fused micro-steps' if fuse > 1 else ''} clip={CLIP}: loss {e_loss:.2e}  log-prob abs {e_lp:.2e}  global grad-norm {rel(gn, gn_o):.2e}  "
                       f"worst block norm {worst} {e_groups[worst]:.2e}  ||g-g_ref||/||g_ref|| {e_dir:.2e}  (|g_ref| = {gn_o:.3e})")
         assert float(info["clipfrac"]) == 0.0
         assert e_lp < LP_BUDGET[datapath]               # margin to the clip boundary (7e-5) is never in question
@@ -133,13 +154,18 @@ def test_train_step_at_the_reference_clip_range(family, ocfg, pred, ctx, datapat
     _check(family, ocfg, pred, hw=16, b=2, ts=[481, 21], ctx_dim=ctx, T=50, datapath=datapath, dtype=torch.float64, seed=3)
 
 
-@pytest.mark.timeout(1500)
+@pytest.mark.timeout(2400)
 def test_train_step_sd15_full_size_shipped_datapath():
-    """One SD-1.5 train_step at 64x64 latents (512^2 px), b = 1, train_cfg: 2 forwards + 2 backwards of the 860 M-parameter U-Net on
-    the shipped kernels (f16mx on the long reductions; 128x320 / 128x128 tiles, split-K, 4096^2 d=40 attention forward + backward, atomics-accumulated wgrad)
-    against the float64 oracle (DDPO_PARITY_F32=1 uses an fp32 oracle: half the host time, 1e-6 of noise)."""
-    dtype = torch.float32 if os.environ.get("DDPO_PARITY_F32") == "1" else torch.float64
-    _check("sd15", OU.SD15, "epsilon", hw=64, b=1, ts=[481], ctx_dim=768, T=50, datapath=SHIPPED, dtype=dtype, seed=0)
+    """SD-1.5 train_step at 64x64 latents (512^2 px) at the REFERENCE'S micro-batch — `train.batch_size = 2` per device, train_cfg
+    (/root/reference/config/base.py:61-102): 2 forwards + 2 backwards of the 860 M-parameter U-Net over a U-Net batch of 4
+    on the shipped kernels (f16mx on the long reductions; 128x320 / 128x128 tiles, split-K, 4096^2 d=40 attention forward + backward,
+    atomics-accumulated wgrad) against the oracle in fp32 (1e-6 of noise against the 1e-3 gates; DDPO_PARITY_F64=1: float64, twice the
+    host time).  DDPO_TRAIN_PARITY_FUSE=k (default 1) runs k such micro-batches through ONE train_steps_fused launch — the shape class
+    bench.py's train line times — against the oracle's k accumulated steps (k x the host time; run once per round for the record,
+    profiles/r05_parity_margins.log)."""
+    dtype = torch.float64 if os.environ.get("DDPO_PARITY_F64") == "1" else torch.float32
+    fuse = int(os.environ.get("DDPO_TRAIN_PARITY_FUSE", "1"))
+    _check("sd15", OU.SD15, "epsilon", hw=64, b=2, ts=[481, 21, 961, 241][:2 * fuse], ctx_dim=768, T=50, datapath=SHIPPED, dtype=dtype, seed=0, fuse=fuse)
 
 
 @pytest.mark.timeout(1500)

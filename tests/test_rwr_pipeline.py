@@ -21,13 +21,13 @@ def _rows(n, seed=0):
 
 def test_local_writer_reader_round_trip_and_masking(tmp_path):
     from ddpo_amd.training.callbacks import encode_jpeg
-    w = bucket.LocalWriter(str(tmp_path), split_size=5)
+    w = bucket.LocalWriter(str(tmp_path), split_size=5, run_id="r")
     w.configure("images", encode_fn=encode_jpeg, decode_fn=bucket.decode_jpeg)
     b1, b2 = _rows(6, 1), _rows(4, 2)
     mask = np.array([1, 0, 1, 1, 0, 1], dtype=bool)
     assert w.add_batch(b1, mask=mask[:, None]) == 4 and w.add_batch(b2) == 4 and len(w) == 8
     w.close(metadata={"guidance_scale": 5.0})
-    assert sorted(f for f in os.listdir(tmp_path) if f.endswith(".npz")) == ["0_00000.npz", "0_00001.npz"]
+    assert sorted(f for f in os.listdir(tmp_path) if f.endswith(".npz")) == ["0_r_00000.npz", "0_r_00001.npz"]
     assert json.load(open(tmp_path / "metadata.json"))["guidance_scale"] == 5.0
     rd = bucket.LocalReader(str(tmp_path))
     assert len(rd) == 8
@@ -45,27 +45,33 @@ def test_rerun_into_the_same_directory_does_not_mix_stale_shards(tmp_path):
     run's shards in the RWR training set.  A writer removes ITS rank's old shards; the reader reads what the manifests list, and only the
     ranks of the run that wrote last (manifest `world`)."""
     for rank in (0, 1):                                   # first run: two ranks, three shards each
-        w = bucket.LocalWriter(str(tmp_path), split_size=2, rank=rank)
+        w = bucket.LocalWriter(str(tmp_path), split_size=2, rank=rank, run_id="run-a")
         w.add_batch(_rows(6, 10 + rank))
         w.close(metadata={"guidance_scale": 5.0}, world=2)
     assert len(bucket.LocalReader(str(tmp_path))) == 12
-    w = bucket.LocalWriter(str(tmp_path), split_size=4, rank=0)      # second run: one rank, one shard
+    w = bucket.LocalWriter(str(tmp_path), split_size=4, rank=0, run_id="run-b")      # second run: one rank, one shard
     b = _rows(3, 99)
     w.add_batch(b)
+    # ADVICE r04: nothing of the previous dataset is touched before close() — a run that crashes here (or was started by mistake) leaves it readable
+    assert len(bucket.LocalReader(str(tmp_path))) == 12
     w.close(metadata={"guidance_scale": 5.0}, world=1)
-    assert sorted(f for f in os.listdir(tmp_path) if f.startswith("0_")) == ["0_00000.npz"]          # rank 0's old shards are gone
+    assert sorted(f for f in os.listdir(tmp_path) if f.startswith("0_")) == ["0_run-b_00000.npz"]    # rank 0's old shards are gone, after close()
     rd = bucket.LocalReader(str(tmp_path))                                                            # rank 1's stale shards are ignored
     assert len(rd) == 3 and [rd[i]["inference_prompts"] for i in range(3)] == list(b["inference_prompts"])
-    os.remove(tmp_path / "0_00000.npz")
+    os.remove(tmp_path / "0_run-b_00000.npz")
     with pytest.raises(FileNotFoundError):
         bucket.LocalReader(str(tmp_path))
     # a run whose rank-1 manifest is missing is refused rather than silently halved
-    w = bucket.LocalWriter(str(tmp_path), split_size=4, rank=0)
+    w = bucket.LocalWriter(str(tmp_path), split_size=4, rank=0, run_id="run-c")
     w.add_batch(b)
     w.close(world=2)
+    with pytest.raises(FileNotFoundError, match="different sampling runs"):      # rank 1's manifest is run-a's: a mixture of two runs is refused
+        bucket.LocalReader(str(tmp_path))
     os.remove(tmp_path / "manifest_1.json")
     with pytest.raises(FileNotFoundError):
         bucket.LocalReader(str(tmp_path))
+    # writers without an explicit id get distinct ones (timestamp + random suffix), so two independent single-rank runs never collide
+    assert bucket.LocalWriter(str(tmp_path)).run_id != bucket.LocalWriter(str(tmp_path)).run_id
 
 
 def test_maskers_and_dataset_weights(tmp_path):

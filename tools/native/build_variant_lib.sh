@@ -1,6 +1,6 @@
 #!/bin/bash
-# Private build of the whole library with extra compiler flags (build-time experiment macros of csrc/: -DDDPO_EXP_DPP_REDUCE, -DDDPO_OUT_NT=1,
-# -DDDPO_A_CPOL='" nt"' ...), for tools/ab_bench.sh:
+# Private build of the whole library with extra compiler flags, for tools/ab_bench.sh (how a candidate change is put through the parity tests and
+# an interleaved A/B before it becomes the code; round 5's rule: csrc/ carries no experiment macros between rounds — a candidate lands or is deleted):
 #   bash tools/native/build_variant_lib.sh <tag> <flags...>     ->   tools/native/libddpo_hip_<tag>.so
 set -e
 TAG=$1; shift || { echo "usage: build_variant_lib.sh <tag> <flags...>"; exit 64; }

@@ -13,8 +13,7 @@
 //                                               planes, accuracy against fp64
 //   kernel_probe wgrad [batch=16] [iters=10]    bf16x3 weight gradients: wide 128x320 tile vs the 128x128 kernel, fp32 and plane operands
 //   kernel_probe attn [batch=16] [iters=10]     bf16x3 / fp32 flash-attention shapes of the same forward
-//   kernel_probe gelu                           gelu(tanh): libm tanhf form vs the v_exp / v_rcp sigmoid form of -DDDPO_EXP_FAST_GELU against float64, and their VALU cost
-//   kernel_probe reduce                         wave butterfly: ds_bpermute form vs the DPP / lane-swap form of -DDDPO_EXP_DPP_REDUCE, bit for bit + latency
+//   kernel_probe gelu                           gelu(tanh): libm tanhf form vs the v_exp / v_rcp sigmoid form of csrc/common.h (shipped since round 5) against float64, and their VALU cost
 //   kernel_probe stream                         plain copy of 21 ... 336 MB: what the memory system gives the bytes of a short-reduction layer
 //   kernel_probe ppo                            scoring-mode log-prob + PPO-clip + grouped micro-batches vs a host loop
 //
@@ -796,128 +795,8 @@ static int probe_stream() {
   return 0;
 }
 
-// ------------------------------------------------------------------------------------------------ wave reduction forms
-// The shipped butterfly (six ds_bpermute) against the DPP / lane-swap form of -DDDPO_EXP_DPP_REDUCE (csrc/common.h; both copied here so the check
-// does not depend on how the library was built): every lane of every wave must hold the same BITS, on random data, on data with cancellation
-// and on NaN / inf / denormal patterns; then a latency-bound micro-timing (dependent chains, one wave per SIMD).
-typedef unsigned int probe_u32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float red_ref(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-__device__ __forceinline__ float red_lane_xor_dpp(float v, int o) {
-  const int x = __builtin_bit_cast(int, v);
-  int t;
-  if (o == 1) t = __builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, true);
-  else if (o == 2) t = __builtin_amdgcn_mov_dpp(x, 0x4E, 0xF, 0xF, true);
-  else if (o == 8) t = __builtin_amdgcn_mov_dpp(x, 0x128, 0xF, 0xF, true);
-  else {
-    t = __builtin_amdgcn_update_dpp(x, x, 0x104, 0xF, 0x5, false);
-    t = __builtin_amdgcn_update_dpp(t, x, 0x114, 0xF, 0xA, false);
-  }
-  return __builtin_bit_cast(float, t);
-}
-// the swap instructions exchange halves / rows BETWEEN their two registers: the second operand must be a distinct register holding a copy
-// (given the same SSA value twice the compiler may hand the instruction one register for both — first hardware run of this probe: both
-// results came back as [lo, lo]); the copy is laundered through an empty asm
-__device__ __forceinline__ unsigned red_copy(unsigned a) { asm volatile("" : "+v"(a)); return a; }
-__device__ __forceinline__ float red_dpp(float v) {
-  probe_u32x2 r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), red_copy(__builtin_bit_cast(unsigned, v)), false, false);
-  v = __builtin_bit_cast(float, r.x) + __builtin_bit_cast(float, r.y);
-  r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), red_copy(__builtin_bit_cast(unsigned, v)), false, false);
-  v = __builtin_bit_cast(float, r.x) + __builtin_bit_cast(float, r.y);
-  v += red_lane_xor_dpp(v, 8);
-  v += red_lane_xor_dpp(v, 4);
-  v += red_lane_xor_dpp(v, 2);
-  v += red_lane_xor_dpp(v, 1);
-  return v;
-}
-__global__ void reduce_check_kernel(const float* __restrict__ x, float* __restrict__ a, float* __restrict__ b, int64_t n) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const float v = i < n ? x[i] : 0.f;                  // whole waves only reach the reductions (n is a multiple of 64)
-  a[i] = red_ref(v);
-  b[i] = red_dpp(v);
-}
-// which lane does each primitive of the DPP / lane-swap form read?  v = lane index in; out[step * 64 + lane] = the partner's index (steps: ^32,
-// ^16 as the two swap results (x, y), ^8, ^4, ^2, ^1)
-__global__ void reduce_partner_kernel(float* __restrict__ out) {
-  const int lane = threadIdx.x;
-  const float v = (float)lane;
-  probe_u32x2 r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), red_copy(__builtin_bit_cast(unsigned, v)), false, false);
-  out[0 * 64 + lane] = __builtin_bit_cast(float, r.x); out[1 * 64 + lane] = __builtin_bit_cast(float, r.y);
-  r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), red_copy(__builtin_bit_cast(unsigned, v)), false, false);
-  out[2 * 64 + lane] = __builtin_bit_cast(float, r.x); out[3 * 64 + lane] = __builtin_bit_cast(float, r.y);
-  out[4 * 64 + lane] = red_lane_xor_dpp(v, 8);
-  out[5 * 64 + lane] = red_lane_xor_dpp(v, 4);
-  out[6 * 64 + lane] = red_lane_xor_dpp(v, 2);
-  out[7 * 64 + lane] = red_lane_xor_dpp(v, 1);
-}
-template <bool DPP>
-__global__ void __launch_bounds__(256) reduce_chain_kernel(const float* __restrict__ x, float* __restrict__ y, int reps) {
-  float v = x[blockIdx.x * blockDim.x + threadIdx.x];
-  for (int r = 0; r < reps; ++r) v = (DPP ? red_dpp(v) : red_ref(v)) * 0.015625f + 1.0f;      // dependent chain: latency of one reduction
-  y[blockIdx.x * blockDim.x + threadIdx.x] = v;
-}
-static int probe_reduce() {
-  const int64_t n = 1 << 20;
-  std::vector<float> h(n);
-  uint32_t st = 12345u;
-  auto rnd = [&] { st = st * 1664525u + 1013904223u; return st; };
-  for (int64_t i = 0; i < n; ++i) {
-    const int mode = (int)((i >> 6) % 6);              // one pattern per wave
-    const float u = (float)(rnd() >> 8) * (1.0f / 16777216.0f) - 0.5f;
-    float v = u;
-    if (mode == 1) v = u * 1e6f + ((i & 1) ? 1e6f : -1e6f);                  // cancellation
-    else if (mode == 2) v = u * 1e-41f;                                      // denormals
-    else if (mode == 3) v = (i & 63) == (int64_t)(rnd() & 63) ? INFINITY : u;
-    else if (mode == 4) v = (i & 63) == 7 ? NAN : u;
-    else if (mode == 5) v = (float)(i & 63);                                 // lane index: a wrong partner shows up as a wrong integer
-    h[i] = v;
-  }
-  float *x = (float*)dalloc(n * 4), *a = (float*)dalloc(n * 4), *b = (float*)dalloc(n * 4);
-  HIP_OK(hipMemcpy(x, h.data(), n * 4, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(reduce_check_kernel, dim3((unsigned)(n / 256)), dim3(256), 0, 0, x, a, b, n);
-  std::vector<uint32_t> ha(n), hb(n);
-  HIP_OK(hipMemcpy(ha.data(), a, n * 4, hipMemcpyDeviceToHost));
-  HIP_OK(hipMemcpy(hb.data(), b, n * 4, hipMemcpyDeviceToHost));
-  int64_t bad = 0, first = -1;
-  for (int64_t i = 0; i < n; ++i)
-    if (ha[i] != hb[i] && !(((ha[i] & 0x7F800000u) == 0x7F800000u && (ha[i] & 0x7FFFFFu)) && ((hb[i] & 0x7F800000u) == 0x7F800000u && (hb[i] & 0x7FFFFFu)))) {
-      if (first < 0) first = i;                        // (two NaNs of different payload are the same answer)
-      ++bad;
-    }
-  // lane-index waves: the sum of 0 .. 63 in every lane
-  int64_t wrong_sum = 0;
-  for (int64_t i = 0; i < n; ++i)
-    if ((i >> 6) % 6 == 5 && hb[i] != 0x44FC0000u) ++wrong_sum;               // 2016.0f
-  printf("reduce: %lld of %lld lanes differ between the ds_bpermute and the DPP / lane-swap butterfly%s; lane-index waves wrong: %lld\n",
-         (long long)bad, (long long)n, bad ? " -> FAIL" : " (bit-identical)", (long long)wrong_sum);
-  if (first >= 0) printf("  first difference at element %lld (wave pattern %lld): %08x vs %08x\n", (long long)first, (long long)((first >> 6) % 6), ha[first], hb[first]);
-  {
-    float* pd = (float*)dalloc(8 * 64 * 4);
-    hipLaunchKernelGGL(reduce_partner_kernel, dim3(1), dim3(64), 0, 0, pd);
-    std::vector<float> hp(8 * 64);
-    HIP_OK(hipMemcpy(hp.data(), pd, 8 * 64 * 4, hipMemcpyDeviceToHost));
-    const char* names[8] = {"permlane32_swap.x", "permlane32_swap.y", "permlane16_swap.x", "permlane16_swap.y", "xor8 row_ror:8", "xor4 row_shl/shr:4", "xor2 quad_perm", "xor1 quad_perm"};
-    for (int st_ = 0; st_ < 8; ++st_) {
-      // expected: the four DPP steps read lane ^ {8, 4, 2, 1}; the swaps return x = [lo, lo] / [r0, r0, r2, r2] and y = [hi, hi] / [r1, r1, r3, r3]
-      printf("reduce: %-20s lanes 0..63 read:", names[st_]);
-      for (int l = 0; l < 64; ++l) printf(" %d", (int)hp[st_ * 64 + l]);
-      printf("\n");
-    }
-    HIP_OK(hipFree(pd));
-  }
-  const int reps = 2000, blocks = 256;                 // one workgroup of four waves per CU
-  const float t0 = time_ms(5, [&] { hipLaunchKernelGGL(reduce_chain_kernel<false>, dim3(blocks), dim3(256), 0, 0, x, a, reps); });
-  const float t1 = time_ms(5, [&] { hipLaunchKernelGGL(reduce_chain_kernel<true>, dim3(blocks), dim3(256), 0, 0, x, b, reps); });
-  printf("reduce: dependent chain of %d reductions: ds_bpermute %.1f ns each, DPP / lane swap %.1f ns each (x%.2f)\n", reps, t0 * 1e6 / reps, t1 * 1e6 / reps, t0 / t1);
-  HIP_OK(hipFree(x)); HIP_OK(hipFree(a)); HIP_OK(hipFree(b));
-  return (bad || wrong_sum) ? 1 : 0;
-}
-
 // ------------------------------------------------------------------------------------------------ gelu forms
-// gelu(x, approximate=tanh): libm tanhf (shipped) vs the v_exp_f32 / v_rcp_f32 sigmoid form of -DDDPO_EXP_FAST_GELU (csrc/common.h; both copied
+// gelu(x, approximate=tanh): libm tanhf (rounds 1-4) vs the v_exp_f32 / v_rcp_f32 sigmoid form csrc/common.h ships since round 5 (both copied
 // here), against float64 on a dense sweep of [-12, 12] plus large / special arguments; then the VALU cost of 32 evaluations per lane.
 __device__ __forceinline__ float gelu_ref_f(float x) {
   const float k0 = 0.7978845608028654f, k1 = 0.044715f;
@@ -1003,7 +882,6 @@ int main(int argc, char** argv) {
   else if (mode == "attn") rc = probe_attn(B, iters);
   else if (mode == "ppo") rc = probe_ppo();
   else if (mode == "stream") rc = probe_stream();
-  else if (mode == "reduce") rc = probe_reduce();
   else if (mode == "gelu") rc = probe_gelu();
 #ifdef PROBE_TIMING
   else if (mode == "ktime") rc = probe_ktime(B);
