@@ -93,16 +93,20 @@ __host__ __device__ __forceinline__ int64_t plane_off(int64_t row, int c, int ld
 // scale per output column, chunks [l8 | h8 | l8 | h8] (ddpo_pack_weights_f16mx).
 typedef _Float16 mx_half2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void mx_split4(const float4 v, uint2& h16, uint32_t& h8, uint32_t& l8) {
-  const float lim = 65504.f;              // f16 range: larger magnitudes saturate (Stable Diffusion runs in f16 end to end)
-  const _Float16 a = (_Float16)fminf(fmaxf(v.x, -lim), lim), b = (_Float16)fminf(fmaxf(v.y, -lim), lim);
-  const _Float16 c = (_Float16)fminf(fmaxf(v.z, -lim), lim), e = (_Float16)fminf(fmaxf(v.w, -lim), lim);
+  // Saturation (tests/test_gpu_f16mx.py::test_operands_beyond_the_f16_range_...): the value is clamped to the f16 range FIRST and every
+  // part is derived from the clamped value (the low part of an unclamped 7e4 would be 4496 * 2^11 = inf in e5m2), and the e5m2 image of h is taken
+  // from h clamped to e5m2's largest finite value 57344 (f16 values above 61440 round to e5m2 infinity otherwise; the cross terms are 2^-3 relative,
+  // so the clamp costs such a value nothing it had).  Values inside +-57344 — every activation of the model — produce the same bits as before.
+  const float lim = 65504.f, lim8 = 57344.f;
+  const float vx = fminf(fmaxf(v.x, -lim), lim), vy = fminf(fmaxf(v.y, -lim), lim), vz = fminf(fmaxf(v.z, -lim), lim), vw = fminf(fmaxf(v.w, -lim), lim);
+  const _Float16 a = (_Float16)vx, b = (_Float16)vy, c = (_Float16)vz, e = (_Float16)vw;
   h16.x = __builtin_bit_cast(uint32_t, mx_half2{a, b});
   h16.y = __builtin_bit_cast(uint32_t, mx_half2{c, e});
   const float ha = (float)a, hb = (float)b, hc = (float)c, he = (float)e;
-  int p = __builtin_amdgcn_cvt_pk_bf8_f32(ha, hb, 0, false);
-  h8 = (uint32_t)__builtin_amdgcn_cvt_pk_bf8_f32(hc, he, p, true);
-  p = __builtin_amdgcn_cvt_pk_bf8_f32((v.x - ha) * 2048.f, (v.y - hb) * 2048.f, 0, false);
-  l8 = (uint32_t)__builtin_amdgcn_cvt_pk_bf8_f32((v.z - hc) * 2048.f, (v.w - he) * 2048.f, p, true);
+  int p = __builtin_amdgcn_cvt_pk_bf8_f32(fminf(fmaxf(ha, -lim8), lim8), fminf(fmaxf(hb, -lim8), lim8), 0, false);
+  h8 = (uint32_t)__builtin_amdgcn_cvt_pk_bf8_f32(fminf(fmaxf(hc, -lim8), lim8), fminf(fmaxf(he, -lim8), lim8), p, true);
+  p = __builtin_amdgcn_cvt_pk_bf8_f32((vx - ha) * 2048.f, (vy - hb) * 2048.f, 0, false);
+  l8 = (uint32_t)__builtin_amdgcn_cvt_pk_bf8_f32((vz - hc) * 2048.f, (vw - he) * 2048.f, p, true);
 }
 // 4 consecutive channels c .. c+3 (c % 4 == 0) of `row` into the two f16mx planes (p16 / p8 addressed like bf16 planes: plane_off)
 __device__ __forceinline__ void mx_store4(uint16_t* __restrict__ p16, uint16_t* __restrict__ p8, int64_t row, int c, int ld, int64_t rows,

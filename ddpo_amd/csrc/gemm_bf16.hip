@@ -529,7 +529,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 64 ? 3 : 1)) g
   constexpr bool BFULL = (BN % BR) == 0;                // else the last W pass covers only part of the threads
   static_assert(BM % AR == 0 && WTM % 32 == 0 && WTN % 32 == 0, "tile / wave-grid mismatch");
   constexpr bool MX = NPASS == 4;                       // f16mx datapath (plane-fed only): f16 plane + 8-bit plane per operand
-  static_assert(!MX || APL == 3, "the f16mx datapath exists on the plane-fed 128-row tiles only");
+  static_assert(!MX || APL == 3 || APL == 7, "the f16mx datapath exists on the plane-fed 128-row tiles (APL 3) and on the tall tile (APL 7)");
   constexpr int NPL = (NPASS >= 3) ? 2 : 1;
   constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -733,7 +733,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 64 ? 3 : 1)) g
         if (conv && tap < ntaps) set_tap(tap);
       }
     };
-    if constexpr (APL == 5) {
+    if constexpr (APL == 5 || APL == 6) {
       // Schedule of the TALL 256x320 tile (64 x 160 per wave: 160 accumulator registers leave room for ONE fragment set;
       // the second wave of the SIMD covers the LDS latency).  28 fragment reads and 9 LDS-DMA pieces feed 60 MFMAs per wave and
       // k-tile, against 24 + 7 for 30 MFMAs on the 128x320 tile: 36 % fewer L2 and 42 % fewer LDS bytes per MFMA.
@@ -876,8 +876,81 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 64 ? 3 : 1)) g
         __builtin_amdgcn_sched_barrier(0);
         as = as_n; ws = ws_n;
       }
+    } else if constexpr (APL == 7) {
+      // f16mx on the TALL 256 x 320 tile (round 5): eight waves of 64 x 160, two per SIMD (256 registers per lane: 160 accumulators + 96).
+      // Why a tall tile: the f16mx kernels are bound by the chip's L2 -> LDS stream (8.4 - 11.4 TB/s, tools/native/dma_bench), not by the
+      // matrix pipe — the 128 x 320 tile fetches 57 KB per k-tile for 1.31 M MAC (23 MAC / B), this one 73.7 KB for 2.62 M (35.5 MAC / B):
+      // 36 % fewer operand bytes per product.  Round 3 built this tile twice and lost 44 - 58 values to scratch around the 8-register operands
+      // of the scaled MFMA; this form keeps the fragment set at 64 registers by construction: the activation fragments of the k-tile
+      // (2 x [f16 ks 0 | f16 ks 1 | 8-bit] = 32 registers) stay resident, the weight fragments of ONE column block (16 registers) are read in
+      // front of that block's six MFMAs into one of two buffers, and scheduling barriers between the column blocks keep the compiler from
+      // hoisting later blocks' reads (a four-wave form — 128 x 160 per wave, 320 accumulators — does not compile to anything usable: the
+      // MFMAs take the AGPR form, 64 accumulators do not fit the 256 AGPRs and travel through v_accvgpr moves and 1.8 KB of scratch).
+      // Per accumulator the order is f16 ks 0, f16 ks 1, MX — the 128-row kernel's — so the results are bit-identical to it.
+      // Two LDS stages (2 x 72 KB); one barrier per k-tile: behind it stage cur ^ 1 is free (every wave's reads of k-tile kt - 1 returned:
+      // lgkmcnt(0) in front of the barrier) and k-tile kt is published (every wave waited for its own pieces: vmcnt(0)).  The upper half of
+      // the waves requests its pieces of k-tile kt + 1 two column blocks later than the lower half (the 128-row loop's stagger).
+      static_assert(MX && BM == 256 && BN == 320 && WM == 4 && WN == 2, "the f16mx tall tile");
+      // fragment reads (offsets as in ldfrag_at: the 8-bit plane of an operand sits A_BYTES / B_BYTES behind its 16-bit plane)
+      const bool late = (d.splits & 1) != 0 && wv >= NW / 2;
+      fill(0);
+      auto ktile = [&](int kt, auto cur_c) {
+        constexpr int cur = decltype(cur_c)::value;
+        const char* sa = smem + cur * STAGE;
+        const char* sb = sa + NPL * A_BYTES;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt == 0) DBG_T(1);
+        if (kt + 1 < nk && !late) fill(cur ^ 1);
+        // phase 1: the two f16 products of every accumulator (k halves 0 and 1 of the k-tile)
+        {
+          bf16x8 ah0[TM], ah1[TM];
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            ah0[i] = *reinterpret_cast<const bf16x8*>(sa + a_ld0 + i * 2048);
+            ah1[i] = *reinterpret_cast<const bf16x8*>(sa + a_ld1 + i * 2048);
+          }
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const bf16x8 bh0 = *reinterpret_cast<const bf16x8*>(sb + b_ld0 + j * 2048);
+            const bf16x8 bh1 = *reinterpret_cast<const bf16x8*>(sb + b_ld1 + j * 2048);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah0[i]), __builtin_bit_cast(f16x8, bh0), acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah1[i]), __builtin_bit_cast(f16x8, bh1), acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        if (kt + 1 < nk && late) fill(cur ^ 1);
+        // phase 2: the MX product (both cross terms of the whole k-tile in one 32x32x64 MFMA per accumulator)
+        {
+          i32x8 a8[TM];
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const i32x4 x = *reinterpret_cast<const i32x4*>(sa + a_ld0 + A_BYTES + i * 2048), y = *reinterpret_cast<const i32x4*>(sa + a_ld1 + A_BYTES + i * 2048);
+            a8[i] = i32x8{x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
+          }
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const i32x4 x = *reinterpret_cast<const i32x4*>(sb + b_ld0 + B_BYTES + j * 2048), y = *reinterpret_cast<const i32x4*>(sb + b_ld1 + B_BYTES + j * 2048);
+            const i32x8 b8 = i32x8{x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[i][j] = mx_mfma(a8[i], b8, acc[i][j], mx_sa, j & 3, mx_sbp[j >> 2]);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      };
+      int kt = 0;
+#pragma unroll 1
+      for (; kt + 1 < nk; kt += 2) {
+        ktile(kt, std::integral_constant<int, 0>{});
+        ktile(kt + 1, std::integral_constant<int, 1>{});
+      }
+      if (kt < nk) ktile(kt, std::integral_constant<int, 0>{});
     } else {
-      static_assert(APL == 3 || APL == 5, "plane-fed k-loops: 3 = three weight stages (128-row tiles), 5 = tall tile");
+      static_assert(APL == 3 || APL == 5 || APL == 6, "plane-fed k-loops: 3 = three weight stages (128-row tiles), 5 = tall tile, 6 = tall tile with the GEGLU output stage, 7 = f16mx tall tile");
     }
   } else {
     const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(d.src);
@@ -1072,6 +1145,53 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 64 ? 3 : 1)) g
       Epi ep;
       const int colb = n0 + wn * WTN;
       static_assert(TM == 2, "the tall tile's output stage is written for two 32-row passes per wave");
+      if constexpr (APL == 6) {
+        // GEGLU on the tall tile (round 5; its own instantiation, APL = 6, so that the plain tall tile's code does not change by an instruction).  The weight columns of tile t come as [a (160) | gate (160)] of output columns 160 t .. 160 t + 159
+        // (ddpo_gemm_desc.epilogue == 2), so the wave pair (wm, 0) / (wm, 1) holds the value and the gate accumulators of the SAME 64 x 160
+        // outputs.  Per 32-row pass: both waves add their bias IN REGISTERS (a lane's column is fixed per accumulator block), the gate wave
+        // applies gelu_tanh there too, both transpose into their LDS slices (adjacent: wid = 2 wm + wn); one barrier; then each wave of the
+        // pair multiplies and emits 16 of the 32 rows (40 float4 per row, 10 wave instructions), so all eight waves store.  Same arithmetic
+        // per element as the 128 x 128 GEGLU tile — (acc_a + b_a) * gelu_tanh(acc_g + b_g) on the same accumulation order — so the two
+        // tiles agree bit for bit (tests/test_gpu_bf16.py::test_linear_geglu_tall_tile_is_bit_identical).
+        static_assert(WN == 2 && WTN == 160, "value / gate wave pairs of 160 columns");
+        const int oc0 = (n0 / 320) * 160;                  // first OUTPUT column of this tile
+        float bj[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bj[j] = d.bias ? d.bias[colb + j * 32 + (lane & 31)] : 0.f;
+        const float* ca = reinterpret_cast<const float*>(smem) + (wid & ~1) * (32 * WTN);
+        const float* cg = ca + 32 * WTN;
+        auto gpass = [&](auto IH) {
+          constexpr int ih = decltype(IH)::value;
+          if (ih > 0) __syncthreads();                     // every wave has read the slices of the previous pass
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              float v = acc[ih][j][r] + bj[j];
+              if (wn == 1) v = gelu_tanh_f(v);
+              cw[((r & 3) + 8 * (r >> 2) + 4 * khalf) * WTN + j * 32 + (lane & 31)] = v;
+            }
+          __syncthreads();
+          constexpr int GL = WTN / 4;                      // float4 per output row
+          int ln = lane;
+          asm volatile("" : "+v"(ln));                     // (as in EpiRows: keeps the index arithmetic of the iterations from being hoisted and spilled)
+#pragma unroll
+          for (int it = 0; it < 16 * GL / 64; ++it) {
+            const int e = it * 64 + ln, rr = wn * 16 + e / GL, c4 = (e - (e / GL) * GL) * 4;
+            const float4 a = *reinterpret_cast<const float4*>(ca + rr * WTN + c4);
+            const float4 g = *reinterpret_cast<const float4*>(cg + rr * WTN + c4);
+            const float4 o = make_float4(a.x * g.x, a.y * g.y, a.z * g.z, a.w * g.w);
+            const int row = m0 + wm * WTM + ih * 32 + rr, col = oc0 + c4;
+            if (row >= d.M) continue;
+            if (d.out) st_out4(d.out + (int64_t)row * d.ld_out + col, o);
+            if (d.out_hi) store_planes4(d, row, col, o);
+          }
+        };
+        gpass(std::integral_constant<int, 0>{});
+        gpass(std::integral_constant<int, 1>{});
+        DBG_T(3);
+        return;
+      }
       // (the passes are spelled out: left as a loop the optimizer declined to unroll it, and the dynamically indexed accumulators went to scratch)
       auto pass = [&](auto IH) {
         constexpr int ih = decltype(IH)::value;
@@ -1220,7 +1340,7 @@ static bool planes_out_ok(const ddpo_gemm_desc& d) {
   if (!d.out_hi) return d.out != nullptr && !d.out_lo;
   if (!d.out_lo || d.ld_planes < 0 || (d.ld_planes & 3)) return false;
   if ((reinterpret_cast<uintptr_t>(d.out_hi) | reinterpret_cast<uintptr_t>(d.out_lo)) & 7) return false;
-  const int ncols = d.epilogue == 1 ? d.N / 2 : d.N;
+  const int ncols = d.epilogue != 0 ? d.N / 2 : d.N;
   if (d.ld_planes == 0 ? (ncols & 31) != 0 : d.ld_planes < ncols) return false;      // 0: k-blocked (ncols / 32, M, 32)
   if (d.planes_fmt != 0 && (d.planes_fmt != 1 || (ncols & 31) || (d.ld_planes & 31))) return false;      // f16mx planes: whole 32-column blocks
   if (d.N & 3) return false;
@@ -1398,15 +1518,43 @@ static int launch_bf16_tall(const ddpo_gemm_desc& d, const uint16_t* w_hi, const
   return DDPO_OK;
 }
 
+// f16mx on the tall tile: eight waves of 64x160 (APL = 7), 144 KB of operand stages, no split-K (launched only where the grid fills the chip).
+static int launch_mx_tall(const ddpo_gemm_desc& d, const uint16_t* w16, const uint16_t* w8, hipStream_t st) {
+  constexpr int BM = 256, BN = 320, WM = 4, WN = 2;
+  const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;
+  const int nblk = tiles_m * tiles_n;
+  const int nk_total = d.K / BF_BK;
+  const size_t lds = 8 * 32 * 160 * 4;                      // the output stage's slices (160 KB) > two stages of [A16 | A8 | W16 | W8] (144 KB)
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_bf16_buf_kernel<BM, BN, 4, 0, WM, WN, true, 7>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  count_tile(TC_TALL);
+  count_tile(TC_MX);
+  hipLaunchKernelGGL((gemm_conv_bf16_buf_kernel<BM, BN, 4, 0, WM, WN, true, 7>), dim3(nblk, 1), dim3(64 * WM * WN), lds, st, d, w16, w8, 0,
+                     tiles_m, tiles_n, nblk, nk_total, (float*)nullptr);
+  DDPO_LAUNCH_CHECK();
+  return DDPO_OK;
+}
+
 // Tile-shape / split-K selection shared by the fp32-fed and the plane-fed entry points: the SAME rules, so both produce
 // bit-identical results for the same layer (APL is only instantiated for npass == 3).
 template <int APL>
 static int dispatch_bf16(const ddpo_gemm_desc& d, const uint16_t* w_hi, const uint16_t* w_lo, int ldw, int npass, void* ws, size_t ws_bytes,
                          hipStream_t st) {
   if (d.epilogue != 0) {       // GEGLU output stage: 128-wide tiles of the buffer-addressed kernel, vector epilogue only
-    if (d.epilogue != 1 || (d.N & 127) || !buf_path_ok(d, ldw) || d.rowbias || d.residual || d.alpha != 1.0f || d.w_dgrad) return DDPO_EINVAL;
+    if ((d.epilogue != 1 && d.epilogue != 2) || (d.N & 127) || !buf_path_ok(d, ldw) || d.rowbias || d.residual || d.alpha != 1.0f || d.w_dgrad) return DDPO_EINVAL;
     if ((d.ld_out & 3) || (reinterpret_cast<uintptr_t>(d.out) & 15) || (d.bias && (reinterpret_cast<uintptr_t>(d.bias) & 15))) return DDPO_EINVAL;
     if (reinterpret_cast<uintptr_t>(d.aux_out) & 15) return DDPO_EINVAL;
+    if (d.epilogue == 2) {     // the tall 256 x 320 tile with value / gate wave pairs: plane-fed bf16x3 only, columns in [a (160) | gate (160)] blocks
+      if constexpr (APL == 3) {
+        if (npass != 3 || d.N % 320 || d.aux_out || ((d.N >> 1) & 3)) return DDPO_EINVAL;
+        return launch_bf16_tall<6>(d, w_hi, w_lo, ldw, st);
+      }
+      return DDPO_EINVAL;
+    }
     if constexpr (APL == 3) { if (npass == 4) return launch_bf16<128, 128, 4, 2, 2, 3>(d, w_hi, w_lo, ldw, nullptr, 0, st); }
     return npass == 3 ? launch_bf16<128, 128, 3, 2, 2, APL>(d, w_hi, w_lo, ldw, nullptr, 0, st) : launch_bf16<128, 128, 1>(d, w_hi, w_lo, ldw, nullptr, 0, st);
   }
@@ -1430,6 +1578,17 @@ static int dispatch_bf16(const ddpo_gemm_desc& d, const uint16_t* w_hi, const ui
     // @64^2, profiles/r03_probe_mx_tall.log.  The f16mx tall tile wants FOUR waves of 128 x 160 (one per SIMD, accumulators in AGPRs).)
     if (tall_mode && npass == 3 && d.N % 320 == 0 && d.epilogue == 0 && ntall >= 200 && eff_tall * 1.08 >= eff_wide)
       return launch_bf16_tall<5>(d, w_hi, w_lo, ldw, st);
+    if constexpr (APL == 3) {
+      // f16mx layers on the tall tile (APL = 7) under the bf16x3 tall tile's rule: grids that fill whole rounds of the chip unsplit — the 64x64
+      // level at batch 16 and the up-sampled 32x32 -> 64x64 convolution.  Measured round 5 (profiles/r05_probe_mx_tall.log, r05_ab_mx_tall.log):
+      // conv 320->320 @64^2 0.259 -> 0.236 ms, 960->320 0.930 -> 0.709 ms, up-conv 640->640 1.084 -> 0.878 ms, bit-identical; sampling +1.4 %.
+      // A split-K grid of tall tiles for the 32x32 / 16x16 levels (128 / 64 tiles x 2 / 4 splits) was built and measured with it: no gain over
+      // the 128x320 tile there (4.09 vs 4.09 images/s) — deleted.  DDPO_MX_TALL=0 (read per launch) keeps every f16mx layer on the 128-row tiles:
+      // the probe's and the tests' bit-identity comparison.
+      const char* mx_tall_env = getenv("DDPO_MX_TALL");
+      if (npass == 4 && !(mx_tall_env && mx_tall_env[0] == '0') && d.N % 320 == 0 && d.epilogue == 0 && ntall >= 200 && eff_tall * 1.08 >= eff_wide)
+        return launch_mx_tall(d, w_hi, w_lo, st);
+    }
   }
   const int wsplits = wide_splits(d, wsf != nullptr, ws_bytes);
   if (wide_mode && d.N % 320 == 0 && d.M >= 512 && buf_path_ok(d, ldw) && !(d.K / BF_BK < 16 && d.N > 1280) &&

@@ -39,7 +39,7 @@ class GemmDesc(ctypes.Structure):
                 ("w_scale", c_void_p), ("planes_fmt", c_int), ("colsum", c_void_p), ("aux_out", c_void_p)]
 
 
-ABI_VERSION = 12         # must equal ddpo_abi_version() of the loaded library (include/ddpo_hip.h)
+ABI_VERSION = 13         # must equal ddpo_abi_version() of the loaded library (include/ddpo_hip.h)
 
 _SIGS = {
     "ddpo_abi_version": (c_int, []),
@@ -237,6 +237,8 @@ PLANES = os.environ.get("DDPO_PLANES", "1") == "1"
 # The TRAINING forward writes its GroupNorm / LayerNorm results as planes too (they are consumed only by the layer's GEMM and by
 # its weight gradient, ddpo_gemm_conv_wgrad_bf16x3_planes): plane-fed forward GEMMs and no activation split in the wgrad loader.
 TRAIN_PLANES = os.environ.get("DDPO_TRAIN_PLANES", "1") == "1"
+# FF1 + GEGLU of the sampling forward on the 256 x 320 tile where its grid fills the chip (round 5; geglu_tall_pays).  DDPO_GEGLU_TALL=0: the 128 x 128 tile everywhere.
+GEGLU_TALL = os.environ.get("DDPO_GEGLU_TALL", "1") == "1"
 # GEMM output stages that emit planes for a following GEMM (GEGLU -> FF2, block output -> down / up-sampler convolution)
 PLANES_OUT = os.environ.get("DDPO_PLANES_OUT", "1") == "1"
 PLANES_ALL = os.environ.get("DDPO_PLANES_ALL", "0") == "1"      # plane-feed every eligible layer, also where it is measured slower
@@ -794,10 +796,10 @@ def pack_weights_geglu(w, bias):
     ent = PACKED.get(w.data_ptr())
     if ent is None:
         return False
+    mk = lambda: torch.zeros(N, K, dtype=torch.int16, device=w.device)
     if "geglu" not in ent:
         idx = torch.arange(F, device=w.device).view(F // 32, 1, 32)
         perm = torch.cat([idx, idx + F], dim=1).reshape(-1)               # [a_0 | gate_0 | a_1 | gate_1 | ...]
-        mk = lambda: torch.zeros(N, K, dtype=torch.int16, device=w.device)
         ent["geglu"] = dict(perm=perm, hi=mk(), lo=mk(), bias=torch.empty(N, dtype=torch.float32, device=w.device), w_layout=1 if W_KBLOCKED else 0)
     g = ent["geglu"]
     wp = w.index_select(1, g["perm"]).contiguous()
@@ -806,6 +808,18 @@ def pack_weights_geglu(w, bias):
         _check(load().ddpo_pack_weights_bf16_kblocked(_p(wp), K, N, _p(g["hi"]), _p(g["lo"]), _stream()), "ddpo_pack_weights_bf16_kblocked")
     else:
         _check(load().ddpo_pack_weights_bf16(_p(wp), K, N, K, _p(g["hi"]), _p(g["lo"]), None, None, _stream()), "ddpo_pack_weights_bf16")
+    # second column order for the 256 x 320 GEGLU tile (ddpo_gemm_desc.epilogue = 2, ABI v13): 320-column blocks [a (160) | gate (160)]; bf16x3 layers
+    # only (FF1's reduction is the model width: never an f16mx layer), k-blocked planes.  Which of the two orders a call uses: geglu_tall_pays().
+    if GEGLU_TALL and W_KBLOCKED and _x3() and N % 320 == 0 and not (_mx() and K >= MX_MIN_K):
+        if "tall" not in g:
+            idx = torch.arange(F, device=w.device).view(F // 160, 1, 160)
+            g["tall"] = dict(perm=torch.cat([idx, idx + F], dim=1).reshape(-1), hi=mk(), lo=mk(), bias=torch.empty(N, dtype=torch.float32, device=w.device))
+        t = g["tall"]
+        wt = w.index_select(1, t["perm"]).contiguous()
+        torch.index_select(bias, 0, t["perm"], out=t["bias"])
+        _check(load().ddpo_pack_weights_bf16_kblocked(_p(wt), K, N, _p(t["hi"]), _p(t["lo"]), _stream()), "ddpo_pack_weights_bf16_kblocked")
+    else:
+        g.pop("tall", None)
     if _mx() and K >= MX_MIN_K:
         if "mx" not in g:
             g["mx"] = dict(w16=torch.zeros(K // 32, N, 32, dtype=torch.int16, device=w.device), w8=torch.zeros(K // 32, N, 64, dtype=torch.uint8, device=w.device),
@@ -816,6 +830,23 @@ def pack_weights_geglu(w, bias):
         g.pop("mx", None)
     g["stale"] = False
     return True
+
+
+def geglu_tall_pays(w, rows):
+    """True when the fused FF1 + GEGLU of weight `w` on `rows` rows should run on the 256 x 320 tile (epilogue = 2): registered with the tall column
+    order, no pre-activation wanted (sampling), and the grid of tall tiles fills whole rounds of the 256 CUs well — the same rule as the C++ dispatch
+    applies to the plain tall tile (>= 200 tiles, round efficiency within 8 % of the 128 x 320 grid's).  The caller then feeds bf16 hi / lo PLANES
+    (LayerNorm `planes=1`).  Why: at K = 320 .. 1280 the 128 x 128 GEGLU tile streams 16 MAC per operand byte and FF1 sits on the chip's L2 -> LDS
+    stream (3.3 GB per launch at the 64 x 64 level = 8 TB/s); the tall tile moves 35 MAC per byte."""
+    ent = PACKED.get(w.data_ptr())
+    if not (GEGLU_TALL and PLANES and _x3() and ent is not None and "geglu" in ent and not ent["geglu"]["stale"] and "tall" in ent["geglu"]):
+        return False
+    K, N = ent["K"], ent["N"]
+    if rows * K * 4 >= 0x7FFFFFFF or K % 32:
+        return False
+    ntall, nwide = -(-rows // 256) * (N // 320), -(-rows // 128) * (N // 320)
+    eff = lambda n: n / (-(-n // 256) * 256)
+    return ntall >= 200 and eff(ntall) * 1.08 >= eff(nwide)
 
 
 def linear_geglu(x, w, out=None, planes_out=False, pre_out=False):
@@ -849,12 +880,14 @@ def linear_geglu(x, w, out=None, planes_out=False, pre_out=False):
         if out is None:
             out = torch.empty(M, N // 2, dtype=torch.float32, device=x.device)
         d.out = out.data_ptr(); d.ld_out = N // 2
+    tall = pl is not None and pl.fmt == 0 and not pre_out and geglu_tall_pays(w, M)
+    gw = g["tall"] if tall else g
     d.src = x.data_ptr(); d.ld_src = K
-    d.bias = g["bias"].data_ptr()
+    d.bias = gw["bias"].data_ptr()
     d.alpha = 1.0
     d.M, d.N, d.K = int(M), int(N), int(K)
-    d.epilogue = 1
-    d.w_layout = g["w_layout"]
+    d.epilogue = 2 if tall else 1
+    d.w_layout = 1 if tall else g["w_layout"]
     pre = None
     if pre_out:
         pre = torch.empty(M, N, dtype=torch.float32, device=x.device)
@@ -870,7 +903,7 @@ def linear_geglu(x, w, out=None, planes_out=False, pre_out=False):
         _check(load().ddpo_gemm_conv_fwd_f16mx_planes(byref(d), _p(pl.hi), _p(pl.lo), pl.ld, _p(m["w16"]), _p(m["w8"]), None, 0, _stream()),
                "ddpo_gemm_conv_fwd_f16mx_planes")
     elif pl is not None:
-        _check(load().ddpo_gemm_conv_fwd_bf16_planes(byref(d), _p(pl.hi), _p(pl.lo), pl.ld, _p(g["hi"]), _p(g["lo"]), K, None, 0, _stream()),
+        _check(load().ddpo_gemm_conv_fwd_bf16_planes(byref(d), _p(pl.hi), _p(pl.lo), pl.ld, _p(gw["hi"]), _p(gw["lo"]), K, None, 0, _stream()),
                "ddpo_gemm_conv_fwd_bf16_planes")
     else:
         _check(load().ddpo_gemm_conv_fwd_bf16(byref(d), _p(g["hi"]), _p(g["lo"]), K, npass, None, 0, _stream()), "ddpo_gemm_conv_fwd_bf16")

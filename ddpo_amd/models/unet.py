@@ -353,6 +353,8 @@ class UNet2DCondition:
             pl_1 = 0
         pl_2 = npf(tb + ".attn2.to_q.kernel")
         pl_3 = npf(tb + ".ff.net_0.proj.kernel")
+        if inf and pl_3 != 1 and L.geglu_tall_pays(P[tb + ".ff.net_0.proj.kernel"], B * N):
+            pl_3 = 1                               # FF1 + GEGLU on the 256 x 320 tile is plane-fed: norm3 writes bf16 hi / lo planes
         F = P[tb + ".ff.net_2.kernel"].shape[0]
         pl_ff2 = inf and L.PLANES_OUT and L.planes_pay(P[tb + ".ff.net_2.kernel"], F, B * N)       # GEGLU output stage -> planes -> plane-fed FF2
         pl_out = inf and emit_planes and L.planes_out_ok(P[name + ".proj_out.kernel"], C, B * N, C)

@@ -181,13 +181,16 @@ typedef struct {
                                      1: GEGLU.  The N columns of W / bias come as interleaved 32-column blocks
                                         [a_0 | gate_0 | a_1 | gate_1 ...]; out has N/2 columns,
                                         out[:, 32q + c] = (acc_a + bias_a) * gelu_tanh(acc_gate + bias_gate);
-                                        needs N % 128 == 0, K % 32 == 0, no rowbias / residual, alpha == 1 */
+                                        needs N % 128 == 0, K % 32 == 0, no rowbias / residual, alpha == 1
+                                     2: GEGLU on the 256 x 320 tile (ABI v13; ddpo_gemm_conv_fwd_bf16_planes only).  The columns of W / bias come
+                                        as 320-column blocks [a (160) | gate (160)]: block t holds the value and gate columns of the output
+                                        columns 160 t .. 160 t + 159; same formula, bit-identical results; needs N % 320 == 0, no aux_out */
   /* plane-emitting output stage (ddpo_gemm_conv_fwd_bf16 / _planes on the buffer-addressed kernels only; NULL elsewhere).
    * When out_hi != NULL the final value v of every output element is ALSO written as bf16 hi / lo planes
    * (hi = bf16(v), lo = bf16(v - hi): the operand format of ddpo_gemm_conv_fwd_bf16_planes, bit for bit what the
    * fp32-fed loader would split v into), rows of ld_planes elements (% 4 == 0, planes 8-byte aligned).  `out` may then be
    * NULL (planes only).  Needs the vector output stage (N, ld_out, ld_res, ld_rowbias % 4 == 0, 16-byte aligned
-   * pointers); DDPO_EINVAL otherwise.  With epilogue == 1 the planes hold the N/2 GEGLU outputs. */
+   * pointers); DDPO_EINVAL otherwise.  With epilogue == 1 / 2 the planes hold the N/2 GEGLU outputs. */
   uint16_t* out_hi; uint16_t* out_lo; int ld_planes;
   /* layout of the forward weight planes handed to ddpo_gemm_conv_fwd_bf16 / _planes (ABI v6):
    *   0: row-major (N, ldw) bf16, k contiguous per output column (ddpo_pack_weights_bf16);

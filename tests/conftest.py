@@ -16,11 +16,11 @@ os.environ.setdefault("DDPO_ALLOW_SYNTHETIC", "1")
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     # The CPU oracle (torch) is what the slow tests wait for.  torch's default thread count on the GPU box is the host's 256 hardware threads,
-    # which OVERSUBSCRIBES its convolutions: one CFG step of the SD-1.5 oracle takes 12.4 s there against 4.4 s on 32 threads (round 5:
-    # profiles/r05_parity_trajectory_50_steps.log vs bench.py's cpu_baseline; tools/oracle_threads.py sweeps it).  DDPO_ORACLE_THREADS overrides.
+    # which OVERSUBSCRIBES its convolutions: one CFG step of the SD-1.5 oracle takes 12.1 s at the default 128 threads, 7.5 s on 64, 4.65 s on 32 and 4.25 s on 16; forward + backward at 32x32: 16.6 / 8.2 / 4.3 / 3.6 s (round 5:
+    # tools/oracle_threads.py, profiles/r05_oracle_threads.log).  DDPO_ORACLE_THREADS overrides.
     try:
         import torch
-        n = int(os.environ.get("DDPO_ORACLE_THREADS", "0")) or min(os.cpu_count() or 1, 32)
+        n = int(os.environ.get("DDPO_ORACLE_THREADS", "0")) or min(os.cpu_count() or 1, 16)
         torch.set_num_threads(n)
     except Exception:
         pass

@@ -109,6 +109,36 @@ def test_linear_geglu_fused_epilogue(datapath, mode, M, K, F):
     assert L.linear_geglu(x, w) is None
 
 
+@pytest.mark.parametrize("M,K,F", [(65536, 320, 1280), (16384, 640, 2560), (4096, 1280, 5120), (65536 - 77, 320, 640)])
+def test_linear_geglu_tall_tile_is_bit_identical(datapath, M, K, F, monkeypatch):
+    """FF1 + GEGLU on the 256 x 320 tile with value / gate wave pairs (ddpo_gemm_desc.epilogue = 2, ABI v13; the sampling forward's route at
+    the 64x64 / 32x32 / 16x16 levels of SD-1.5 at batch 16): same accumulation order and the same (acc_a + b_a) * gelu_tanh(acc_g + b_g) per
+    element as the 128 x 128 GEGLU tile, so fp32 output AND emitted planes are bit-identical to it; ragged M (rows beyond M are masked)."""
+    L.DATAPATH = "bf16x3"
+    g = torch.Generator().manual_seed(M + K + F)
+    x = torch.randn(M, K, generator=g).to(DEV)
+    w = (torch.randn(K, 2 * F, generator=g) / math.sqrt(K)).to(DEV)
+    b = torch.randn(2 * F, generator=g).to(DEV)
+    L.pack_weights(w)
+    assert L.pack_weights_geglu(w, b)
+    assert L.geglu_tall_pays(w, M)
+    xp = L.split_planes(x)
+    before = L.gemm_tile_launch_counts()
+    tall = L.linear_geglu(xp, w)
+    tall_pl = L.linear_geglu(xp, w, planes_out=1)
+    assert L.gemm_tile_launch_counts()["tall_256x320"] - before["tall_256x320"] == 2
+    monkeypatch.setattr(L, "GEGLU_TALL", False)
+    assert not L.geglu_tall_pays(w, M)
+    before = L.gemm_tile_launch_counts()
+    ref = L.linear_geglu(xp, w)
+    ref_pl = L.linear_geglu(xp, w, planes_out=1)
+    assert L.gemm_tile_launch_counts()["tall_256x320"] == before["tall_256x320"]
+    assert torch.equal(tall, ref)
+    assert torch.equal(tall_pl.hi, ref_pl.hi) and torch.equal(tall_pl.lo, ref_pl.lo)
+    f64 = x[:512].cpu().double() @ w.cpu().double() + b.cpu().double()
+    assert _rel(tall[:512], f64[:, :F] * TF.gelu(f64[:, F:], approximate="tanh")) < TOL["bf16x3"]
+
+
 def test_unregistered_weights_stay_on_fp32(datapath):
     L.DATAPATH = "bf16"
     g = torch.Generator().manual_seed(0)

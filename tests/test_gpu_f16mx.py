@@ -126,7 +126,9 @@ def test_output_stage_emits_f16mx_planes_of_the_result():
 def test_operands_beyond_the_f16_range_saturate_instead_of_overflowing():
     """every f16 split of the f16mx datapath (activation planes: common.h mx_split4; the attention's V / dO / K / Q images:
     split2h in attention_bf16.hip / attention_bwd_bf16.hip) clamps to +-65504 (60000 in the backward) before the conversion, so an
-    activation beyond the f16 range degrades to a saturated value — never to inf, and never to the NaN an inf - inf low part would be."""
+    activation beyond the f16 range degrades to a saturated value — never to inf, and never to the NaN an inf - inf low part would be.
+    (Round 5: the first run of this test found two holes in mx_split4 — the low part was taken from the UNCLAMPED value, and f16 values above
+    61440 round to e5m2 infinity in the 8-bit image of h; both parts now derive from the clamped value, h8 from h clamped to 57344.)"""
     old = L.DATAPATH
     L.DATAPATH = "f16mx"
     try:

@@ -372,7 +372,26 @@ static void run_mx(int B, int H, int Cin, int Cout, int ks, int stride, int ups,
   d1.out = out1; d2.out = out2; d2.w_scale = wsc;
   auto f1 = [&] { ABI_OK(ddpo_gemm_conv_fwd_bf16_planes(&d1, ah, al, acols, hi, lo, 0, ws, ws_bytes, nullptr)); };
   auto f2 = [&] { ABI_OK(ddpo_gemm_conv_fwd_f16mx_planes(&d2, a16, a8, acols, w16, w8, ws, ws_bytes, nullptr)); };
+  // f16mx tile routing (csrc/gemm_bf16.hip dispatch, DDPO_MX_TALL read per launch): 0 = 128-row tiles only, default = the 256x320 tall tile where
+  // its grid fills the chip.  Timed back to back, and the outputs compared BIT FOR BIT over the whole tensor (same per-accumulator order
+  // f16 ks 0, f16 ks 1, MX on both tiles).
+  const char* keep = getenv("DDPO_MX_TALL");
+  const std::string keep_s = keep ? keep : "";
+  float ms_mode[2] = {0.f, 0.f};
+  long long ndiff = 0;
+  std::vector<float> h_ref((size_t)M * N), h_cmp((size_t)M * N);
+  for (int mode = 0; mode < 2; ++mode) {
+    setenv("DDPO_MX_TALL", mode == 0 ? "0" : "1", 1);
+    HIP_OK(hipMemset(out2, 0xFF, (size_t)M * N * 4));
+    ms_mode[mode] = time_ms(iters, f2);
+    HIP_OK(hipMemcpy((mode == 0 ? h_ref : h_cmp).data(), out2, (size_t)M * N * 4, hipMemcpyDeviceToHost));
+  }
+  for (size_t q = 0; q < h_ref.size(); ++q) ndiff += memcmp(&h_ref[q], &h_cmp[q], 4) != 0;
+  if (keep) setenv("DDPO_MX_TALL", keep_s.c_str(), 1); else unsetenv("DDPO_MX_TALL");
   const float ms1 = time_ms(iters, f1), ms2 = time_ms(iters, f2);
+  printf("   f16mx, 128-row tiles only %.3f ms | with the tall-tile rule %.3f ms (x%.2f, %s)\n", ms_mode[0], ms_mode[1], ms_mode[0] / ms_mode[1],
+         ndiff == 0 ? "bit-identical" : "DIFFERS");
+  if (ndiff) ++g_fail;
   std::vector<uint16_t> h_a16(apl / 2), h_a8(apl / 2), h_w16(wpl / 2), h_w8(wpl / 2);
   std::vector<uint8_t> h_sc(N);
   HIP_OK(hipMemcpy(h_a16.data(), a16, apl, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(h_a8.data(), a8, apl, hipMemcpyDeviceToHost));
