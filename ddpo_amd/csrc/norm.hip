@@ -331,11 +331,106 @@ __global__ void __launch_bounds__(256) layernorm_rows_kernel(const float* __rest
     if (row0 + r < rows) ln_row<PL, 2>(v[r], lane, C4, C, eps, row0 + r, rows, y, gamma, beta, y_hi, y_lo, pair, ldy);
 }
 
+// C == 320 (the 64x64 level of SD-1.x / SD-2.x: 65536 rows at batch 16, the LayerNorm launches that matter): a row is 80 float4 = 16 lanes x 5,
+// so a wave works on FOUR rows at once, one per 16-lane DPP row, every lane busy (one row per wave leaves 48 of 128 lane slots idle), and both
+// reductions of a row stay inside its 16 lanes: four DPP steps (row_ror:8, row_shl / shr:4 under bank masks, two quad_perms — each verified on
+// MI355X to read exactly lane ^ {8, 4, 2, 1}, profiles/r04_probe_reduce.log; 64 ns per reduction against 193 ns for the six ds_bpermute of wave_sum)
+// instead of 12 trips through the LDS crossbar per row.  The lane pairing of the 16-byte plane stores is a quad_perm as well.  RS row sets
+// (8 rows) are requested per wave before the first is reduced.  Selected by C ALONE (any row count), so a row's bits do not depend on how many
+// rows its launch has — the property the sampler / training-forward equality rests on (tests/test_gpu_kernels.py).
+__device__ __forceinline__ float row16_xor(float v, int o) {              // the value of lane (i ^ o) inside the lane's 16-lane row, o in {1, 2, 4, 8}
+  const int x = __builtin_bit_cast(int, v);
+  int t;
+  if (o == 1) t = __builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, true);                 // quad_perm [1, 0, 3, 2]
+  else if (o == 2) t = __builtin_amdgcn_mov_dpp(x, 0x4E, 0xF, 0xF, true);            // quad_perm [2, 3, 0, 1]
+  else if (o == 8) t = __builtin_amdgcn_mov_dpp(x, 0x128, 0xF, 0xF, true);           // row_ror:8
+  else {
+    t = __builtin_amdgcn_update_dpp(x, x, 0x104, 0xF, 0x5, false);                   // row_shl:4 -> banks 0, 2 (lane i reads i + 4)
+    t = __builtin_amdgcn_update_dpp(t, x, 0x114, 0xF, 0xA, false);                   // row_shr:4 -> banks 1, 3 (lane i reads i - 4)
+  }
+  return __builtin_bit_cast(float, t);
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += row16_xor(v, 8);
+  v += row16_xor(v, 4);
+  v += row16_xor(v, 2);
+  v += row16_xor(v, 1);
+  return v;
+}
+template <bool PL, int NV, int RS>
+__global__ void __launch_bounds__(256) layernorm_rows16_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, int rows, float eps, uint16_t* __restrict__ y_hi,
+                                                               uint16_t* __restrict__ y_lo, int pair, int ldy) {
+  constexpr int C = NV * 64;
+  const int lane = threadIdx.x & 63, g = lane >> 4, sub = lane & 15;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (4 * RS);
+  if (row0 >= rows) return;
+  float4 v[RS][NV];
+#pragma unroll
+  for (int s = 0; s < RS; ++s) {
+    const float* xr = x + (int64_t)min(row0 + 4 * s + g, rows - 1) * C;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) v[s][j] = *reinterpret_cast<const float4*>(xr + ((sub + 16 * j) << 2));
+  }
+#pragma unroll
+  for (int s = 0; s < RS; ++s) {
+    const int64_t row = row0 + 4 * s + g;
+    const bool live = row < rows;                      // (a clamped duplicate row still takes part in the DPP steps: no divergence in front of them)
+    float sm = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) sm += (v[s][j].x + v[s][j].y) + (v[s][j].z + v[s][j].w);
+    const float mean = row16_sum(sm) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const float a = v[s][j].x - mean, b = v[s][j].y - mean, c = v[s][j].z - mean, d = v[s][j].w - mean;
+      q += (a * a + b * b) + (c * c + d * d);
+    }
+    const float rstd = rsqrtf(row16_sum(q) / (float)C + eps);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int c4 = sub + 16 * j;
+      const float4 gm = *reinterpret_cast<const float4*>(gamma + (c4 << 2));
+      const float4 bt = *reinterpret_cast<const float4*>(beta + (c4 << 2));
+      float4 o;
+      o.x = (v[s][j].x - mean) * rstd * gm.x + bt.x;
+      o.y = (v[s][j].y - mean) * rstd * gm.y + bt.y;
+      o.z = (v[s][j].z - mean) * rstd * gm.z + bt.z;
+      o.w = (v[s][j].w - mean) * rstd * gm.w + bt.w;
+      if (PL && pair == 2) {
+        if (live) mx_store4(y_hi, y_lo, row, c4 << 2, ldy, rows, o);
+      } else if (PL) {
+        uint2 h, l;
+        split4(o, h, l);
+        if (pair) {                                    // lane-paired 16-byte stores: lanes 2k / 2k + 1 hold adjacent channel quads of one row
+          const bool odd = lane & 1;
+          const uint32_t sx = odd ? h.x : l.x, sy = odd ? h.y : l.y;
+          const uint32_t rx = (uint32_t)__builtin_amdgcn_mov_dpp((int)sx, 0xB1, 0xF, 0xF, true), ry = (uint32_t)__builtin_amdgcn_mov_dpp((int)sy, 0xB1, 0xF, 0xF, true);
+          if (live) {
+            if (!odd) *reinterpret_cast<uint4*>(y_hi + plane_off(row, c4 << 2, ldy, rows)) = make_uint4(h.x, h.y, rx, ry);
+            else *reinterpret_cast<uint4*>(y_lo + plane_off(row, (c4 << 2) - 4, ldy, rows)) = make_uint4(rx, ry, l.x, l.y);
+          }
+        } else if (live) {
+          *reinterpret_cast<uint2*>(y_hi + plane_off(row, c4 << 2, ldy, rows)) = h;
+          *reinterpret_cast<uint2*>(y_lo + plane_off(row, c4 << 2, ldy, rows)) = l;
+        }
+      } else if (live) {
+        *reinterpret_cast<float4*>(y + row * C + (c4 << 2)) = o;
+      }
+    }
+  }
+}
+#define LN16_C 320          /* NV = 5 */
+#define LN16_RS 2
+
 extern "C" int ddpo_layernorm_fwd(const float* x, float* y, const float* gamma, const float* beta, int rows, int C, float eps,
                                   void* stream) {
   if (!x || !y || !gamma || !beta || rows <= 0 || C <= 0 || (C & 3) || C > 256 * LN_MAXV) return DDPO_EINVAL;
   uint16_t* const no = nullptr;
-  if (C <= 512 && rows >= 4096)
+  if (C == LN16_C)
+    hipLaunchKernelGGL((layernorm_rows16_kernel<false, LN16_C / 64, LN16_RS>), dim3((rows + 16 * LN16_RS - 1) / (16 * LN16_RS)), dim3(256), 0, as_stream(stream), x, y,
+                       gamma, beta, rows, eps, no, no, 0, C);
+  else if (C <= 512 && rows >= 4096)
     hipLaunchKernelGGL(layernorm_rows_kernel<false>, dim3((rows + 4 * LN_RPW - 1) / (4 * LN_RPW)), dim3(256), 0, as_stream(stream), x, y, gamma, beta, rows, C,
                        eps, no, no, 0);
   else
@@ -353,7 +448,10 @@ extern "C" int ddpo_layernorm_fwd_planes(const float* x, uint16_t* y_hi, uint16_
   if ((reinterpret_cast<uintptr_t>(y_hi) | reinterpret_cast<uintptr_t>(y_lo)) & 7) return DDPO_EINVAL;
   float* const nof = nullptr;
   const int pair = mx ? 2 : ((C & 7) == 0 && ((reinterpret_cast<uintptr_t>(y_hi) | reinterpret_cast<uintptr_t>(y_lo)) & 15) == 0) ? 1 : 0;
-  if (C <= 512 && rows >= 4096)
+  if (C == LN16_C)
+    hipLaunchKernelGGL((layernorm_rows16_kernel<true, LN16_C / 64, LN16_RS>), dim3((rows + 16 * LN16_RS - 1) / (16 * LN16_RS)), dim3(256), 0, as_stream(stream), x, nof,
+                       gamma, beta, rows, eps, y_hi, y_lo, pair, kblocked ? 0 : C);
+  else if (C <= 512 && rows >= 4096)
     hipLaunchKernelGGL(layernorm_rows_kernel<true>, dim3((rows + 4 * LN_RPW - 1) / (4 * LN_RPW)), dim3(256), 0, as_stream(stream), x, nof, gamma, beta, rows, C,
                        eps, y_hi, y_lo, pair, kblocked ? 0 : C);
   else
