@@ -154,65 +154,70 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__
 }
 
 // Small feature maps (HW <= 256: the 16x16 and 8x8 levels, 29 of the 61 norms of an SD-1.5 forward): statistics, finalize and apply in ONE
-// launch, one workgroup per (image, group), a thread holding the group's channels of one pixel in registers (cpg = 40 / 60 / 80 floats).
+// launch, one workgroup per (image, group), its <= 256 x 80 values in registers (a thread = one channel quad of up to 22 pixels).
 // The three-launch form spends 10 + 5 + 7 us on these shapes, all of it launch latency (the data of a level is 1 - 21 MB, L2-resident).
 // Same formulas as the three kernels above: float partial sums per thread, the reduction over the group in double in a fixed order (lanes by the
 // wave butterfly, then the waves in order), var = E[x^2] - mean^2 in double, a = rstd * gamma, s = beta - mean * a, y = act(x * a + s);
 // the saved statistics (ab, mr) are written for the backward as before.  Selected by the layer's geometry ALONE (HW, channels per group), never by
 // the batch, so the sampler and the training forward of one layer always run the same arithmetic.
 #define GNF_MAXQ 20        // float4 per pixel and group: channels per group <= 80
+#define GNF_MAXP 22        // pixels per thread: ceil(256 / floor(256 / GNF_MAXQ))
 template <bool SILU, int MODE>        // MODE 0: fp32 output, 1: bf16 hi / lo planes, 2: f16mx planes
 __global__ void __launch_bounds__(256) gn_fused_small_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, uint16_t* __restrict__ y_hi,
                                                              uint16_t* __restrict__ y_lo, int ldy, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float* __restrict__ ab, float* __restrict__ mr,
                                                              int HW, int C, int G, float eps, int64_t rows_total) {
+  // thread = (pixel slot ps, channel quad q) with the quad FASTEST: the lanes of a wave read whole 160 .. 320-byte runs of consecutive pixels'
+  // group channels (the first form of this kernel gave a thread one pixel's whole run: 16 bytes per lane and cache line, 23 us per launch)
   __shared__ double s_red[2][4];
-  const int g = blockIdx.x, b = blockIdx.y, p = threadIdx.x;
+  const int g = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
   const int cpg = C / G, cq = cpg >> 2;
-  const bool live = p < HW;
-  const int64_t row = (int64_t)b * HW + (live ? p : 0);
-  const float* xr = x + row * ldx + g * cpg;
-  float4 v[GNF_MAXQ];
+  const int pps = blockDim.x / cq;                   // pixels per pass
+  const int ps = t / cq, q = t - ps * cq;
+  const bool lane_on = ps < pps;
+  const int c = g * cpg + (q << 2);
+  const float* xb = x + (int64_t)b * HW * ldx + c;
+  float4 v[GNF_MAXP];
   float sm = 0.f, sq = 0.f;
 #pragma unroll
-  for (int j = 0; j < GNF_MAXQ; ++j) {
-    v[j] = (j < cq && live) ? *reinterpret_cast<const float4*>(xr + (j << 2)) : make_float4(0.f, 0.f, 0.f, 0.f);
-    sm += v[j].x; sq += v[j].x * v[j].x;
-    sm += v[j].y; sq += v[j].y * v[j].y;
-    sm += v[j].z; sq += v[j].z * v[j].z;
-    sm += v[j].w; sq += v[j].w * v[j].w;
+  for (int i = 0; i < GNF_MAXP; ++i) {
+    const int p = ps + i * pps;
+    v[i] = (lane_on && p < HW) ? *reinterpret_cast<const float4*>(xb + (int64_t)p * ldx) : make_float4(0.f, 0.f, 0.f, 0.f);
+    sm += v[i].x; sq += v[i].x * v[i].x;
+    sm += v[i].y; sq += v[i].y * v[i].y;
+    sm += v[i].z; sq += v[i].z * v[i].z;
+    sm += v[i].w; sq += v[i].w * v[i].w;
   }
   const double wa = wave_sum_d((double)sm), wq = wave_sum_d((double)sq);
-  const int lane = p & 63, wid = p >> 6, nw = (blockDim.x + 63) >> 6;
+  const int lane = t & 63, wid = t >> 6, nw = (blockDim.x + 63) >> 6;
   if (lane == 0) { s_red[0][wid] = wa; s_red[1][wid] = wq; }
   __syncthreads();
-  double a = 0.0, q = 0.0;
-  for (int w = 0; w < nw; ++w) { a += s_red[0][w]; q += s_red[1][w]; }
+  double a = 0.0, qq = 0.0;
+  for (int w = 0; w < nw; ++w) { a += s_red[0][w]; qq += s_red[1][w]; }
   const double cnt = (double)cpg * (double)HW;
   const double mean = a / cnt;
-  double var = q / cnt - mean * mean;
+  double var = qq / cnt - mean * mean;
   if (var < 0.0) var = 0.0;
   const float rstd = (float)(1.0 / sqrt(var + (double)eps));
   const float meanf = (float)mean;
-  if (p == 0) { mr[2 * (b * G + g)] = meanf; mr[2 * (b * G + g) + 1] = rstd; }
-  for (int c = p; c < cpg; c += blockDim.x) {
-    const float k = rstd * gamma[g * cpg + c];
-    ab[2 * ((int64_t)b * C + g * cpg + c)] = k;
-    ab[2 * ((int64_t)b * C + g * cpg + c) + 1] = beta[g * cpg + c] - meanf * k;
+  if (t == 0) { mr[2 * (b * G + g)] = meanf; mr[2 * (b * G + g) + 1] = rstd; }
+  if (!lane_on) return;
+  const float4 gm = *reinterpret_cast<const float4*>(gamma + c);
+  const float4 bt = *reinterpret_cast<const float4*>(beta + c);
+  const float kx = rstd * gm.x, ky = rstd * gm.y, kz = rstd * gm.z, kw = rstd * gm.w;
+  const float sx = bt.x - meanf * kx, sy = bt.y - meanf * ky, sz = bt.z - meanf * kz, sw = bt.w - meanf * kw;
+  if (ps == 0) {                                     // the saved per-channel affine (a = rstd * gamma, s = beta - mean * a) of this quad
+    float* o = ab + 2 * ((int64_t)b * C + c);
+    *reinterpret_cast<float4*>(o) = make_float4(kx, sx, ky, sy);
+    *reinterpret_cast<float4*>(o + 4) = make_float4(kz, sz, kw, sw);
   }
-  if (!live) return;
 #pragma unroll
-  for (int j = 0; j < GNF_MAXQ; ++j) {
-    if (j >= cq) continue;
-    const int c = g * cpg + (j << 2);
-    const float4 gm = *reinterpret_cast<const float4*>(gamma + c);
-    const float4 bt = *reinterpret_cast<const float4*>(beta + c);
-    const float kx = rstd * gm.x, ky = rstd * gm.y, kz = rstd * gm.z, kw = rstd * gm.w;
+  for (int i = 0; i < GNF_MAXP; ++i) {
+    const int p = ps + i * pps;
+    if (p >= HW) continue;
+    const int64_t row = (int64_t)b * HW + p;
     float4 o;
-    o.x = v[j].x * kx + (bt.x - meanf * kx);
-    o.y = v[j].y * ky + (bt.y - meanf * ky);
-    o.z = v[j].z * kz + (bt.z - meanf * kz);
-    o.w = v[j].w * kw + (bt.w - meanf * kw);
+    o.x = v[i].x * kx + sx; o.y = v[i].y * ky + sy; o.z = v[i].z * kz + sz; o.w = v[i].w * kw + sw;
     if (SILU) { o.x = silu_f(o.x); o.y = silu_f(o.y); o.z = silu_f(o.z); o.w = silu_f(o.w); }
     if (MODE == 2) {
       mx_store4(y_hi, y_lo, row, c, ldy, rows_total, o);
@@ -267,7 +272,7 @@ static int groupnorm_fwd_impl(const float* x, int ldx, float* y, uint16_t* y_hi,
   float* ab = stats;                                  // (B, C, 2): a = rstd*gamma, s = beta - mean*a
   float* mr = stats + (size_t)B * C * 2;              // (B, G, 2): mean, rstd
   if (gn_fused_small_ok(HW, C, G)) {
-    const dim3 grid(G, B), blk(((HW + 63) / 64) * 64);
+    const dim3 grid(G, B), blk(256);
     const int64_t rt = (int64_t)B * HW;
     const int mode = planes ? (mx ? 2 : 1) : 0;
 #define GNF_LAUNCH(S, M) hipLaunchKernelGGL((gn_fused_small_kernel<S, M>), grid, blk, 0, st, x, ldx, y, y_hi, y_lo, ldy, gamma, beta, ab, mr, HW, C, G, eps, rt)
