@@ -1764,6 +1764,41 @@ extern "C" int ddpo_pack_weights_bf16_kblocked(const float* w, int K, int N, uin
   return DDPO_OK;
 }
 
+// Data-gradient planes straight from the forward kernel w (taps, Cin, Cout) (HWIO flattened; dense: taps = 1): the forward-style operand of
+// dX = dY * W' is W'[k'][n'] = w[taps - 1 - tap'][n'][co] with k' = tap' * Cout + co (taps flipped, channels transposed), K' = taps * Cout rows,
+// N' = Cin columns.  For a fixed column n' consecutive k' are consecutive co: the reads are contiguous along the same index the k-blocked
+// layout stores contiguously, so no LDS transpose is needed (one thread per element: lanes along k').  Replaces the flip / permute /
+// contiguous copy torch made of every contraction weight after every optimizer update.
+__global__ void __launch_bounds__(256) pack_weights_kblocked_dgrad_kernel(const float* __restrict__ w, int taps, int Cin, int Cout,
+                                                                          uint16_t* __restrict__ hi, uint16_t* __restrict__ lo) {
+  const int kb = blockIdx.y, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int Kd = taps * Cout;
+  const int k = kb * 32 + tx;
+  const bool kok = k < Kd;
+  const int tap = kok ? k / Cout : 0, co = k - tap * Cout;
+  const float* src = w + ((int64_t)(taps - 1 - tap) * Cin) * Cout + co;
+  for (int r = ty; r < 32; r += 8) {
+    const int n = blockIdx.x * 32 + r;
+    if (n >= Cin) continue;
+    uint32_t h = 0, l = 0;
+    if (kok) {
+      const float x = src[(int64_t)n * Cout];
+      h = cvt_pk_bf16(x, 0.f) & 0xFFFFu;
+      l = cvt_pk_bf16(x - __uint_as_float(h << 16), 0.f) & 0xFFFFu;
+    }
+    const int64_t o = ((int64_t)kb * Cin + n) * 32 + tx;
+    hi[o] = (uint16_t)h;
+    lo[o] = (uint16_t)l;
+  }
+}
+extern "C" int ddpo_pack_weights_bf16_kblocked_dgrad(const float* w, int taps, int Cin, int Cout, uint16_t* hi, uint16_t* lo, void* stream) {
+  if (!w || !hi || !lo || taps <= 0 || Cin <= 0 || Cout <= 0) return DDPO_EINVAL;
+  dim3 grid((Cin + 31) / 32, (taps * Cout + 31) / 32);
+  hipLaunchKernelGGL(pack_weights_kblocked_dgrad_kernel, grid, dim3(256), 0, as_stream(stream), w, taps, Cin, Cout, hi, lo);
+  DDPO_LAUNCH_CHECK();
+  return DDPO_OK;
+}
+
 extern "C" int ddpo_pack_weights_bf16(const float* w, int K, int N, int Kp, uint16_t* fwd_hi, uint16_t* fwd_lo, uint16_t* bwd_hi,
                                       uint16_t* bwd_lo, void* stream) {
   if (!w || !fwd_hi || !fwd_lo || K <= 0 || N <= 0 || Kp < K || (Kp & 7) || (bwd_hi && !bwd_lo)) return DDPO_EINVAL;

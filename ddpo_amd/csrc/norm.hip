@@ -160,6 +160,8 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__
 // wave butterfly, then the waves in order), var = E[x^2] - mean^2 in double, a = rstd * gamma, s = beta - mean * a, y = act(x * a + s);
 // the saved statistics (ab, mr) are written for the backward as before.  Selected by the layer's geometry ALONE (HW, channels per group), never by
 // the batch, so the sampler and the training forward of one layer always run the same arithmetic.
+// (A 1024-thread form of the same kernel for the 32x32 level — 16 pixels per thread — was built and measured: 4.199 vs 4.207 images/s for the
+// three launches there, profiles/r05_ab_gn_fused3.log; not kept.)
 #define GNF_MAXQ 20        // float4 per pixel and group: channels per group <= 80
 #define GNF_MAXP 22        // pixels per thread: ceil(256 / floor(256 / GNF_MAXQ))
 template <bool SILU, int MODE>        // MODE 0: fp32 output, 1: bf16 hi / lo planes, 2: f16mx planes

@@ -80,6 +80,7 @@ _SIGS = {
     "ddpo_layernorm_fwd_planes": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p]),
     "ddpo_pack_weights_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ddpo_pack_weights_bf16_kblocked": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "ddpo_pack_weights_bf16_kblocked_dgrad": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "ddpo_pack_weights_f16mx": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ddpo_split_planes_f16mx": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p]),
     "ddpo_gemm_conv_fwd_f16mx_planes": (c_int, [POINTER(GemmDesc), c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -483,6 +484,11 @@ def _p_rows(t):
     return c_void_p(t.data_ptr())
 
 
+def _pr(t, ld):
+    """Pointer of an operand passed with an explicit row stride `ld` (a column slice of a wider row-major matrix) or, ld falsy, contiguous."""
+    return _p_rows(t) if ld else _p(t)
+
+
 def _f32(t, name="tensor"):
     if t.dtype != torch.float32 or not t.is_cuda:
         raise DdpoHipError(f"{name} must be a float32 CUDA tensor, got {t.dtype} on {t.device}")
@@ -719,15 +725,16 @@ def pack_weights(w, bwd=True):
 def _pack_dgrad_planes(w, ent):
     """ent["dg"]: forward-style planes of the data-gradient weight of `w` — conv (kh, kw, ci, co): W'[ky, kx, co, ci] = W[kh-1-ky, kw-1-kx, ci, co],
     i.e. K' = kh * kw * co reduction rows, N' = ci output columns; dense (K, N): W^T, K' = N, N' = K."""
-    wt = w.flip(0, 1).permute(0, 1, 3, 2).contiguous() if w.dim() == 4 else w.t().contiguous()
-    Nd = wt.shape[-1]
-    Kd = wt.numel() // Nd
+    taps = w.shape[0] * w.shape[1] if w.dim() == 4 else 1
+    Nd, cout = (w.shape[2], w.shape[3]) if w.dim() == 4 else (w.shape[0], w.shape[1])
+    Kd = taps * cout
     Kp = (Kd + 31) // 32 * 32
     dg = ent.get("dg")
     if dg is None or dg["K"] != Kd or dg["N"] != Nd:
         mk = lambda *sh: torch.zeros(*sh, dtype=torch.int16, device=w.device)
         dg = ent["dg"] = dict(K=Kd, N=Nd, hi=mk(Nd, Kp), lo=mk(Nd, Kp))
-    _check(load().ddpo_pack_weights_bf16_kblocked(_p(wt), Kd, Nd, _p(dg["hi"]), _p(dg["lo"]), _stream()), "ddpo_pack_weights_bf16_kblocked")
+    # packed straight from w (ABI v13): no flipped / transposed fp32 copy after every optimizer update (ADVICE r04)
+    _check(load().ddpo_pack_weights_bf16_kblocked_dgrad(_p(w), taps, Nd, cout, _p(dg["hi"]), _p(dg["lo"]), _stream()), "ddpo_pack_weights_bf16_kblocked_dgrad")
     # NO f16mx planes for data gradients, on any datapath: the f16mx ACTIVATION planes carry no scale (f16 + e5m2 at the value's own exponent),
     # which is right for O(1) activations and wrong for dY — PPO / RWR gradients sit at 1e-7 .. 1e-3, i.e. in f16's subnormal range: measured
     # on hardware (round 4, full-size SD-1.5 / SD-2.1 train step) ||g - g_ref|| / ||g_ref|| went from 7e-5 to 1e-2 .. 4e-2 with f16mx data
@@ -1064,7 +1071,7 @@ def attention(q, k, v, B, heads, Nq, Nk, d, scale=None, out=None, ldq=None, ldk=
         ws = _scratch(nb, q.device, "attn_kv") if nb else None
         fn, name = (load().ddpo_attention_fwd_f16p_po, "ddpo_attention_fwd_f16p_po") if _mx() else \
             (load().ddpo_attention_fwd_bf16x3_po, "ddpo_attention_fwd_bf16x3_po")
-        _check(fn(_p(q), int(ldq or C), _p(k), int(ldk or C), _p(v), int(ldv or C), _p(opl.hi), _p(opl.lo), opl.ld,
+        _check(fn(_pr(q, ldq), int(ldq or C), _pr(k, ldk), int(ldk or C), _pr(v, ldv), int(ldv or C), _p(opl.hi), _p(opl.lo), opl.ld,
                   None, B, heads, Nq, Nk, d, sc, _p(ws), nb, _stream()), name)
         return opl
     if out is None:
@@ -1075,10 +1082,10 @@ def attention(q, k, v, B, heads, Nq, Nk, d, scale=None, out=None, ldq=None, ldk=
         ws = _scratch(nb, q.device, "attn_kv") if nb else None
         # the f16mx datapath's attention is the f16p operator (probabilities as one f16 term, two second-product passes); bf16x3 keeps three
         fn, name = (load().ddpo_attention_fwd_f16p, "ddpo_attention_fwd_f16p") if _mx() else (load().ddpo_attention_fwd_bf16x3, "ddpo_attention_fwd_bf16x3")
-        _check(fn(_p(q), int(ldq or C), _p(k), int(ldk or C), _p(v), int(ldv or C), _p(out), int(ldo or C),
+        _check(fn(_pr(q, ldq), int(ldq or C), _pr(k, ldk), int(ldk or C), _pr(v, ldv), int(ldv or C), _p(out), int(ldo or C),
                   _p(lse), B, heads, Nq, Nk, d, sc, _p(ws), nb, _stream()), name)
     else:
-        _check(load().ddpo_attention_fwd(_p(q), int(ldq or C), _p(k), int(ldk or C), _p(v), int(ldv or C), _p(out), int(ldo or C),
+        _check(load().ddpo_attention_fwd(_pr(q, ldq), int(ldq or C), _pr(k, ldk), int(ldk or C), _pr(v, ldv), int(ldv or C), _p(out), int(ldo or C),
                                          _p(lse), B, heads, Nq, Nk, d, sc, _stream()), "ddpo_attention_fwd")
     return (out, lse) if return_lse else out
 

@@ -62,6 +62,7 @@ class ParamStore:
         self.n_params = sum(math.prod(s) for s in self.shapes.values())
         self.flat = torch.zeros(off, dtype=torch.float32, device=device)
         self.views = {n: self.flat[o:o + math.prod(self.shapes[n])].view(self.shapes[n]) for n, o in self.offsets.items()}
+        self.fused_qkv = {}               # "<…>.attn1." -> (K, 3C) fp32 copy [to_q | to_k | to_v] of a self-attention's projections (pack_bf16)
 
     def __getitem__(self, name):
         return self.views[name]
@@ -88,6 +89,18 @@ class ParamStore:
                 L.pack_weights(v, bwd=bwd)
                 if n.endswith(".ff.net_0.proj.kernel"):          # GEGLU feed-forward: extra planes for the fused forward
                     L.pack_weights_geglu(v, self.views[n[:-len("kernel")] + "bias"])
+                if QKV_FUSED and n.endswith(".attn1.to_q.kernel"):
+                    # self-attention of the SAMPLING forward: q, k, v as ONE (K, 3C) projection of the LayerNorm output (round 5).  Three launches
+                    # of N = C columns become one of 3C: at the 16x16 level (M = 4096 at batch 16) that is 128 x 320 tiles instead of 128 x 64
+                    # ones — 2.1x fewer operand bytes through the L2 -> LDS stream these short reductions are bound by — and two kernel
+                    # boundaries less everywhere.  Same k order per column: bit-identical to the three projections.
+                    pre = n[:-len("to_q.kernel")]
+                    parts = [v, self.views[pre + "to_k.kernel"], self.views[pre + "to_v.kernel"]]
+                    buf = self.fused_qkv.get(pre)
+                    if buf is None:
+                        buf = self.fused_qkv[pre] = torch.empty(v.shape[0], sum(t.shape[1] for t in parts), dtype=torch.float32, device=v.device)
+                    torch.cat(parts, dim=1, out=buf)
+                    L.pack_weights(buf, bwd=False)
 
     def init_synthetic(self, seed=0):
         """Random-init weights of the right architecture (no checkpoints are reachable offline)."""
@@ -187,6 +200,7 @@ SKIP_INPLACE = os.environ.get("DDPO_SKIP_INPLACE", "1") == "1"
 H3_PLANES = os.environ.get("DDPO_H3_PLANES", "1") == "1"
 # sampling: the attention kernels hand their result to to_out as planes (see _attention); 0 restores the fp32 hand-over (A/B switch)
 ATTN_PLANES = os.environ.get("DDPO_ATTN_PLANES", "1") == "1"
+QKV_FUSED = os.environ.get("DDPO_QKV_FUSED", "1") == "1"       # sampling self-attention: q / k / v as one (K, 3C) projection (ParamStore.pack_bf16)
 
 
 class Act:
@@ -307,9 +321,13 @@ class UNet2DCondition:
         103 -> 62 us per launch in the model, profiles/r04_timeline_sampling_step.txt) — the bf16 hi / lo planes the attention kernel's output
         stage writes instead (the same values, so the block's result does not change by a bit)."""
         P = self.params
-        q = L.linear(x, P[name + ".to_q.kernel"])
         po = bool(rec is None and ATTN_PLANES and L.PLANES_OUT and L.attention_planes_ok(C // heads) and
                   L.planes_pay(P[name + ".to_out_0.kernel"], C, B * N) == 1)
+        fq = P.fused_qkv.get(name + ".") if (QKV_FUSED and ctx is None and rec is None and L.current_datapath() != "fp32") else None
+        if fq is not None and L.PACKED.get(fq.data_ptr()) is not None:      # sampling self-attention: one projection launch for q, k, v
+            qkv = L.linear(x, fq)
+            return L.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], B, heads, N, N, C // heads, planes_out=po, ldq=3 * C, ldk=3 * C, ldv=3 * C)
+        q = L.linear(x, P[name + ".to_q.kernel"])
         cached = self._ctx_kv.get((name, ctx.shape[0])) if (ctx is not None and rec is None and self._ctx_kv_active) else None
         if cached is not None:                     # text-context K / V were projected once for this sampling call
             k, v = cached[0], cached[1]

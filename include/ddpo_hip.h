@@ -263,6 +263,11 @@ int ddpo_pack_weights_f16mx(const float* w, int K, int N, uint16_t* w16, uint16_
 int ddpo_split_planes_f16mx(const float* x, int ldx, uint16_t* p16, uint16_t* p8, int ld_out, int64_t rows, int cols, void* stream);
 /* fp32 W (K, N) -> bf16 hi / lo planes in the k-blocked forward layout (ceil(K / 32), N, 32), zero padded in k (w_layout = 1). */
 int ddpo_pack_weights_bf16_kblocked(const float* w, int K, int N, uint16_t* fwd_hi, uint16_t* fwd_lo, void* stream);
+/* ABI v13.  The DATA-GRADIENT operand of the layer with forward kernel w (taps, Cin, Cout) (HWIO flattened; dense layer: taps = 1), packed straight from
+ * w into the same k-blocked layout: W'[tap' * Cout + co][ci] = w[taps - 1 - tap'][ci][co], i.e. (ceil(taps * Cout / 32), Cin, 32) planes — what
+ * ddpo_gemm_conv_fwd_bf16[_planes] reads to compute dX as a forward contraction of dY (/root/reference/ddpo/training/policy_gradient.py:104-139,
+ * the jax.grad of the U-Net call).  Same values as packing the flipped / transposed copy of w with ddpo_pack_weights_bf16_kblocked. */
+int ddpo_pack_weights_bf16_kblocked_dgrad(const float* w, int taps, int Cin, int Cout, uint16_t* hi, uint16_t* lo, void* stream);
 /* x:(rows, cols) fp32, row stride ldx -> hi / lo bf16 planes (rows, ld_out): hi = bf16(x), lo = bf16(x - hi). */
 int ddpo_split_planes_bf16(const float* x, int ldx, uint16_t* hi, uint16_t* lo, int ld_out, int64_t rows, int cols,
                            void* stream);

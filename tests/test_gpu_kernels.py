@@ -153,7 +153,8 @@ def test_adamw_matches_oracle(mu_bf16):
 
 
 # ------------------------------------------------------------------------------------------------ norms / elementwise
-@pytest.mark.parametrize("B,HW,C", [(2, 64, 32), (2, 64, 96), (3, 256, 320), (2, 1024, 640), (2, 64, 1280), (2, 64, 1920), (1, 64, 2560), (2, 4096, 128)])
+@pytest.mark.parametrize("B,HW,C", [(2, 64, 32), (2, 64, 96), (3, 256, 320), (2, 1024, 640), (2, 64, 1280), (2, 64, 1920), (1, 64, 2560), (2, 4096, 128),
+                                    (2, 256, 2560), (2, 1024, 1920), (2, 900, 1280), (1, 1024, 2560)])      # round 5: the one-launch form (HW <= 256) at its widest group, and 32x32-level shapes on the three-launch path
 @pytest.mark.parametrize("silu", [True, False])
 def test_groupnorm(B, HW, C, silu):
     g = torch.Generator().manual_seed(0)

@@ -385,6 +385,46 @@ def test_skip_concat_in_place_is_bit_identical_to_copies(family, ctx_dim, datapa
     assert torch.equal(unet.forward(x, t, c, tape=[]), out[True][0])
 
 
+@pytest.mark.parametrize("family,ctx_dim,datapath,planes_all", [("tiny", 64, "bf16x3", False), ("tiny21", 96, "bf16x3", True), ("tiny", 64, "f16mx", True)])
+def test_fused_qkv_projection_of_the_sampling_self_attention_is_bit_identical(family, ctx_dim, datapath, planes_all, monkeypatch):
+    """Round 5: the sampling forward projects q, k, v of a self-attention in ONE launch on the (K, 3C) concatenation of the three kernels
+    (ParamStore.pack_bf16 keeps it next to them) and hands the attention column slices of the result (row stride 3C).  Every column
+    accumulates in the same k order as in its own projection, so the U-Net output must not move by a bit — fp32-fed and plane-fed, eagerly and
+    under graph replay — and the fused path must actually have been taken (strided q / k / v reach the attention entry)."""
+    from ddpo_amd.models import unet as U
+    monkeypatch.setattr(L, "DATAPATH", datapath)
+    monkeypatch.setattr(L, "PLANES_ALL", planes_all)
+    if datapath == "f16mx":
+        monkeypatch.setattr(L, "MX_MIN_K", 256)
+    unet = UNet2DCondition(UNetConfig.named(family), DEV)
+    unet.params.init_synthetic(4)
+    unet.params.pack_bf16(bwd=False)
+    assert len(unet.params.fused_qkv) == len([n for n in unet.params.views if n.endswith(".attn1.to_q.kernel")]) > 0
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(4, 4, 16, 16, generator=g).to(DEV)
+    t = torch.tensor([981, 21, 501, 481], dtype=torch.int32, device=DEV)
+    c = torch.randn(4, 77, ctx_dim, generator=g).to(DEV)
+    strided = {"n": 0}
+    real_attn = L.attention
+
+    def attn(*a, **kw):
+        strided["n"] += bool(kw.get("ldq"))
+        return real_attn(*a, **kw)
+
+    monkeypatch.setattr(L, "attention", attn)
+    out = {}
+    for on in (False, True):
+        monkeypatch.setattr(U, "QKV_FUSED", on)
+        out[on] = unet(x, t, c).clone()
+    assert strided["n"] == len(unet.params.fused_qkv)            # every self-attention of the fused forward, none of the unfused one
+    assert torch.equal(out[True], out[False])
+    unet.params["down_blocks_0.attentions_0.transformer_blocks_0.attn1.to_k.kernel"].mul_(1.5)      # an "optimizer update": re-packing refreshes the copy
+    unet.params.pack_bf16(bwd=False)
+    o2 = unet(x, t, c)
+    monkeypatch.setattr(U, "QKV_FUSED", False)
+    assert torch.equal(o2, unet(x, t, c)) and not torch.equal(o2, out[True])
+
+
 @pytest.mark.parametrize("family,ctx_dim,datapath", [("tiny", 64, "bf16x3"), ("tiny21", 96, "bf16x3"), ("tiny", 64, "f16mx")])
 def test_plane_handover_behind_attention_and_ff2_is_bit_identical(family, ctx_dim, datapath, monkeypatch):
     """Round 4: in the sampling forward the attention kernels hand their result to to_out, and the second feed-forward GEMM hands h3 to

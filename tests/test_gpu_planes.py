@@ -341,3 +341,27 @@ def test_kblocked_activation_planes_are_bit_identical_to_row_major(monkeypatch, 
             assert float((a - b_).abs().max()) <= 2e-6 * float(b_.abs().max()) + 1e-7
         else:
             assert torch.equal(a, b_), i
+
+
+@pytest.mark.parametrize("shape", [(3, 3, 64, 96), (3, 3, 320, 320), (1, 1, 96, 40), (640, 320), (100, 72)])
+def test_dgrad_planes_packed_straight_from_w_equal_the_planes_of_the_flipped_transposed_copy(shape):
+    """ADVICE r04 / ABI v13: ddpo_pack_weights_bf16_kblocked_dgrad writes the data-gradient operand W'[tap' * Cout + co][ci] =
+    w[taps - 1 - tap'][ci][co] from the forward kernel directly; rounds 3-4 materialised the flipped / transposed fp32 copy with torch after
+    every optimizer update and packed that.  Same planes bit for bit, ragged K' (zero padded to whole 32-blocks) included."""
+    import ctypes
+    g = torch.Generator().manual_seed(sum(shape))
+    w = torch.randn(*shape, generator=g).to("cuda")
+    wt = w.flip(0, 1).permute(0, 1, 3, 2).contiguous() if w.dim() == 4 else w.t().contiguous()
+    Nd = wt.shape[-1]
+    Kd = wt.numel() // Nd
+    Kp = (Kd + 31) // 32 * 32
+    mk = lambda: torch.full((Nd, Kp), 0x5555, dtype=torch.int16, device="cuda")
+    rh, rl, nh, nl = mk(), mk(), mk(), mk()
+    lib = L.load()
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    assert lib.ddpo_pack_weights_bf16_kblocked(p(wt), Kd, Nd, p(rh), p(rl), None) == 0
+    taps = shape[0] * shape[1] if len(shape) == 4 else 1
+    cin, cout = (shape[2], shape[3]) if len(shape) == 4 else shape
+    assert lib.ddpo_pack_weights_bf16_kblocked_dgrad(p(w), taps, cin, cout, p(nh), p(nl), None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(nh, rh) and torch.equal(nl, rl)
