@@ -516,6 +516,8 @@ __global__ void __launch_bounds__(256) layernorm_rows16_kernel(const float* __re
     }
   }
 }
+/* (C = 640 on the same kernel, NV = 10, one row set: measured 4.2525 vs 4.2479 images/s = nothing, profiles/r05_ab_ln16_640.log — those launches already
+ * move their 84 MB at 4.5 - 5.3 TB/s; not kept.) */
 #define LN16_C 320          /* NV = 5 */
 #define LN16_RS 2
 

@@ -21,6 +21,8 @@ N=2 timeout 900 bash tools/pmc_unet_traffic.sh > gpurun_out/r05_pmc_traffic.log 
 # stamp it into profiles/roofline_traffic.json ON THE BOX so the bench line below carries it (re-run tools/stamp_traffic.py locally afterwards: adds the git commit)
 python tools/stamp_traffic.py f16mx > /dev/null 2>&1 && cp profiles/roofline_traffic.json gpurun_out/roofline_traffic_stamped.json
 timeout 900 python bench.py > gpurun_out/r05_bench_final.log 2>&1; echo "exit $?" >> gpurun_out/r05_bench_final.log; tail -2 gpurun_out/r05_bench_final.log | cut -c1-1500
+# for the record (not part of the suite: 4x the oracle time): TWO micro-batches of the reference's b = 2 through ONE fused launch, against the oracle's two accumulated steps
+DDPO_TRAIN_PARITY_FUSE=2 DDPO_PARITY_LOG=$R/gpurun_out/r05_parity_train_fused.log timeout 900 python -m pytest tests/test_gpu_train_parity.py -k sd15_full_size -m gpu -q -p no:cacheprovider 2>&1 | tail -2; cat gpurun_out/r05_parity_train_fused.log | cut -c1-300
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_s6 -o bench -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-train-extra --no-alt-datapath-extra > $R/gpurun_out/prof_s6.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_t6 -o bench -- python $R/bench.py --mode train --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > $R/gpurun_out/prof_t6.log 2>&1
