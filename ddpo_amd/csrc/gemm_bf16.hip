@@ -1148,11 +1148,12 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 64 ? 3 : 1)) g
       if constexpr (APL == 6) {
         // GEGLU on the tall tile (round 5; its own instantiation, APL = 6, so that the plain tall tile's code does not change by an instruction).  The weight columns of tile t come as [a (160) | gate (160)] of output columns 160 t .. 160 t + 159
         // (ddpo_gemm_desc.epilogue == 2), so the wave pair (wm, 0) / (wm, 1) holds the value and the gate accumulators of the SAME 64 x 160
-        // outputs.  Per 32-row pass: both waves add their bias IN REGISTERS (a lane's column is fixed per accumulator block), the gate wave
-        // applies gelu_tanh there too, both transpose into their LDS slices (adjacent: wid = 2 wm + wn); one barrier; then each wave of the
-        // pair multiplies and emits 16 of the 32 rows (40 float4 per row, 10 wave instructions), so all eight waves store.  Same arithmetic
-        // per element as the 128 x 128 GEGLU tile — (acc_a + b_a) * gelu_tanh(acc_g + b_g) on the same accumulation order — so the two
-        // tiles agree bit for bit (tests/test_gpu_bf16.py::test_linear_geglu_tall_tile_is_bit_identical).
+        // outputs.  Per 32-row pass: both waves add their bias IN REGISTERS (a lane's column is fixed per accumulator block) and transpose
+        // the pre-activations into their LDS slices (adjacent: wid = 2 wm + wn); one barrier; then each wave of the pair takes 16 of the 32
+        // rows (40 float4 per row, 10 wave instructions): gelu_tanh of the gate, the product, the stores — and, for the training forward,
+        // the pre-activation rows in the original [a | gate] column order (aux_out) — so the gelus and the stores are spread over all eight
+        // waves.  Same arithmetic per element as the 128 x 128 GEGLU tile — (acc_a + b_a) * gelu_tanh(acc_g + b_g) on the same accumulation
+        // order — so the two tiles agree bit for bit (tests/test_gpu_bf16.py::test_linear_geglu_tall_tile_is_bit_identical).
         static_assert(WN == 2 && WTN == 160, "value / gate wave pairs of 160 columns");
         const int oc0 = (n0 / 320) * 160;                  // first OUTPUT column of this tile
         float bj[TN];
@@ -1167,9 +1168,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 64 ? 3 : 1)) g
           for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              float v = acc[ih][j][r] + bj[j];
-              if (wn == 1) v = gelu_tanh_f(v);
-              cw[((r & 3) + 8 * (r >> 2) + 4 * khalf) * WTN + j * 32 + (lane & 31)] = v;
+              cw[((r & 3) + 8 * (r >> 2) + 4 * khalf) * WTN + j * 32 + (lane & 31)] = acc[ih][j][r] + bj[j];
             }
           __syncthreads();
           constexpr int GL = WTN / 4;                      // float4 per output row
@@ -1180,9 +1179,14 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 64 ? 3 : 1)) g
             const int e = it * 64 + ln, rr = wn * 16 + e / GL, c4 = (e - (e / GL) * GL) * 4;
             const float4 a = *reinterpret_cast<const float4*>(ca + rr * WTN + c4);
             const float4 g = *reinterpret_cast<const float4*>(cg + rr * WTN + c4);
-            const float4 o = make_float4(a.x * g.x, a.y * g.y, a.z * g.z, a.w * g.w);
+            const float4 o = make_float4(a.x * gelu_tanh_f(g.x), a.y * gelu_tanh_f(g.y), a.z * gelu_tanh_f(g.z), a.w * gelu_tanh_f(g.w));
             const int row = m0 + wm * WTM + ih * 32 + rr, col = oc0 + c4;
             if (row >= d.M) continue;
+            if (d.aux_out) {                               // pre-activation in the original [a | gate] column order (training forward)
+              float* pa = d.aux_out + (int64_t)row * d.N + col;
+              *reinterpret_cast<float4*>(pa) = a;
+              *reinterpret_cast<float4*>(pa + (d.N >> 1)) = g;
+            }
             if (d.out) st_out4(d.out + (int64_t)row * d.ld_out + col, o);
             if (d.out_hi) store_planes4(d, row, col, o);
           }
@@ -1550,7 +1554,7 @@ static int dispatch_bf16(const ddpo_gemm_desc& d, const uint16_t* w_hi, const ui
     if (reinterpret_cast<uintptr_t>(d.aux_out) & 15) return DDPO_EINVAL;
     if (d.epilogue == 2) {     // the tall 256 x 320 tile with value / gate wave pairs: plane-fed bf16x3 only, columns in [a (160) | gate (160)] blocks
       if constexpr (APL == 3) {
-        if (npass != 3 || d.N % 320 || d.aux_out || ((d.N >> 1) & 3)) return DDPO_EINVAL;
+        if (npass != 3 || d.N % 320 || ((d.N >> 1) & 3)) return DDPO_EINVAL;
         return launch_bf16_tall<6>(d, w_hi, w_lo, ldw, st);
       }
       return DDPO_EINVAL;

@@ -841,7 +841,7 @@ def pack_weights_geglu(w, bias):
 
 def geglu_tall_pays(w, rows):
     """True when the fused FF1 + GEGLU of weight `w` on `rows` rows should run on the 256 x 320 tile (epilogue = 2): registered with the tall column
-    order, no pre-activation wanted (sampling), and the grid of tall tiles fills whole rounds of the 256 CUs well — the same rule as the C++ dispatch
+    order and the grid of tall tiles fills whole rounds of the 256 CUs well — the same rule as the C++ dispatch
     applies to the plain tall tile (>= 200 tiles, round efficiency within 8 % of the 128 x 320 grid's).  The caller then feeds bf16 hi / lo PLANES
     (LayerNorm `planes=1`).  Why: at K = 320 .. 1280 the 128 x 128 GEGLU tile streams 16 MAC per operand byte and FF1 sits on the chip's L2 -> LDS
     stream (3.3 GB per launch at the 64 x 64 level = 8 TB/s); the tall tile moves 35 MAC per byte."""
@@ -887,7 +887,7 @@ def linear_geglu(x, w, out=None, planes_out=False, pre_out=False):
         if out is None:
             out = torch.empty(M, N // 2, dtype=torch.float32, device=x.device)
         d.out = out.data_ptr(); d.ld_out = N // 2
-    tall = pl is not None and pl.fmt == 0 and not pre_out and geglu_tall_pays(w, M)
+    tall = pl is not None and pl.fmt == 0 and geglu_tall_pays(w, M)
     gw = g["tall"] if tall else g
     d.src = x.data_ptr(); d.ld_src = K
     d.bias = gw["bias"].data_ptr()

@@ -184,7 +184,7 @@ typedef struct {
                                         needs N % 128 == 0, K % 32 == 0, no rowbias / residual, alpha == 1
                                      2: GEGLU on the 256 x 320 tile (ABI v13; ddpo_gemm_conv_fwd_bf16_planes only).  The columns of W / bias come
                                         as 320-column blocks [a (160) | gate (160)]: block t holds the value and gate columns of the output
-                                        columns 160 t .. 160 t + 159; same formula, bit-identical results; needs N % 320 == 0, no aux_out */
+                                        columns 160 t .. 160 t + 159; same formula, bit-identical results (aux_out included); needs N % 320 == 0 */
   /* plane-emitting output stage (ddpo_gemm_conv_fwd_bf16 / _planes on the buffer-addressed kernels only; NULL elsewhere).
    * When out_hi != NULL the final value v of every output element is ALSO written as bf16 hi / lo planes
    * (hi = bf16(v), lo = bf16(v - hi): the operand format of ddpo_gemm_conv_fwd_bf16_planes, bit for bit what the

@@ -126,14 +126,17 @@ def test_linear_geglu_tall_tile_is_bit_identical(datapath, M, K, F, monkeypatch)
     before = L.gemm_tile_launch_counts()
     tall = L.linear_geglu(xp, w)
     tall_pl = L.linear_geglu(xp, w, planes_out=1)
-    assert L.gemm_tile_launch_counts()["tall_256x320"] - before["tall_256x320"] == 2
+    tall2, tall_pre = L.linear_geglu(xp, w, pre_out=True)            # training forward: the same launch also stores the pre-activation
+    assert L.gemm_tile_launch_counts()["tall_256x320"] - before["tall_256x320"] == 3
     monkeypatch.setattr(L, "GEGLU_TALL", False)
     assert not L.geglu_tall_pays(w, M)
     before = L.gemm_tile_launch_counts()
     ref = L.linear_geglu(xp, w)
     ref_pl = L.linear_geglu(xp, w, planes_out=1)
+    ref2, ref_pre = L.linear_geglu(xp, w, pre_out=True)
     assert L.gemm_tile_launch_counts()["tall_256x320"] == before["tall_256x320"]
-    assert torch.equal(tall, ref)
+    assert torch.equal(tall, ref) and torch.equal(tall2, ref) and torch.equal(ref2, ref)
+    assert torch.equal(tall_pre, ref_pre) and torch.equal(L.geglu(tall_pre), tall)
     assert torch.equal(tall_pl.hi, ref_pl.hi) and torch.equal(tall_pl.lo, ref_pl.lo)
     f64 = x[:512].cpu().double() @ w.cpu().double() + b.cpu().double()
     assert _rel(tall[:512], f64[:, :F] * TF.gelu(f64[:, F:], approximate="tanh")) < TOL["bf16x3"]
