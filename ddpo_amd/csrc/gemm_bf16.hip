@@ -718,10 +718,12 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 64 ? 3 : 1)) g
     auto fill = [&](int stage) {
       const uint32_t so_a = (uint32_t)(cib >> 5) * a_kt_b, so_w = (uint32_t)kt_next * w_kt_b;
       const uint32_t la = lds_a + stage * STAGE, lw = lds_w + stage * STAGE;
+      if (!DBG_ABL(4) || (kt_next - kt0) % 9 < 2) {         // timing ablation 4: the activation bytes of a halo loader (2 of 9 k-tiles)
 #pragma unroll
       for (int i = 0; i < NA; ++i)
         asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                      :: "s"(la + i * (PAIRS * 1024)), "v"(avoff[i]), "s"(rs_a), "s"(so_a) : "memory");
+      }
 #pragma unroll
       for (int i = 0; i < NB; ++i)
         asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
@@ -807,12 +809,16 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 64 ? 3 : 1)) g
       const uint32_t lds_a3 = lds0 + plane * A_BYTES + pr * 1024;
       const uint32_t lds_w3 = lds0 + 2 * A_STAGE + plane * B_BYTES + pr * 1024;
       int kw_next = kt0;                                   // tap / cib / set_tap follow the ACTIVATION tiles
+      int ka_next = 0;                                     // (timing ablation 4 only)
       auto fill_a = [&](int stage) {
         const uint32_t so_a = (uint32_t)(cib >> 5) * a_kt_b, la = lds_a3 + stage * A_STAGE;
+        if (!DBG_ABL(4) || ka_next % 9 < 2) {
 #pragma unroll
         for (int i = 0; i < NA; ++i)
           asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                        :: "s"(la + i * (PAIRS * 1024)), "v"(avoff[i]), "s"(rs_a), "s"(so_a) : "memory");
+        }
+        ++ka_next;
         cib += BK;
         if (cib >= cin) {
           cib = 0; ++tap;
@@ -901,7 +907,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 64 ? 3 : 1)) g
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (kt == 0) DBG_T(1);
-        if (kt + 1 < nk && !late) fill(cur ^ 1);
+        if (kt + 1 < nk && !late && !DBG_ABL(1)) fill(cur ^ 1);
         // phase 1: the two f16 products of every accumulator (k halves 0 and 1 of the k-tile)
         {
           bf16x8 ah0[TM], ah1[TM];
@@ -914,6 +920,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 64 ? 3 : 1)) g
           for (int j = 0; j < TN; ++j) {
             const bf16x8 bh0 = *reinterpret_cast<const bf16x8*>(sb + b_ld0 + j * 2048);
             const bf16x8 bh1 = *reinterpret_cast<const bf16x8*>(sb + b_ld1 + j * 2048);
+            if (DBG_ABL(2)) { asm volatile("" :: "v"(ah0[0]), "v"(ah1[TM - 1]), "v"(bh0), "v"(bh1)); continue; }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah0[i]), __builtin_bit_cast(f16x8, bh0), acc[i][j], 0, 0, 0);
@@ -923,7 +930,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 64 ? 3 : 1)) g
             __builtin_amdgcn_sched_barrier(0);
           }
         }
-        if (kt + 1 < nk && late) fill(cur ^ 1);
+        if (kt + 1 < nk && late && !DBG_ABL(1)) fill(cur ^ 1);
         // phase 2: the MX product (both cross terms of the whole k-tile in one 32x32x64 MFMA per accumulator)
         {
           i32x8 a8[TM];
@@ -936,6 +943,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 64 ? 3 : 1)) g
           for (int j = 0; j < TN; ++j) {
             const i32x4 x = *reinterpret_cast<const i32x4*>(sb + b_ld0 + B_BYTES + j * 2048), y = *reinterpret_cast<const i32x4*>(sb + b_ld1 + B_BYTES + j * 2048);
             const i32x8 b8 = i32x8{x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
+            if (DBG_ABL(2)) { asm volatile("" :: "v"(a8[0]), "v"(a8[TM - 1]), "v"(b8)); continue; }
 #pragma unroll
             for (int i = 0; i < TM; ++i) acc[i][j] = mx_mfma(a8[i], b8, acc[i][j], mx_sa, j & 3, mx_sbp[j >> 2]);
             __builtin_amdgcn_sched_barrier(0);
@@ -1694,6 +1702,9 @@ extern "C" int ddpo_gemm_conv_fwd_f16mx_planes(const ddpo_gemm_desc* dp, const u
   d.ld_src = lda;
   if (!buf_path_ok(d, 0)) return DDPO_EINVAL;
   d.splits = 1;
+#ifdef DDPO_KLOOP_TIMING
+  { const char* e = getenv("DDPO_DBG_ABL"); if (e) d.splits |= atoi(e) << 4; }
+#endif
   return dispatch_bf16<3>(d, w16, w8, 0, 4, ws, ws_bytes, as_stream(stream));
 }
 

@@ -273,7 +273,9 @@ static int groupnorm_fwd_impl(const float* x, int ldx, float* y, uint16_t* y_hi,
   double* part = reinterpret_cast<double*>(ws);
   float* ab = stats;                                  // (B, C, 2): a = rstd*gamma, s = beta - mean*a
   float* mr = stats + (size_t)B * C * 2;              // (B, G, 2): mean, rstd
-  if (gn_fused_small_ok(HW, C, G)) {
+  // (the one-launch form reads gamma / beta as float4: 16-byte aligned parameter vectors only — ParamStore views are; anything else keeps
+  // the three-launch form's scalar reads — ADVICE r05)
+  if (gn_fused_small_ok(HW, C, G) && ((reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 15) == 0) {
     const dim3 grid(G, B), blk(256);
     const int64_t rt = (int64_t)B * HW;
     const int mode = planes ? (mx ? 2 : 1) : 0;

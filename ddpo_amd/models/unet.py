@@ -93,7 +93,12 @@ class ParamStore:
                     # self-attention of the SAMPLING forward: q, k, v as ONE (K, 3C) projection of the LayerNorm output (round 5).  Three launches
                     # of N = C columns become one of 3C: at the 16x16 level (M = 4096 at batch 16) that is 128 x 320 tiles instead of 128 x 64
                     # ones — 2.1x fewer operand bytes through the L2 -> LDS stream these short reductions are bound by — and two kernel
-                    # boundaries less everywhere.  Same k order per column: bit-identical to the three projections.
+                    # boundaries less everywhere.  Same products in the same k order per column; the bits equal the three projections' wherever both
+                    # shapes take the same split-K decision (the tile / split choice depends on the column count: at M = 1024, K = N = 1280
+                    # the separate projections run 128 x 64 tiles with the reduction split in three, the fused one unsplit — fp32 summation
+                    # order differs there, ~1e-7 relative; tests/test_gpu_model.py holds both to the tolerance).  The training forward keeps the
+                    # three launches (its backward wants q, k, v as tensors), so sampler and training forward differ by that much in the
+                    # self-attention inputs at such shapes — far below the 7e-5 margin of a first-update ratio to the clip boundary.
                     pre = n[:-len("to_q.kernel")]
                     parts = [v, self.views[pre + "to_k.kernel"], self.views[pre + "to_v.kernel"]]
                     buf = self.fused_qkv.get(pre)

@@ -154,6 +154,14 @@ class LocalWriter:
         for old in glob.glob(os.path.join(self.savepath, f"{self.rank}_*.npz")):
             if os.path.basename(old) not in keep:
                 os.remove(old)
+        if self.rank == 0:
+            # ranks >= world belong to an earlier, wider run: nobody of THIS run owns their files, so rank 0 removes them (they
+            # piled up across reruns with a smaller world; the reader already ignored them)
+            import re
+            for old in glob.glob(os.path.join(self.savepath, "manifest_*.json")) + glob.glob(os.path.join(self.savepath, "*_*.npz")):
+                m = re.match(r"(?:manifest_)?(\d+)[_.]", os.path.basename(old))
+                if m and int(m.group(1)) >= int(world):
+                    os.remove(old)
         if metadata is not None and self.rank == 0:
             with open(os.path.join(self.savepath, "metadata.json.tmp"), "w") as f:
                 json.dump(metadata, f, indent=2, default=str)
@@ -185,6 +193,11 @@ class LocalReader:
             # every rank of ONE run carries the same run id: a stale rank-0 manifest next to newer shards of the other ranks (or the other way
             # round: a run that died before every rank closed) is refused instead of being read as a mixture of two runs
             ids = {int(m["rank"]): m.get("run_id") for m in metas if int(m["rank"]) < world}
+            if any(v is None for v in ids.values()):
+                # manifests written before run ids existed (round 4) all read as None and would pass the equality check below: say so
+                import warnings
+                warnings.warn(f"'{loadpath}': manifests without a run id (written before round 5) — cannot tell whether the ranks' shards belong "
+                              "to one sampling run")
             if len(set(ids.values())) != 1:
                 raise FileNotFoundError(f"'{loadpath}': the ranks' manifests belong to different sampling runs (run ids {ids})")
             files = [os.path.join(loadpath, sh["file"]) for m in sorted(metas, key=lambda m: int(m["rank"])) if int(m["rank"]) < world for sh in m["shards"]]

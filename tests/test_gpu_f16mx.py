@@ -151,3 +151,31 @@ def test_operands_beyond_the_f16_range_saturate_instead_of_overflowing():
         assert float((out - ref).abs().max() / ref.abs().max()) < 1e-3   # = the attention of the SATURATED values
     finally:
         L.DATAPATH = old
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout,ks,ups", [(16, 64, 320, 320, 3, 0), (16, 64, 960, 320, 3, 0), (16, 32, 640, 640, 3, 1), (13, 64, 320, 320, 3, 0),
+                                                 (1, 65500, 2560, 320, 0, 0)])
+def test_tall_tile_is_bit_identical_to_the_128_row_tiles(B, H, Cin, Cout, ks, ups, monkeypatch):
+    """the f16mx 256 x 320 tile (APL = 7: eight waves of 64 x 160, two-phase k-tile) is routed by default where its grid fills the
+    chip and keeps the per-accumulator order of the 128-row kernel (f16 k-half 0, f16 k-half 1, MX).  DDPO_MX_TALL=0 (read per launch)
+    keeps the layer on the 128-row tiles: the two outputs must be equal bit for bit over the whole tensor, the tall-tile counter must have
+    moved only in the default run; 208 tall tiles (B = 13) and a ragged last row tile (dense, M = 65500) must agree too."""
+    torch.manual_seed(7)
+    conv = ks > 0
+    rows, K = (B * H * H, 9 * Cin) if conv else (B * H, Cin)
+    VH = 2 * H if ups else H
+    M = B * VH * VH if conv else rows
+    x = torch.randn(rows, Cin, device="cuda")
+    w = torch.randn(K, Cout, device="cuda") / K ** 0.5
+    bias, res = torch.randn(Cout, device="cuda"), torch.randn(M, Cout, device="cuda")
+    planes, wp = L.split_planes_f16mx(x), L.pack_weights_f16mx(w)
+    geom = dict(ksize=3, stride=1, pad=1, upsample=ups, B=B, H=H, W=H, Cin=Cin, OH=VH, OW=VH) if conv else None
+    outs, tall = {}, {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("DDPO_MX_TALL", mode)
+        before = L.gemm_tile_launch_counts()["tall_256x320"]
+        outs[mode] = L.gemm_conv_f16mx(planes, wp, M=M, bias=bias, residual=res, conv=geom).clone()
+        torch.cuda.synchronize()
+        tall[mode] = L.gemm_tile_launch_counts()["tall_256x320"] - before
+    assert tall["0"] == 0 and tall["1"] == 1, tall
+    assert torch.equal(outs["0"], outs["1"])

@@ -2,7 +2,7 @@
 
 BASELINE configs[1] as `bench.py` runs it — SD-1.5, 64x64 latents (512^2 px), `sample_batch_size 8` (U-Net batch 16 under classifier-free
 guidance), `jit=True` (captured HIP graph), the shipped datapath (lib.SHIPPED_DATAPATH), cfg_dup, time-projection table, cached text-context
-K / V images — for TWO DDIM steps, against `oracle.sampler.sample` on the same prompts / key:
+K / V images — for FIVE DDIM steps (DDPO_HEADLINE_STEPS; two until round 6), against `oracle.sampler.sample` on the same prompts / key:
 /root/reference/ddpo/diffusers_patch/pipeline_flax_stable_diffusion.py:204-270.
 
 Every other oracle comparison at size runs b = 1, where the 256x320 "tall" GEMM tile (16 % of the sampling step) is never selected
@@ -10,7 +10,8 @@ Every other oracle comparison at size runs b = 1, where the 256x320 "tall" GEMM 
 tools/native/kernel_probe).  Here the tall tile, the 128x320 f16mx tile, split-K and the LDS-DMA attention all run at the headline shapes
 and the launch counters of the library (ddpo_gemm_tile_launch_counts) prove it.
 
-Host time: 2 x the oracle U-Net on a batch of 16 at 64x64 (about 1-2 minutes on the GPU box's cores)."""
+Host time: 5 x the oracle U-Net on a batch of 16 at 64x64 (about 3 minutes on the GPU box's cores; VERDICT r05 weak 1b: the tall tiles
+must see a trajectory, not two steps)."""
 import os
 
 import numpy as np
@@ -48,7 +49,7 @@ def test_headline_geometry_sampler_matches_oracle_and_runs_the_tall_tile():
         sched = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", set_alpha_to_one=False, steps_offset=1)
         pipe = StableDiffusionPipeline(unet, None, sched)
         state = sched.create_state(device=DEV)
-        B, T = 8, 2
+        B, T = 8, int(os.environ.get("DDPO_HEADLINE_STEPS", "5"))
         g = torch.Generator().manual_seed(41)
         emb = torch.randn(B, 77, 768, generator=g)
         neg = torch.randn(1, 77, 768, generator=g).expand(B, -1, -1).contiguous()
@@ -95,10 +96,10 @@ def test_headline_size_trajectory_error_growth_over_many_steps():
     and BASELINE's metric is quoted at 50 steps: hold a LONG stochastic trajectory of the full SD-1.5 U-Net at 64x64 latents, B = 1,
     on the shipped datapath and the captured-graph path to the oracle's sampling loop and record how the error grows step by step
     (VERDICT r04 missing 2 / ADVICE r04: "at least 20 steps at the headline geometry").  `num_inference_steps = 50` sets the
-    timestep grid of the headline run; DDPO_TRAJ_STEPS (default 20) is how many of its 50 steps are walked — the oracle costs
-    ~4.4 s of host time per CFG step, all 50 run with DDPO_TRAJ_STEPS=50."""
+    timestep grid of the headline run; DDPO_TRAJ_STEPS (default 50 since round 6: ALL of them, so that the driver's suite sees what the
+    builder's log claims — VERDICT r05 weak 1b; the oracle costs ~4.4 s of host time per CFG step) is how many of its 50 steps are walked."""
     datapath = os.environ.get("DDPO_PARITY_DATAPATH") or L.SHIPPED_DATAPATH
-    n_walk = int(os.environ.get("DDPO_TRAJ_STEPS", "20"))
+    n_walk = int(os.environ.get("DDPO_TRAJ_STEPS", "50"))
     old = L.DATAPATH
     L.DATAPATH = datapath
     try:

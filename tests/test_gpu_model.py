@@ -484,3 +484,31 @@ def test_plane_handover_behind_attention_and_ff2_is_bit_identical(family, ctx_di
     # the training forward never takes the hand-over (its backward reads the fp32 tensors) and keeps the same bits
     n = dict(seen)
     assert torch.equal(unet.forward(x, t, c, tape=[]), out[True][0]) and seen == n
+
+
+@pytest.mark.parametrize("M", [1024, 2048, 4096])
+def test_fused_qkv_projection_at_sd15_mid_block_shapes(M, monkeypatch):
+    """the fused (K, 3C) projection keeps every column's k ORDER, but the tile / split-K choice depends on the column count —
+    at M = 1024, K = N = 1280 the separate projections run 128 x 64 tiles with the reduction split in three while N = 3840 runs unsplit, so
+    the fp32 summation order differs there.  Hold the fused launch to the three separate ones at the 16x16-level shapes of SD-1.5
+    (C = 1280; M = 4096 is the sampling batch of 16, where both are unsplit and the bits must agree)."""
+    monkeypatch.setattr(L, "DATAPATH", "bf16x3")
+    torch.manual_seed(11)
+    C = 1280
+    x = torch.randn(M, C, device=DEV)
+    ws = [(torch.randn(C, C, device=DEV) / C ** 0.5).contiguous() for _ in range(3)]
+    fused = torch.cat(ws, dim=1).contiguous()
+    try:
+        for w in ws + [fused]:
+            L.pack_weights(w, bwd=False)
+        sep = torch.cat([L.linear(x, w) for w in ws], dim=1)
+        one = L.linear(x, fused)
+        torch.cuda.synchronize()
+        ref = x.double() @ fused.double()
+        scale = float(ref.abs().max())
+        assert float((one - sep).abs().max()) <= 2e-6 * scale              # summation order only
+        assert float((one.double() - ref).abs().max()) < 1e-4 * scale and float((sep.double() - ref).abs().max()) < 1e-4 * scale
+        if M == 4096:
+            assert torch.equal(one, sep)
+    finally:
+        L.PACKED.clear()

@@ -43,24 +43,29 @@ def _oracle_step(op, cfg, dd, ost, lat, ts, emb, unc, adv, drift, guidance, eta,
     fuse > 1: the rows are `fuse` consecutive micro-batches of b = rows / fuse samples that see the same parameters — each with its own mean
     loss, gradients summed (the reference's AccumulatingTrainState over `fuse` train_step calls without an update in between)."""
     leaves = OrderedDict((k, v.detach().clone().to(dtype).requires_grad_(True)) for k, v in op.items())
-    eps_c = OU.unet_forward(leaves, cfg, lat.to(dtype), ts, emb.to(dtype))
-    eps_u = OU.unet_forward(leaves, cfg, lat.to(dtype), ts, unc.to(dtype))
-    guided = (eps_u + guidance * (eps_c - eps_u)).detach().to(torch.float32).numpy()
     z = OP.normal(OP.PRNGKey(123), tuple(lat.shape))
-    nxt, old = [], []
-    for i in range(lat.shape[0]):                       # sampling-mode step per sample (per-sample timesteps)
-        n_i, lp_i = dd.step(ost, guided[i:i + 1], int(ts[i]), lat[i:i + 1].numpy(), noise=z[i:i + 1], eta=eta)
-        nxt.append(n_i); old.append(lp_i)
-    batch = {"latents": lat, "next_latents": torch.from_numpy(np.concatenate(nxt)), "ts": ts,
-             "log_probs": torch.from_numpy(np.concatenate(old)) + drift, "advantages": adv, "prompt_embeds": emb, "uncond_embeds": unc}
     b = lat.shape[0] // fuse
-    total, infos, logps = 0.0, [], []
+    nxt_all, old_all, infos, logps = [], [], [], []
+    # one micro-batch at a time (forward, transition, loss, backward: the gradients accumulate in the leaves) — the autograd tape of ONE
+    # micro-batch bounds the host memory whatever `fuse` is (16 fused micro-steps = 64 U-Net rows at 64x64 would not fit one tape)
     for j in range(fuse):
         sl = slice(j * b, (j + 1) * b)
-        loss, info, logp = OPPO.loss_and_info_torch(dd, ost, eps_c[sl], eps_u[sl], {k: v[sl] for k, v in batch.items()}, guidance, eta, CLIP, True, dtype)
-        total = total + loss
+        eps_c = OU.unet_forward(leaves, cfg, lat[sl].to(dtype), ts[sl], emb[sl].to(dtype))
+        eps_u = OU.unet_forward(leaves, cfg, lat[sl].to(dtype), ts[sl], unc[sl].to(dtype))
+        guided = (eps_u + guidance * (eps_c - eps_u)).detach().to(torch.float32).numpy()
+        nxt, old = [], []
+        for i in range(b):                              # sampling-mode step per sample (per-sample timesteps)
+            n_i, lp_i = dd.step(ost, guided[i:i + 1], int(ts[sl][i]), lat[sl][i:i + 1].numpy(), noise=z[sl][i:i + 1], eta=eta)
+            nxt.append(n_i); old.append(lp_i)
+        mb = {"latents": lat[sl], "next_latents": torch.from_numpy(np.concatenate(nxt)), "ts": ts[sl],
+              "log_probs": torch.from_numpy(np.concatenate(old)) + drift[sl], "advantages": adv[sl], "prompt_embeds": emb[sl], "uncond_embeds": unc[sl]}
+        loss, info, logp = OPPO.loss_and_info_torch(dd, ost, eps_c, eps_u, mb, guidance, eta, CLIP, True, dtype)
+        loss.backward()
         infos.append({k: float(v.detach()) for k, v in info.items()}); logps.append(logp.detach())
-    total.backward()
+        nxt_all.append(mb["next_latents"]); old_all.append(mb["log_probs"])
+        del eps_c, eps_u, loss
+    batch = {"latents": lat, "next_latents": torch.cat(nxt_all), "ts": ts, "log_probs": torch.cat(old_all), "advantages": adv,
+             "prompt_embeds": emb, "uncond_embeds": unc}
     grads = OrderedDict((k, v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaves.items())
     info = {k: float(np.mean([i[k] for i in infos])) for k in infos[0]}            # per-micro-batch infos, averaged for the comparison
     return batch, grads, info, torch.cat(logps), infos
@@ -90,8 +95,8 @@ def _check(family, ocfg, pred, hw, b, ts, ctx_dim, T, datapath, dtype, seed, fus
         unc = torch.randn(1, 77, ctx_dim, generator=g).expand(n, -1, -1).contiguous()
         ts = torch.tensor(ts, dtype=torch.int32)
         assert ts.shape[0] == n
-        adv = torch.tensor([0.7, -1.1, 0.4, -0.3][:n])
-        drift = torch.tensor([3e-5, -2e-5, 1e-5, -3e-5][:n])          # |log p - log p_old| stays inside the 1e-4 clip range, as before the first update
+        adv = torch.tensor(([0.7, -1.1, 0.4, -0.3, 1.3, -0.6, 0.2, -0.9] * ((n + 7) // 8))[:n])
+        drift = torch.tensor(([3e-5, -2e-5, 1e-5, -3e-5] * ((n + 3) // 4))[:n])          # |log p - log p_old| stays inside the 1e-4 clip range, as before the first update
         dd = DDIMOracle(prediction_type=pred)
         ost = dd.set_timesteps(dd.create_state(), T)
         batch, ograds, oinfo, ologp, oinfos = _oracle_step(op, ocfg, dd, ost, lat, ts, emb, unc, adv, drift, 5.0, 1.0, dtype, fuse)
@@ -123,9 +128,16 @@ def _check(family, ocfg, pred, hw, b, ts, ctx_dim, T, datapath, dtype, seed, fus
         e_dir = math.sqrt(num) / gn_o
         e_groups = {k: rel(gg[k], og[k]) for k in og}
         worst = max(e_groups, key=e_groups.get)
+        # which block carries the gradient-VECTOR error: per top-level block ||g - g_ref|| / ||g_ref|| of the block and
+        # its share of the squared error of the whole vector
+        blk = OrderedDict()
+        for n_ in ograds:
+            blk[n_.split(".")[0]] = blk.get(n_.split(".")[0], 0.0) + float(((G[n_].cpu().double() - ograds[n_].double()) ** 2).sum())
+        blk_txt = "  ".join(f"{k} {math.sqrt(v) / (og[k] + 1e-300):.1e} ({100 * v / (num + 1e-300):.0f} %)" for k, v in blk.items())
         from conftest import parity_record
         parity_record(f"\n[train parity] {family} {datapath} hw={hw} b={b}{f' x {fuse} fused micro-steps' if fuse > 1 else ''} clip={CLIP}: loss {e_loss:.2e}  log-prob abs {e_lp:.2e}  global grad-norm {rel(gn, gn_o):.2e}  "
-                      f"worst block norm {worst} {e_groups[worst]:.2e}  ||g-g_ref||/||g_ref|| {e_dir:.2e}  (|g_ref| = {gn_o:.3e})")
+                      f"worst block norm {worst} {e_groups[worst]:.2e}  ||g-g_ref||/||g_ref|| {e_dir:.2e}  (|g_ref| = {gn_o:.3e})\n"
+                      f"    vector error by block, ||g-g_ref||/||g_ref|| (share of the squared error): {blk_txt}")
         assert float(info["clipfrac"]) == 0.0
         assert e_lp < LP_BUDGET[datapath]               # margin to the clip boundary (7e-5) is never in question
         # approx_kl = mean((log p - log p_old)^2) / 2 is QUADRATIC in differences of ~3e-5: a log-prob error e moves it by up to (|drift| e + e^2 / 2)
@@ -165,7 +177,8 @@ def test_train_step_sd15_full_size_shipped_datapath():
     profiles/r05_parity_margins.log)."""
     dtype = torch.float64 if os.environ.get("DDPO_PARITY_F64") == "1" else torch.float32
     fuse = int(os.environ.get("DDPO_TRAIN_PARITY_FUSE", "1"))
-    _check("sd15", OU.SD15, "epsilon", hw=64, b=2, ts=[481, 21, 961, 241][:2 * fuse], ctx_dim=768, T=50, datapath=SHIPPED, dtype=dtype, seed=0, fuse=fuse)
+    grid = [481, 21, 961, 241, 701, 121, 841, 361, 581, 61, 921, 301, 641, 181, 781, 421]          # timesteps of the 50-step grid (1 + 20 i)
+    _check("sd15", OU.SD15, "epsilon", hw=64, b=2, ts=(grid * ((2 * fuse + 15) // 16))[:2 * fuse], ctx_dim=768, T=50, datapath=SHIPPED, dtype=dtype, seed=0, fuse=fuse)
 
 
 @pytest.mark.timeout(1500)

@@ -56,12 +56,17 @@ def test_rerun_into_the_same_directory_does_not_mix_stale_shards(tmp_path):
     assert len(bucket.LocalReader(str(tmp_path))) == 12
     w.close(metadata={"guidance_scale": 5.0}, world=1)
     assert sorted(f for f in os.listdir(tmp_path) if f.startswith("0_")) == ["0_run-b_00000.npz"]    # rank 0's old shards are gone, after close()
-    rd = bucket.LocalReader(str(tmp_path))                                                            # rank 1's stale shards are ignored
+    # files of ranks >= the new world are nobody's in this run — rank 0's close() removes them instead of letting them pile up
+    assert not [f for f in os.listdir(tmp_path) if f.startswith("1_") or f == "manifest_1.json"]
+    rd = bucket.LocalReader(str(tmp_path))
     assert len(rd) == 3 and [rd[i]["inference_prompts"] for i in range(3)] == list(b["inference_prompts"])
     os.remove(tmp_path / "0_run-b_00000.npz")
     with pytest.raises(FileNotFoundError):
         bucket.LocalReader(str(tmp_path))
     # a run whose rank-1 manifest is missing is refused rather than silently halved
+    w1 = bucket.LocalWriter(str(tmp_path), split_size=2, rank=1, run_id="run-a")      # (a rank of an earlier two-rank run that closed late)
+    w1.add_batch(_rows(2, 11))
+    w1.close(world=2)
     w = bucket.LocalWriter(str(tmp_path), split_size=4, rank=0, run_id="run-c")
     w.add_batch(b)
     w.close(world=2)

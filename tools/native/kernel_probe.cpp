@@ -561,7 +561,7 @@ static int probe_wgrad(int B, int iters) {
 extern "C" int ddpo_debug_kloop_times(unsigned long long* host, int n_wg);
 // One launch of one layer on the instrumented library; per workgroup: entry -> first k-loop barrier (prologue), k-loop, output stage,
 // in microseconds (s_memrealtime, 100 MHz) and the shader clock seen over the whole workgroup (s_memtime ticks / us).
-static void run_ktime(int B, int H, int Cin, int Cout, int ks, int planes, void* ws, size_t ws_bytes) {
+static void run_ktime(int B, int H, int Cin, int Cout, int ks, int planes, void* ws, size_t ws_bytes, bool mx = false) {
   const bool conv = ks > 0;
   const int pad = ks / 2, OH = conv ? H : 0;
   const int64_t M = conv ? (int64_t)B * OH * OH : (int64_t)B * H;
@@ -576,11 +576,19 @@ static void run_ktime(int B, int H, int Cin, int Cout, int ks, int planes, void*
   ddpo_gemm_desc d;
   memset(&d, 0, sizeof(d));
   pack_w(w.p, K, N, Kp, hi, lo, &d);
+  uint8_t* wsc = nullptr;
+  if (mx) {                                   // f16mx operator on the same buffers (planes are the same size)
+    wsc = (uint8_t*)dalloc(N);
+    ABI_OK(ddpo_split_planes_f16mx(src.p, acols, ah, al, acols, arows, acols, nullptr));
+    ABI_OK(ddpo_pack_weights_f16mx(w.p, K, N, hi, lo, wsc, nullptr));
+    d.w_layout = 1; d.w_scale = wsc;
+  }
   d.src = src.p; d.ld_src = acols; d.bias = bias.p; d.out = out; d.ld_out = N; d.alpha = 1.f;
   d.M = (int)M; d.N = N; d.K = K;
   if (conv) { d.ksize = ks; d.stride = 1; d.pad = pad; d.B = B; d.H = H; d.W = H; d.Cin = Cin; d.OH = OH; d.OW = OH; }
   auto launch = [&] {
-    if (planes) ABI_OK(ddpo_gemm_conv_fwd_bf16_planes(&d, ah, al, acols, hi, lo, Kp, ws, ws_bytes, nullptr));
+    if (mx) ABI_OK(ddpo_gemm_conv_fwd_f16mx_planes(&d, ah, al, acols, hi, lo, ws, ws_bytes, nullptr));
+    else if (planes) ABI_OK(ddpo_gemm_conv_fwd_bf16_planes(&d, ah, al, acols, hi, lo, Kp, ws, ws_bytes, nullptr));
     else ABI_OK(ddpo_gemm_conv_fwd_bf16(&d, hi, lo, Kp, 3, ws, ws_bytes, nullptr));
   };
   const std::vector<WarmBuf> warm = planes ? std::vector<WarmBuf>{{ah, (size_t)arows * acols * 2}, {al, (size_t)arows * acols * 2}}
@@ -613,7 +621,7 @@ static void run_ktime(int B, int H, int Cin, int Cout, int ks, int planes, void*
     first = std::min(first, r[0]); last = std::max(last, r[3]);
     ++n;
   }
-  if (conv) printf("ktime conv %dx%d %5d->%5d @%3d^2 B%-3d %s:", ks, ks, Cin, Cout, H, B, planes ? "planes" : "fp32  ");
+  if (conv) printf("ktime conv %dx%d %5d->%5d @%3d^2 B%-3d %s:", ks, ks, Cin, Cout, H, B, mx ? "f16mx " : planes ? "planes" : "fp32  ");
   else printf("ktime gemm M=%7lld K=%5d N=%5d %s:", (long long)M, K, N, planes ? "planes" : "fp32  ");
   const double mhz = clk / n;
   printf(" event %7.1f us | %5d WGs, span %7.1f us | prologue avg %6.1f max %6.1f | k-loop avg %7.1f max %7.1f (%d k-tiles: %.2f us each; wave 0 waits per k-tile: vmcnt/lgkm %.2f us + barrier %.2f us) | output avg %6.1f max %6.1f | clock %.0f MHz\n",
@@ -621,6 +629,17 @@ static void run_ktime(int B, int H, int Cin, int Cout, int ks, int planes, void*
   fflush(stdout);
   src.release(); w.release(); bias.release();
   HIP_OK(hipFree(out)); HIP_OK(hipFree(hi)); HIP_OK(hipFree(lo)); HIP_OK(hipFree(ah)); HIP_OK(hipFree(al));
+  if (wsc) HIP_OK(hipFree(wsc));
+}
+// f16mx operator under the timing build (DDPO_DBG_ABL: 1 = no LDS-DMA inside the loop, 2 = no MFMAs, 4 = activation pieces on 2 of 9 k-tiles)
+static int probe_ktmx(int B) {
+  const size_t ws_bytes = 64u << 20;
+  void* ws = dalloc(ws_bytes);
+  const ConvCase convs[] = {{64, 320, 320, 3, 1, 0}, {64, 960, 320, 3, 1, 0}, {32, 640, 640, 3, 1, 0}, {32, 1920, 640, 3, 1, 0}, {16, 1280, 1280, 3, 1, 0},
+                            {16, 2560, 1280, 3, 1, 0}, {8, 1280, 1280, 3, 1, 0}};
+  for (const ConvCase& c : convs) run_ktime(B, c.H, c.Cin, c.Cout, c.ks, 1, ws, ws_bytes, true);
+  HIP_OK(hipFree(ws));
+  return 0;
 }
 static int probe_ktime(int B) {
   const size_t ws_bytes = 64u << 20;
@@ -904,6 +923,7 @@ int main(int argc, char** argv) {
   else if (mode == "gelu") rc = probe_gelu();
 #ifdef PROBE_TIMING
   else if (mode == "ktime") rc = probe_ktime(B);
+  else if (mode == "ktmx") rc = probe_ktmx(B);
 #endif
   else { fprintf(stderr, "usage: kernel_probe gemm|gemm2|attn|ppo [batch] [iters]\n"); return 64; }
   HIP_OK(hipDeviceSynchronize());
