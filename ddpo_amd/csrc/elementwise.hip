@@ -5,7 +5,7 @@
 #include "common.h"
 #include <math.h>
 
-extern "C" int ddpo_abi_version(void) { return 13; }
+extern "C" int ddpo_abi_version(void) { return 14; }
 extern "C" size_t ddpo_sizeof_gemm_desc(void) { return sizeof(ddpo_gemm_desc); }
 extern "C" size_t ddpo_sizeof_ddim_consts(void) { return sizeof(ddpo_ddim_consts); }
 

@@ -645,13 +645,18 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 64 ? 3 : 1)) g
 
   if constexpr (APL != 0) {
     // ---------------- LDS-DMA path: A planes + W planes straight into the swizzled LDS image ----------------
-    static_assert(NPASS == 3 || NPASS == 4, "the plane-fed path is the bf16x3 / f16mx datapath");
-    constexpr int NW = WM * WN, PAIRS = NW / 2;          // even waves move hi planes, odd waves lo planes
+    static_assert(NPASS == 1 || NPASS == 3 || NPASS == 4, "the plane-fed path: bf16x3 / f16mx (two planes per operand) or single-pass bf16 (one)");
+    // two planes per operand: even waves move hi planes, odd waves lo planes (PAIRS loader groups per plane); ONE plane (NPASS = 1, round 6):
+    // every wave is a loader group of the only plane.  NB is rounded up: with 8 waves the 20 weight pieces of a 320-column tile are 3 per wave,
+    // the four surplus ones carry an out-of-range offset (they arrive as zeros, no memory traffic) and land in rows 320 .. 383 of a weight
+    // stage padded to B_LDS bytes, which no fragment read touches — every wave issues the same number of pieces, so ONE counted vmcnt serves all.
+    constexpr int NW = WM * WN, PAIRS = NPL == 2 ? NW / 2 : NW;
     constexpr int GA = BM / 16, GB = BN / 16;            // 16-row groups = 1 KiB LDS-DMA pieces per plane
-    static_assert(NW % 2 == 0 && GA % PAIRS == 0 && GB % PAIRS == 0, "pieces must divide evenly over the wave pairs");
-    constexpr int NA = GA / PAIRS, NB = GB / PAIRS;
+    static_assert(NW % 2 == 0 && GA % PAIRS == 0 && (NPL == 1 || GB % PAIRS == 0), "pieces must divide evenly over the loader groups");
+    constexpr int NA = GA / PAIRS, NB = (GB + PAIRS - 1) / PAIRS;
+    constexpr int B_LDS = NB * PAIRS * 1024;             // == B_BYTES unless padded (NPASS = 1, 320 columns on 8 waves: 24 KB for 20)
     const int wv = __builtin_amdgcn_readfirstlane(wid);
-    const int plane = wv & 1, pr = wv >> 1;
+    const int plane = NPL == 2 ? (wv & 1) : 0, pr = NPL == 2 ? (wv >> 1) : wv;
     const int lr = lane >> 2;                            // row inside the 16-row piece
     const uint32_t lc16 = (uint32_t)((lane & 3) ^ ((lane >> 4) & 3)) * 16u;     // source chunk whose lane-linear slot equals swz_off()
     const uint64_t a_ptr = reinterpret_cast<uint64_t>(plane ? reinterpret_cast<const void*>(d.w) : reinterpret_cast<const void*>(d.src));
@@ -705,7 +710,9 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 64 ? 3 : 1)) g
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int n = n0 + 16 * (pr + PAIRS * i) + lr;
-      bvoff[i] = n < d.N ? (uint32_t)n * w_row_b + lc16 : BUF_OOB;
+      bool in_tile = true;
+      if constexpr (GB % PAIRS != 0) in_tile = pr + PAIRS * i < GB;          // surplus pieces of a rounded-up NB (single plane, 320 columns)
+      bvoff[i] = (n < d.N && in_tile) ? (uint32_t)n * w_row_b + lc16 : BUF_OOB;
     }
     const int nk_total = d.K / BK;
     const int kt0 = blockIdx.y * kt_per_split;
@@ -805,9 +812,9 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 64 ? 3 : 1)) g
       // are requested, in that order; the wait in front of the next barrier is a COUNTED vmcnt(NB): everything but the newest NB
       // pieces (the weight tile that is not needed for another whole k-tile) has landed.  Weights are the cold operand in the
       // model — every launch streams them from HBM — and now have two k-tiles of latency tolerance like the register-staged loop.
-      constexpr int A_STAGE = NPL * A_BYTES, W_STAGE = NPL * B_BYTES;
+      constexpr int A_STAGE = NPL * A_BYTES, W_STAGE = NPL * B_LDS;
       const uint32_t lds_a3 = lds0 + plane * A_BYTES + pr * 1024;
-      const uint32_t lds_w3 = lds0 + 2 * A_STAGE + plane * B_BYTES + pr * 1024;
+      const uint32_t lds_w3 = lds0 + 2 * A_STAGE + plane * B_LDS + pr * 1024;
       int kw_next = kt0;                                   // tap / cib / set_tap follow the ACTIVATION tiles
       int ka_next = 0;                                     // (timing ablation 4 only)
       auto fill_a = [&](int stage) {
@@ -957,8 +964,76 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 64 ? 3 : 1)) g
         ktile(kt + 1, std::integral_constant<int, 1>{});
       }
       if (kt < nk) ktile(kt, std::integral_constant<int, 0>{});
+    } else if constexpr (APL == 8) {
+      // SINGLE-PASS bf16 on the TALL 256 x 320 tile (round 6; BASELINE configs[4] names bf16: one v_mfma_f32_32x32x16_bf16 per product, XLA's TPU
+      // default precision).  One plane per operand halves a k-tile's bytes (A 16 KB + W 20 KB, padded to 24), so the 160 KB of LDS hold a RING of
+      // S = 4 stages instead of two: S - 1 k-tiles are requested ahead and the wait in front of a k-tile's barrier is a COUNTED vmcnt that leaves the
+      // S - 2 youngest tiles (10 pieces of this wave) in flight — the stream never drains inside the loop (tools/native/dma_bench2: the same request
+      // pattern sustains 13.5 TB/s with 80 KB in flight per CU against 10.8 with one 40 KB tile and a drain per tile).  Single pass has a third of
+      // bf16x3's MFMAs per byte, i.e. this is the instantiation where the loader structure, not the matrix pipe, sets the rate.
+      // One barrier per k-tile: behind it tile kt is published (every wave waited for its own pieces) and the stage of tile kt - 1 is free
+      // (every wave's fragment reads of it returned: lgkmcnt(0)), so tile kt + S - 1 is requested into it.  Stage offsets are runtime values
+      // (one v_add per fragment base: the 160 KB image exceeds the 64 KB reach of the ds_read offset field).  Per accumulator the order is
+      // k half 0, k half 1 of consecutive k-tiles — the fp32-fed single-pass kernel's — so the two agree bit for bit.
+      static_assert(NPASS == 1 && BM == 256 && BN == 320 && WM == 4 && WN == 2, "the single-pass tall tile");
+      constexpr int S = 4, ST = A_BYTES + B_LDS, P = NA + NB;
+      static_assert(S * ST <= 160 * 1024 && P * (S - 2) < 64, "stage ring must fit the LDS and the vmcnt field");
+      const uint32_t lds_a8 = lds0 + pr * 1024, lds_w8 = lds0 + A_BYTES + pr * 1024;
+      auto fill8 = [&](uint32_t st_off) {
+        const uint32_t so_a = (uint32_t)(cib >> 5) * a_kt_b, so_w = (uint32_t)kt_next * w_kt_b;
+        const uint32_t la = lds_a8 + st_off, lw = lds_w8 + st_off;
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+          asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                       :: "s"(la + i * (PAIRS * 1024)), "v"(avoff[i]), "s"(rs_a), "s"(so_a) : "memory");
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+          asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                       :: "s"(lw + i * (PAIRS * 1024)), "v"(bvoff[i]), "s"(rs_w), "s"(so_w) : "memory");
+        ++kt_next;
+        cib += BK;
+        if (cib >= cin) {
+          cib = 0; ++tap;
+          if (conv && tap < ntaps) set_tap(tap);
+        }
+      };
+      const bool late = (d.splits & 1) != 0 && wv >= NW / 2;
+#pragma unroll
+      for (int s_ = 0; s_ < S - 1; ++s_)
+        if (s_ < nk) fill8(s_ * ST);
+      uint32_t st_c = 0, st_f = (S - 1) * ST;              // byte offsets of the stage computed on / the stage requested into
+#pragma unroll 1
+      for (int kt = 0; kt < nk; ++kt) {
+        // tile kt has landed; the S - 2 younger tiles (if the reduction still has them) stay in flight
+        if (kt + S - 2 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(P * (S - 2)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt == 0) DBG_T(1);
+        if (kt + S - 1 < nk && !late && !DBG_ABL(1)) fill8(st_f);
+        const char* sa = smem + st_c;
+        const char* sb = sa + A_BYTES;
+        bf16x8 ah0[TM], ah1[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          ah0[i] = *reinterpret_cast<const bf16x8*>(sa + a_ld0 + i * 2048);
+          ah1[i] = *reinterpret_cast<const bf16x8*>(sa + a_ld1 + i * 2048);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const bf16x8 bh0 = *reinterpret_cast<const bf16x8*>(sb + b_ld0 + j * 2048);
+          const bf16x8 bh1 = *reinterpret_cast<const bf16x8*>(sb + b_ld1 + j * 2048);
+          if (DBG_ABL(2)) { asm volatile("" :: "v"(ah0[0]), "v"(ah1[TM - 1]), "v"(bh0), "v"(bh1)); continue; }
+#pragma unroll
+          for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0[i], bh0, acc[i][j], 0, 0, 0);
+#pragma unroll
+          for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1[i], bh1, acc[i][j], 0, 0, 0);
+          if (j == 1 && kt + S - 1 < nk && late && !DBG_ABL(1)) fill8(st_f);      // the upper half of the waves requests two column blocks later
+        }
+        st_c = st_c + ST == S * ST ? 0 : st_c + ST;
+        st_f = st_f + ST == S * ST ? 0 : st_f + ST;
+      }
     } else {
-      static_assert(APL == 3 || APL == 5 || APL == 6, "plane-fed k-loops: 3 = three weight stages (128-row tiles), 5 = tall tile, 6 = tall tile with the GEGLU output stage, 7 = f16mx tall tile");
+      static_assert(APL == 3 || APL == 5 || APL == 6, "plane-fed k-loops: 3 = three weight stages (128-row tiles), 5 = tall tile, 6 = tall tile with the GEGLU output stage, 7 = f16mx tall tile, 8 = single-pass tall tile");
     }
   } else {
     const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(d.src);
@@ -1510,7 +1585,7 @@ static int launch_bf16_wide(const ddpo_gemm_desc& d, const uint16_t* w_hi, const
 
 // Tall 256x320 tiles (plane-fed path only, 8 waves of 64x160, one workgroup per CU, plain k-loop APL = 4): for layers whose tile
 // grid still covers the chip — the 64x64-latent level of the U-Net (M = 65536: 256 tiles per 320 columns).  No split-K.
-template <int APL>
+template <int APL, int NPASS = 3>
 static int launch_bf16_tall(const ddpo_gemm_desc& d, const uint16_t* w_hi, const uint16_t* w_lo, int ldw, hipStream_t st) {
   constexpr int BM = 256, BN = 320, WM = 4, WN = 2;
   const int tiles_m = (d.M + BM - 1) / BM, tiles_n = (d.N + BN - 1) / BN;
@@ -1519,12 +1594,12 @@ static int launch_bf16_tall(const ddpo_gemm_desc& d, const uint16_t* w_hi, const
   const size_t lds = 8 * 32 * 160 * 4;                     // epilogue slices (160 KB) > 2 stages of operand tiles (144 KB)
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_bf16_buf_kernel<BM, BN, 3, 0, WM, WN, true, APL>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_bf16_buf_kernel<BM, BN, NPASS, 0, WM, WN, true, APL>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   count_tile(TC_TALL);
-  hipLaunchKernelGGL((gemm_conv_bf16_buf_kernel<BM, BN, 3, 0, WM, WN, true, APL>), dim3(nblk, 1), dim3(64 * WM * WN), lds, st, d, w_hi, w_lo, ldw,
+  hipLaunchKernelGGL((gemm_conv_bf16_buf_kernel<BM, BN, NPASS, 0, WM, WN, true, APL>), dim3(nblk, 1), dim3(64 * WM * WN), lds, st, d, w_hi, w_lo, ldw,
                      tiles_m, tiles_n, nblk, nk_total, (float*)nullptr);
   DDPO_LAUNCH_CHECK();
   return DDPO_OK;
@@ -1567,7 +1642,10 @@ static int dispatch_bf16(const ddpo_gemm_desc& d, const uint16_t* w_hi, const ui
       }
       return DDPO_EINVAL;
     }
-    if constexpr (APL == 3) { if (npass == 4) return launch_bf16<128, 128, 4, 2, 2, 3>(d, w_hi, w_lo, ldw, nullptr, 0, st); }
+    if constexpr (APL == 3) {
+      if (npass == 4) return launch_bf16<128, 128, 4, 2, 2, 3>(d, w_hi, w_lo, ldw, nullptr, 0, st);
+      if (npass == 1) return launch_bf16<128, 128, 1, 2, 2, 3>(d, w_hi, w_lo, ldw, nullptr, 0, st);
+    }
     return npass == 3 ? launch_bf16<128, 128, 3, 2, 2, APL>(d, w_hi, w_lo, ldw, nullptr, 0, st) : launch_bf16<128, 128, 1>(d, w_hi, w_lo, ldw, nullptr, 0, st);
   }
   float* wsf = (ws && !(reinterpret_cast<uintptr_t>(ws) & 15)) ? reinterpret_cast<float*>(ws) : nullptr;
@@ -1591,6 +1669,9 @@ static int dispatch_bf16(const ddpo_gemm_desc& d, const uint16_t* w_hi, const ui
     if (tall_mode && npass == 3 && d.N % 320 == 0 && d.epilogue == 0 && ntall >= 200 && eff_tall * 1.08 >= eff_wide)
       return launch_bf16_tall<5>(d, w_hi, w_lo, ldw, st);
     if constexpr (APL == 3) {
+      // single-pass bf16, plane-fed (round 6): the tall tile with the four-stage ring (APL = 8) under the same rule
+      if (npass == 1 && d.N % 320 == 0 && d.epilogue == 0 && ntall >= 200 && eff_tall * 1.08 >= eff_wide)
+        return launch_bf16_tall<8, 1>(d, w_hi, w_lo, ldw, st);
       // f16mx layers on the tall tile (APL = 7) under the bf16x3 tall tile's rule: grids that fill whole rounds of the chip unsplit — the 64x64
       // level at batch 16 and the up-sampled 32x32 -> 64x64 convolution.  Measured round 5 (profiles/r05_probe_mx_tall.log, r05_ab_mx_tall.log):
       // conv 320->320 @64^2 0.259 -> 0.236 ms, 960->320 0.930 -> 0.709 ms, up-conv 640->640 1.084 -> 0.878 ms, bit-identical; sampling +1.4 %.
@@ -1606,7 +1687,10 @@ static int dispatch_bf16(const ddpo_gemm_desc& d, const uint16_t* w_hi, const ui
   if (wide_mode && d.N % 320 == 0 && d.M >= 512 && buf_path_ok(d, ldw) && !(d.K / BF_BK < 16 && d.N > 1280) &&
       (long)((d.M + 127) / 128) * (d.N / 320) * wsplits >= 200 &&
       !(wsplits > 1 && d.K / BF_BK < 64)) {     // a split short reduction only adds the reduce pass (measured equal to 128x128 unsplit)
-    if constexpr (APL == 3) { if (npass == 4) return launch_bf16_wide<4, 3>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st); }
+    if constexpr (APL == 3) {
+      if (npass == 4) return launch_bf16_wide<4, 3>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st);
+      if (npass == 1) return launch_bf16_wide<1, 3>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st);
+    }
     return npass == 3 ? launch_bf16_wide<3, APL>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st) : launch_bf16_wide<1>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st);
   }
   const long t128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128);
@@ -1620,6 +1704,8 @@ static int dispatch_bf16(const ddpo_gemm_desc& d, const uint16_t* w_hi, const ui
   if constexpr (APL == 3) {
     if (npass == 4)
       return big ? launch_bf16<128, 128, 4, 2, 2, 3>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st) : launch_bf16<128, 64, 4, 2, 2, 3>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st);
+    if (npass == 1)
+      return big ? launch_bf16<128, 128, 1, 2, 2, 3>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st) : launch_bf16<128, 64, 1, 2, 2, 3>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st);
   }
   if (npass == 3)
     return big ? launch_bf16<128, 128, 3, 2, 2, APL>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st) : launch_bf16<128, 64, 3, 2, 2, APL>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st);
@@ -1655,9 +1741,11 @@ extern "C" int ddpo_gemm_conv_fwd_bf16(const ddpo_gemm_desc* dp, const uint16_t*
 extern "C" int ddpo_gemm_conv_fwd_bf16_planes(const ddpo_gemm_desc* dp, const uint16_t* a_hi, const uint16_t* a_lo, int lda,
                                               const uint16_t* w_hi, const uint16_t* w_lo, int ldw, void* ws, size_t ws_bytes,
                                               void* stream) {
-  if (!dp || !a_hi || !a_lo || !w_hi || !w_lo) return DDPO_EINVAL;
+  if (!dp || !a_hi || !w_hi || (a_lo == nullptr) != (w_lo == nullptr)) return DDPO_EINVAL;
+  const int npass = a_lo ? 3 : 1;          // ABI v14: BOTH lo planes NULL = single-pass bf16 (a_hi * w_hi only: XLA's TPU default precision)
   ddpo_gemm_desc d = *dp;
   if (d.M <= 0 || d.N <= 0 || d.K <= 0 || lda < 0 || (lda & 7) || d.w_dgrad || !planes_out_ok(d)) return DDPO_EINVAL;      // lda == 0: k-blocked planes
+  if (npass == 1 && d.epilogue == 2) return DDPO_EINVAL;      // the tall GEGLU tile exists on the three-pass datapath only
   if ((reinterpret_cast<uintptr_t>(a_hi) | reinterpret_cast<uintptr_t>(a_lo) | reinterpret_cast<uintptr_t>(w_hi) |
        reinterpret_cast<uintptr_t>(w_lo)) & 15) return DDPO_EINVAL;
   if (d.w_layout != 0 && d.w_layout != 1) return DDPO_EINVAL;
@@ -1680,7 +1768,7 @@ extern "C" int ddpo_gemm_conv_fwd_bf16_planes(const ddpo_gemm_desc* dp, const ui
 #ifdef DDPO_KLOOP_TIMING
   { const char* e = getenv("DDPO_DBG_ABL"); if (e) d.splits |= atoi(e) << 4; }
 #endif
-  return dispatch_bf16<3>(d, w_hi, w_lo, ldw, 3, ws, ws_bytes, as_stream(stream));
+  return dispatch_bf16<3>(d, w_hi, w_lo, ldw, npass, ws, ws_bytes, as_stream(stream));
 }
 
 /* f16mx plane-fed variant (include/ddpo_hip.h): same kernel family, NPASS = 4 */

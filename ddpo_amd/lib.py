@@ -39,7 +39,7 @@ class GemmDesc(ctypes.Structure):
                 ("w_scale", c_void_p), ("planes_fmt", c_int), ("colsum", c_void_p), ("aux_out", c_void_p)]
 
 
-ABI_VERSION = 13         # must equal ddpo_abi_version() of the loaded library (include/ddpo_hip.h)
+ABI_VERSION = 14         # must equal ddpo_abi_version() of the loaded library (include/ddpo_hip.h)
 
 _SIGS = {
     "ddpo_abi_version": (c_int, []),
@@ -206,6 +206,18 @@ def _mx():
     return current_datapath() == "f16mx"
 
 
+# Single-pass bf16 ("bf16": XLA's TPU default precision, BASELINE configs[4]'s dtype) on the PLANE-FED kernels (round 6, ABI v14): the norms and
+# GEMM output stages write the same bf16 hi / lo planes as under bf16x3 and the consumer reads the hi planes only (both lo pointers NULL at
+# ddpo_gemm_conv_fwd_bf16_planes) — hi = bf16(x) is exactly the operand the fp32-fed single-pass kernel forms in its loader, so the two are
+# bit-identical.  DDPO_BF16_PLANES=0: the fp32-fed kernels everywhere (rounds 1-5).
+BF16_PLANES = os.environ.get("DDPO_BF16_PLANES", "1") == "1"
+
+
+def _planes_dp():
+    """Datapaths whose contractions can be plane-fed."""
+    return _x3() or (BF16_PLANES and current_datapath() == "bf16")
+
+
 def mx_layer(w):
     """True when the forward contraction with weight tensor `w` runs on the f16mx kernel: f16mx datapath, f16mx weight planes registered
     (pack_weights packs them for K >= MX_MIN_K).  A property of the layer — the batch never enters."""
@@ -220,7 +232,7 @@ def norm_planes(w, cin, rows, training=False):
     2 = f16mx planes (= planes_pay's answer), except that the TRAINING forward keeps fp32 in front of an f16mx layer (its weight gradient runs
     on bf16x3 from the fp32 tensor; the forward GEMM splits it on the way in) and wherever DDPO_TRAIN_PLANES is off."""
     p = planes_pay(w, cin, rows)
-    if training and (p == 2 or not TRAIN_PLANES):
+    if training and (p == 2 or not TRAIN_PLANES or not _x3()):      # (single-pass bf16: its weight-gradient kernels take fp32 operands)
         return 0
     return p
 
@@ -313,7 +325,7 @@ def planes_ok(w, cin, rows):
     of a convolution's input, M of a dense layer) can take a plane-fed activation: bf16x3 datapath, weight planes registered
     (pack_weights), 32-channel k-tiles that never straddle a tap, and 31-bit byte offsets (the conditions of the
     buffer-addressed kernel, buf_path_ok() in csrc/gemm_bf16.hip — the VAE's 512x512 levels at batch 8 exceed them)."""
-    if not (PLANES and _x3() and cin % 32 == 0):
+    if not (PLANES and _planes_dp() and cin % 32 == 0):
         return False
     ent = PACKED.get(w.data_ptr())
     if ent is None:
@@ -334,14 +346,25 @@ def planes_pay(w, cin, rows):
         return 2
     if PLANES_ALL:
         return 1
-    return 1 if (PACKED[w.data_ptr()]["K"] >= 2560 or rows >= 32768) else 0
+    ent = PACKED[w.data_ptr()]
+    if not _x3():
+        # single-pass bf16 (round 6): the fp32-fed single-pass kernels already run the long reductions at 750-980 TF; the plane-fed form wins only
+        # where the 256 x 320 tile with the four-stage ring (APL = 8) takes the layer — 1.15-1.27x on the 64x64-level convolutions of SD-1.5,
+        # 1.12x on SD-2.1's 960-column projection — and loses 5-10 % on the 128-row tiles (profiles/r06_breakdown_bf16_planes.log).  Same rule as
+        # the C++ dispatch (dispatch_bf16: >= 200 tall tiles, round efficiency within 8 % of the 128 x 320 grid's), and K >= 1280.
+        N, K = ent["N"], ent["K"]
+        m_out = rows                         # (source rows: an up-sampling convolution has 4x the output rows — it only gains more)
+        ntall, nwide = -(-m_out // 256) * (N // 320), -(-m_out // 128) * (N // 320)
+        eff = lambda n: n / (-(-n // 256) * 256) if n else 0.0
+        return 1 if (N % 320 == 0 and K >= 1280 and ntall >= 200 and eff(ntall) * 1.08 >= eff(nwide)) else 0
+    return 1 if (ent["K"] >= 2560 or rows >= 32768) else 0
 
 
 def planes_out_ok(w, cin, rows, N):
     """True when the GEMM / conv with weight `w` (reduction channels per tap `cin`, `rows` source rows, N output columns) runs on a
     buffer-addressed bf16x3 kernel, i.e. can emit its result as planes (ddpo_gemm_desc.out_hi): the conditions of planes_ok()
     except that the ACTIVATION may be fp32 (then only K % 32 and the 31-bit offsets matter), plus N % 4 == 0."""
-    if not (PLANES and PLANES_OUT and _x3() and cin % 32 == 0 and N % 4 == 0):
+    if not (PLANES and PLANES_OUT and _planes_dp() and cin % 32 == 0 and N % 4 == 0):
         return False
     ent = PACKED.get(w.data_ptr())
     if ent is None:
@@ -873,13 +896,13 @@ def linear_geglu(x, w, out=None, planes_out=False, pre_out=False):
     mxl = _mx() and "mx" in g
     if pl is None and mxl:               # an f16mx layer ALWAYS runs on the f16mx kernel (see DATAPATHS): fp32 input is split on the way in
         pl = x = split_planes(x, fmt=1)
-    if pl is not None and (not _x3() or K % 32 or (pl.fmt == 1) != mxl):
+    if pl is not None and (not _planes_dp() or K % 32 or (pl.fmt == 1) != mxl):
         raise DdpoHipError("plane-fed linear_geglu needs the bf16x3 / f16mx datapath, K % 32 == 0 and planes of the layer's format "
                            "(ask planes_pay / norm_planes for it)")
     d = GemmDesc()
     opl = None
     if planes_out:
-        if not _x3():
+        if not _planes_dp():
             raise DdpoHipError("plane-emitting linear_geglu needs the bf16x3 / f16mx datapath")
         opl = Planes(M, N // 2, x.device, fmt=1 if planes_out == 2 else 0)            # planes_out = the CONSUMER's planes_pay value
         d.out_hi, d.out_lo, d.ld_planes, d.planes_fmt = opl.hi.data_ptr(), opl.lo.data_ptr(), opl.ld, opl.fmt
@@ -910,8 +933,9 @@ def linear_geglu(x, w, out=None, planes_out=False, pre_out=False):
         _check(load().ddpo_gemm_conv_fwd_f16mx_planes(byref(d), _p(pl.hi), _p(pl.lo), pl.ld, _p(m["w16"]), _p(m["w8"]), None, 0, _stream()),
                "ddpo_gemm_conv_fwd_f16mx_planes")
     elif pl is not None:
-        _check(load().ddpo_gemm_conv_fwd_bf16_planes(byref(d), _p(pl.hi), _p(pl.lo), pl.ld, _p(gw["hi"]), _p(gw["lo"]), K, None, 0, _stream()),
-               "ddpo_gemm_conv_fwd_bf16_planes")
+        one = npass == 1
+        _check(load().ddpo_gemm_conv_fwd_bf16_planes(byref(d), _p(pl.hi), None if one else _p(pl.lo), pl.ld, _p(gw["hi"]), None if one else _p(gw["lo"]), K,
+                                                     None, 0, _stream()), "ddpo_gemm_conv_fwd_bf16_planes")
     else:
         _check(load().ddpo_gemm_conv_fwd_bf16(byref(d), _p(g["hi"]), _p(g["lo"]), K, npass, None, 0, _stream()), "ddpo_gemm_conv_fwd_bf16")
     if PROFILE is not None:
@@ -994,9 +1018,9 @@ def gemm_conv(src, w, *, M, N, K, bias=None, rowbias=None, rows_per_batch=0, res
     route = None if w_trans else _bf16_route(w, K, N, conv, False)
     if route is not None:
         d.w_layout = PACKED[w.data_ptr()].get("w_layout", 0)
-    if opl is not None and (route is None or route[3] != 3):
+    if opl is not None and (route is None or not _planes_dp()):
         raise DdpoHipError("a plane-emitting GEMM needs the bf16x3 / f16mx datapath and registered weight planes (check planes_out_ok)")
-    if pl is not None and (route is None or route[3] != 3 or (conv["Cin"] if conv else K) % 32 or ld_src is not None):
+    if pl is not None and (route is None or not _planes_dp() or (conv["Cin"] if conv else K) % 32 or ld_src is not None):
         raise DdpoHipError("a plane-fed GEMM needs the bf16x3 / f16mx datapath, registered weight planes (of the planes' format) and 32-channel "
                            "k-tiles (check planes_ok before asking a producer for planes)")
     if PROFILE is not None:
@@ -1012,7 +1036,8 @@ def gemm_conv(src, w, *, M, N, K, bias=None, rowbias=None, rows_per_batch=0, res
     elif pl is not None:
         hi, lo, ldw, npass = route
         ws = _scratch(SPLITK_WS_BYTES, src.device, "splitk")
-        _check(load().ddpo_gemm_conv_fwd_bf16_planes(byref(d), _p(pl.hi), _p(pl.lo), pl.ld, _p(hi), _p(lo), ldw, _p(ws),
+        one = npass == 1                      # single-pass bf16: the hi planes only (ABI v14: both lo pointers NULL)
+        _check(load().ddpo_gemm_conv_fwd_bf16_planes(byref(d), _p(pl.hi), None if one else _p(pl.lo), pl.ld, _p(hi), None if one else _p(lo), ldw, _p(ws),
                                                      SPLITK_WS_BYTES, _stream()), "ddpo_gemm_conv_fwd_bf16_planes")
     elif route is not None:
         hi, lo, ldw, npass = route

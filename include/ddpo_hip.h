@@ -231,12 +231,16 @@ int ddpo_gemm_conv_wgrad(const ddpo_gemm_desc* d, void* stream);
  * d->w_dgrad = 1 for data gradients.  d->w / d->w_trans are ignored.  Requires Cin % 8 == 0 (K % 8 == 0 if dense). */
 int ddpo_gemm_conv_fwd_bf16(const ddpo_gemm_desc* d, const uint16_t* w_hi, const uint16_t* w_lo, int ldw, int npass,
                             void* ws, size_t ws_bytes, void* stream);
-/* Plane-fed variant (bf16x3 only): the activation operand is given ALREADY split into bf16 hi / lo planes a_hi / a_lo,
+/* Plane-fed variant: the activation operand is given ALREADY split into bf16 hi / lo planes a_hi / a_lo,
  * (rows, lda) bf16 with lda in elements (% 8 == 0), rows = B*H*W source pixels (conv) or M (dense), as written by
  * ddpo_split_planes_bf16 or by the plane-emitting output stage of a normalisation kernel.  d->src / d->ld_src / d->w are
  * ignored.  Both operands reach LDS by LDS-DMA (no register staging, no split in the loader).  Same tiles, k order and
  * MFMA passes as ddpo_gemm_conv_fwd_bf16 on the fp32 tensor the planes were split from: bit-identical results.
- * Requires Cin % 32 == 0 (K % 32 == 0 if dense), no w_dgrad; returns DDPO_EINVAL otherwise (use the fp32-fed entry). */
+ * Requires Cin % 32 == 0 (K % 32 == 0 if dense), no w_dgrad; returns DDPO_EINVAL otherwise (use the fp32-fed entry).
+ * ABI v14: a_lo == NULL AND w_lo == NULL selects SINGLE-PASS bf16 (a_hi * w_hi only, fp32 accumulation: npass = 1 of
+ * ddpo_gemm_conv_fwd_bf16 — XLA's TPU default precision, BASELINE configs[4]'s dtype) on the same LDS-DMA loaders: one plane per operand,
+ * 256 x 320 tiles on a four-stage LDS ring with a counted vmcnt where their grid fills the chip.  hi = bf16(x) is the operand the fp32-fed
+ * single-pass kernel forms in its loader: bit-identical to it.  Exactly one of the two lo pointers NULL, or epilogue == 2, is DDPO_EINVAL. */
 int ddpo_gemm_conv_fwd_bf16_planes(const ddpo_gemm_desc* d, const uint16_t* a_hi, const uint16_t* a_lo, int lda,
                                    const uint16_t* w_hi, const uint16_t* w_lo, int ldw, void* ws, size_t ws_bytes,
                                    void* stream);

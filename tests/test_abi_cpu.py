@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in ddpo_hip.h but not exported"
     assert declared == set(L.EXPORTED_SYMBOLS)
-    assert L.load().ddpo_abi_version() == L.ABI_VERSION == 13
+    assert L.load().ddpo_abi_version() == L.ABI_VERSION == 14
 
 
 def test_struct_mirrors():

@@ -234,6 +234,7 @@ __global__ void diff_kernel(const float* a, const float* b, int64_t n, unsigned 
 }
 
 // fp32-fed kernel vs plane-fed kernel on the same layer: timing of both, bitwise comparison of the two outputs
+static int g_npass = 3;      // mode x1: single-pass bf16 (both lo planes NULL at the plane-fed entry, npass = 1 at the fp32-fed one)
 static void run_gemm2(int B, int H, int Cin, int Cout, int ks, int stride, int ups, int iters, void* ws, size_t ws_bytes) {
   const bool conv = ks > 0;
   const int pad = ks / 2;
@@ -261,8 +262,9 @@ static void run_gemm2(int B, int H, int Cin, int Cout, int ks, int stride, int u
   const bool cold = probe_cold();
   const std::vector<WarmBuf> warm1 = {{src.p, (size_t)arows * acols * 4}, {res.p, (size_t)M * N * 4}};
   const std::vector<WarmBuf> warm2 = {{ah, (size_t)arows * acols * 2}, {al, (size_t)arows * acols * 2}, {res.p, (size_t)M * N * 4}};
-  auto f1 = [&] { ABI_OK(ddpo_gemm_conv_fwd_bf16(&d1, hi, lo, Kp, 3, ws, ws_bytes, nullptr)); };
+  auto f1 = [&] { ABI_OK(ddpo_gemm_conv_fwd_bf16(&d1, hi, lo, Kp, g_npass, ws, ws_bytes, nullptr)); };
   const float ms1 = cold ? time_cold_ms(iters, f1, warm1) : time_ms(iters, f1);
+  if (g_npass == 1) { HIP_OK(hipFree(al)); HIP_OK(hipFree(lo)); al = nullptr; lo = nullptr; }      // the single pass must not touch them
   const int rc = ddpo_gemm_conv_fwd_bf16_planes(&d2, ah, al, acols, hi, lo, Kp, ws, ws_bytes, nullptr);
   if (rc != DDPO_OK) {
     printf("%s K=%d N=%d: plane-fed entry returned %d (layer stays on the fp32-fed kernel)\n", conv ? "conv" : "gemm", K, N, rc);
@@ -285,7 +287,28 @@ static void run_gemm2(int B, int H, int Cin, int Cout, int ks, int stride, int u
   }
   fflush(stdout);
   src.release(); w.release(); bias.release(); res.release();
-  HIP_OK(hipFree(out1)); HIP_OK(hipFree(out2)); HIP_OK(hipFree(hi)); HIP_OK(hipFree(lo)); HIP_OK(hipFree(ah)); HIP_OK(hipFree(al));
+  HIP_OK(hipFree(out1)); HIP_OK(hipFree(out2)); HIP_OK(hipFree(hi)); HIP_OK(hipFree(ah));
+  if (lo) HIP_OK(hipFree(lo));
+  if (al) HIP_OK(hipFree(al));
+}
+
+// single-pass bf16 (BASELINE configs[4]'s dtype): fp32-fed NPASS = 1 kernel vs the plane-fed one (round 6), SD-1.5 at 64x64 and SD-2.1 at 96x96 latents
+static int probe_x1(int B, int iters) {
+  const size_t ws_bytes = 64u << 20;
+  void* ws = dalloc(ws_bytes);
+  g_npass = 1;
+  setenv("PROBE_WKBLK", "1", 1);
+  const ConvCase convs[] = {{64, 320, 320, 3, 1, 0}, {32, 640, 640, 3, 1, 0}, {16, 1280, 1280, 3, 1, 0}, {8, 1280, 1280, 3, 1, 0}, {64, 960, 320, 3, 1, 0},
+                            {32, 640, 640, 3, 1, 1}, {64, 320, 320, 3, 2, 0}, {64, 320, 320, 1, 1, 0},
+                            {96, 320, 320, 3, 1, 0}, {48, 640, 640, 3, 1, 0}, {24, 1280, 1280, 3, 1, 0}, {12, 1280, 1280, 3, 1, 0}, {96, 960, 320, 3, 1, 0},
+                            {48, 1920, 640, 3, 1, 0}, {24, 2560, 1280, 3, 1, 0}, {48, 640, 640, 3, 1, 1}, {20, 64, 96, 3, 1, 0}};
+  for (const ConvCase& c : convs) run_gemm2(B, c.H, c.Cin, c.Cout, c.ks, c.stride, c.ups, iters, ws, ws_bytes);
+  const int dense[][3] = {{4096, 320, 320}, {4096, 320, 2560}, {4096, 1280, 320}, {1024, 640, 640}, {1024, 2560, 640}, {256, 1280, 1280}, {256, 5120, 1280},
+                          {9216, 320, 320}, {9216, 320, 2560}, {9216, 1280, 320}, {2304, 640, 640}, {2304, 2560, 640}, {576, 1280, 1280}, {37, 96, 72}};
+  for (auto& g : dense) run_gemm2(B, g[0], g[1], g[2], 0, 1, 0, iters, ws, ws_bytes);
+  g_npass = 3;
+  HIP_OK(hipFree(ws));
+  return g_fail;
 }
 
 // the VAE decoder's convolutions at 512 x 512 output (batch = images per decode call): few channels, millions of rows
@@ -914,6 +937,7 @@ int main(int argc, char** argv) {
   int rc;
   if (mode == "gemm") rc = probe_gemm(B, iters);
   else if (mode == "gemm2") rc = probe_gemm2(B, iters);
+  else if (mode == "x1") rc = probe_x1(B, iters);
   else if (mode == "mx") rc = probe_mx(B, iters);
   else if (mode == "vae") rc = probe_vae(B, iters);
   else if (mode == "wgrad") rc = probe_wgrad(B, iters);

@@ -14,11 +14,13 @@ L.DATAPATH = L.shipped_datapath()
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 AB = "--ab" in sys.argv
 B = int(args[0]) if args else 16
-unet = UNet2DCondition(UNetConfig.named("sd15"), "cuda")
+MODEL = os.environ.get("MODEL", "sd15")              # MODEL=sd21: the SD-2.1 U-Net at 96x96 latents (BASELINE configs[4])
+HW, CTX = (96, 1024) if MODEL == "sd21" else (64, 768)
+unet = UNet2DCondition(UNetConfig.named(MODEL), "cuda")
 unet.params.init_synthetic(0)
 if L.DATAPATH != "fp32":
     unet.params.pack_bf16(bwd=False)
-x = torch.randn(B, 4, 64, 64, device="cuda"); t = torch.full((B,), 481, dtype=torch.int32, device="cuda"); c = torch.randn(B, 77, 768, device="cuda")
+x = torch.randn(B, 4, HW, HW, device="cuda"); t = torch.full((B,), 481, dtype=torch.int32, device="cuda"); c = torch.randn(B, 77, CTX, device="cuda")
 # monkeypatch gemm_conv / linear_geglu to record shapes (+ whether the activation came as planes)
 orig = L.gemm_conv
 shapes = []
@@ -66,7 +68,9 @@ else:
     tot2 = sum(a[1] for a in pl.values())
     print(f"planes  : total gemm/conv ms {tot2:.2f}; {sum(a[2] for a in pl.values())/tot2/1e9:.1f} TF avg; "
           f"{sum(a[0] for a in pl.values() if a[3])} launches plane-fed")
-    for sh, a in sorted(base.items(), key=lambda kv: -kv[1][1])[:32]:
+    best = sum(min(a[1], pl[sh][1]) if sh in pl else a[1] for sh, a in base.items())
+    print(f"best of both per layer shape: {best:.2f} ms")
+    for sh, a in sorted(base.items(), key=lambda kv: -kv[1][1])[:48]:
         b = pl.get(sh)
         if b is None:
             continue
