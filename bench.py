@@ -348,6 +348,13 @@ def measure_train(args, comm, L, unet, sched, state, emb, neg, steps, warmup):
                                                  "note": "end-to-end: 6 x U-Net-forward algorithmic FLOPs per sample-timestep (2 fwd + 2 bwd) / wall time, per GPU"}}
 
 
+# Measured context for `roofline` (round 6; never used as its `peak`): algorithmic TFLOP/s of a PURE MFMA stream per datapath — no loads, no LDS, random
+# operands, every SIMD issuing back to back (tools/native/mfma_mix_bench, profiles/r06_mfma_mix_bench.log).  Under that load the chip settles at
+# 1.58-1.68 GHz, not 2.4: single-pass bf16 sustains 1.60-1.64 PFLOP/s (97 % MFMA issue at the clock it holds), so the three-pass / f16 + MX-fp8
+# operators top out at a third / about half of that however their operands are fed.
+SUSTAINED_MFMA_ONLY_TFLOPS = {"bf16": 1615.0, "bf16x3": 539.0, "f16mx": 849.0}
+SUSTAINED_MFMA_ONLY_NOTE = ("tools/native/mfma_mix_bench on MI355X, profiles/r06_mfma_mix_bench.log: pure MFMA streams (no memory traffic, random operands) hold "
+                            "1.58-1.68 GHz; bf16 x1 1595-1636, f16 + MX-fp8 845-853, bf16x3 538-541 algorithmic TFLOP/s")
 HBM_PEAK_GBPS = 8000.0                                 # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (about 6.3 TB/s achievable)
 
 
@@ -374,6 +381,29 @@ def measure_hbm_kernels(args, comm, L, ucfg, sched, state, unet):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) * 1e-3 / reps
 
+    def timed_graph(fn, reps):
+        """`reps` launches captured into ONE HIP graph and replayed: what a launch costs on the DEVICE.  The microsecond kernels (DDIM step,
+        PPO forward + backward) are launched from captured graphs / behind a 36 ms U-Net replay in the product; `timed` on them measures the
+        Python + ctypes + launch rate of the host (9.5 us per call whatever the kernel does: a two-sample launch took as long as 64)."""
+        fn(); torch.cuda.synchronize()
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            fn()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            for _ in range(reps):
+                fn()
+        graph.replay(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            graph.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / (3 * reps)
+
     def row(name, unit_bytes, units, dt, note):
         gbps = unit_bytes * units / dt / 1e9
         out[name] = {"bound": "hbm", "algorithmic_bytes_per_unit": unit_bytes, "units_per_launch": units, "avg_launch_us": dt * 1e6,
@@ -385,17 +415,18 @@ def measure_hbm_kernels(args, comm, L, ucfg, sched, state, unet):
     eu, ec, x, z = mk(B), mk(B), mk(B), mk(B)
     ts = torch.full((B,), 481, dtype=torch.int32, device=dev)
     xn, lp = torch.empty_like(x), torch.empty(B, device=dev)
-    dt = timed(lambda: L.ddim_step_fwd(eu, ec, x, z, ts, 5.0, consts, x_next=xn, logp=lp), 200)
-    row("ddim_step", 4 * 4 * chw, B, dt, f"{B} samples per launch = {B * 16 * chw / 2**20:.1f} MiB: launch-latency-bound by construction (one workgroup per "
-        f"sample); the kernel also reads the pre-drawn Threefry noise (5 passes of {4 * chw // 1024} KiB in all)")
+    dt = timed_graph(lambda: L.ddim_step_fwd(eu, ec, x, z, ts, 5.0, consts, x_next=xn, logp=lp), 100)
+    row("ddim_step", 4 * 4 * chw, B, dt, f"{B} samples per launch = {B * 16 * chw / 2**20:.1f} MiB: latency-bound by construction (one workgroup per "
+        f"sample); the kernel also reads the pre-drawn Threefry noise (5 passes of {4 * chw // 1024} KiB in all); 100 launches replayed from one HIP graph")
     Bt = args.train_batch_size * max(1, args.train_fuse)
     eu, ec, x, x2 = mk(Bt), mk(Bt), mk(Bt), mk(Bt)
     ts = torch.full((Bt,), 481, dtype=torch.int32, device=dev)
     old_lp, adv = torch.full((Bt,), -1.0, device=dev), torch.randn(Bt, generator=g).to(dev)
     pre = L.ddim_logprob_ppo_fwd_bwd(ec, eu, x, x2, ts, old_lp, adv, 5.0, 1e-4, True, consts, group=args.train_batch_size)      # outputs allocated once, outside the timed calls
-    dt = timed(lambda: L.ddim_logprob_ppo_fwd_bwd(ec, eu, x, x2, ts, old_lp, adv, 5.0, 1e-4, True, consts, group=args.train_batch_size, out=pre), 100)
+    dt = timed_graph(lambda: L.ddim_logprob_ppo_fwd_bwd(ec, eu, x, x2, ts, old_lp, adv, 5.0, 1e-4, True, consts, group=args.train_batch_size, out=pre), 100)
     row("ppo_fwd_bwd_grouped", 10 * 4 * chw, Bt, dt, f"{Bt} sample-timesteps per launch ({max(1, args.train_fuse)} fused micro-batches of {args.train_batch_size}), "
-        "one workgroup per sample-timestep; outputs pre-allocated outside the timed calls")
+        "a cluster of 8 workgroups per sample-timestep (round 6: inputs read once, partial sums exchanged write-through, info row in the same launch); "
+        "outputs pre-allocated; 100 launches replayed from one HIP graph (as train_steps_fused launches it)")
     n = unet.params.flat.numel()
     gbuf = torch.randn(n, generator=torch.Generator(device=dev).manual_seed(1), device=dev) * 1e-3
     sq = torch.zeros(1, dtype=torch.float64, device=dev)
@@ -654,7 +685,11 @@ def main(argv=None):
                     "launches": len(recs), "avg_launch_ms": ms / max(len(recs), 1),
                     "algorithmic_gflop_per_launch": flops / max(len(recs), 1) / 1e9,
                     "mfma_passes_per_algorithmic_flop": passes, "mfma_issue_frac": passes * achieved / peak,
-                    "by_instantiation": {k: {"launches": v[0], "tflops": v[1] / (v[2] * 1e-3) / 1e12 if v[2] else None, "ms": v[2]} for k, v in by_fam.items()}}
+                    "by_instantiation": {k: {"launches": v[0], "tflops": v[1] / (v[2] * 1e-3) / 1e12 if v[2] else None, "ms": v[2],
+                                             "frac_of_sustained_mfma_only": (v[1] / (v[2] * 1e-3) / 1e12 / SUSTAINED_MFMA_ONLY_TFLOPS[k])
+                                             if (v[2] and k in SUSTAINED_MFMA_ONLY_TFLOPS) else None} for k, v in by_fam.items()},
+                    # context, NOT the roofline: what a pure stream of this datapath's MFMAs (no memory traffic, random operands) sustains on this chip
+                    "sustained_mfma_only": {"tflops": SUSTAINED_MFMA_ONLY_TFLOPS, "source": SUSTAINED_MFMA_ONLY_NOTE}}
     ar = time_allreduce(comm, unet.params.flat.numel()) if comm.dist is not None else None
     extra = {}
     if not args.no_train_extra and args.model in ("sd15", "sd21"):

@@ -268,6 +268,151 @@ __global__ void __launch_bounds__(1024) ppo_fwd_bwd_kernel(const float* __restri
   }
 }
 
+// Round 6 (13.5 us for 21 MB, one workgroup per sample-timestep = 32 of the 256 CUs): the SAME arithmetic on a CLUSTER of S
+// workgroups per sample (S * B <= 256: every workgroup resident, one per CU).  Each workgroup keeps its slice of the four inputs in registers
+// (NV float4 per thread and tensor), publishes the partial sum of its slice and waits for its S - 1 siblings (write-through payload, drained, then a
+// per-sample arrival ticket; write-through reads behind it: cdna_hip_programming.md G16 / MI355X_MICROARCH.md handoff-flag — the siblings sit on different XCDs); every sibling then adds the S partials IN SLICE
+// ORDER, so all of them hold the same log-prob bit for bit, and writes its slice of the gradients from the registers: the inputs are read once,
+// not twice.  The per-micro-batch info row is computed by the workgroup that completes the micro-batch (second arrival counter) with the
+// reduction tree of ppo_info_kernel.  Counters live in device globals, are zero between launches (the last reader resets them) and are only
+// ever touched by one launch at a time (the entry points are called from the training thread's stream only: SURVEY 8b).
+// The partial sums change the fp32 summation order of the log-prob relative to the one-workgroup form (~1e-7 relative): both entry points
+// (grouped and not) use the cluster form whenever it applies, so fused and unfused micro-steps keep agreeing bit for bit.
+#define PPO_MAXB 256
+#define PPO_MAXS 8
+__device__ float g_ppo_part[PPO_MAXB * PPO_MAXS];
+__device__ unsigned g_ppo_cnt[PPO_MAXB], g_ppo_done[PPO_MAXB], g_ppo_grp[PPO_MAXB];
+__device__ unsigned g_ppo_timeout;               // != 0: a cluster gave up waiting (never observed; the entry point's debug query)
+
+template <int NV>
+__global__ void __launch_bounds__(256) ppo_cluster_kernel(const float* __restrict__ eps_c, const float* __restrict__ eps_u,
+                                                         const float* __restrict__ x, const float* __restrict__ x_next,
+                                                         const int32_t* __restrict__ ts, const float* __restrict__ old_logp,
+                                                         const float* __restrict__ adv_in, float g, float clip, int train_cfg,
+                                                         ddpo_ddim_consts c, float* __restrict__ d_eps_c, float* __restrict__ d_eps_u,
+                                                         float* __restrict__ per_sample, float* __restrict__ info, int group, int chw, int S) {
+  __shared__ float red[16];
+  __shared__ float s_lp;
+  __shared__ int s_last;
+  const int b = blockIdx.x / S, sl = blockIdx.x - b * S;
+  const DdimCoef k = ddim_coef(c, ts[b]);
+  const int64_t base = (int64_t)b * chw;
+  const int n4 = chw >> 2, chunk4 = (n4 + S - 1) / S;
+  const int lo4 = sl * chunk4, hi4 = min(n4, lo4 + chunk4);
+  const float inv2v = 1.0f / (2.0f * (k.std_c * k.std_c));
+  const float cst = -logf(k.std_c) - LOG_SQRT_2PI;
+  float4 dv[NV];                                   // x' - mu of this thread's elements (all the backward needs)
+  float acc = 0.f;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int i4 = lo4 + threadIdx.x + v * 256;
+    dv[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i4 < hi4) {
+      const int64_t o = base + (int64_t)i4 * 4;
+      const float4 ec = *reinterpret_cast<const float4*>(eps_c + o);
+      float4 eu = ec;
+      if (train_cfg) eu = *reinterpret_cast<const float4*>(eps_u + o);
+      const float4 xv = *reinterpret_cast<const float4*>(x + o);
+      const float4 xn = *reinterpret_cast<const float4*>(x_next + o);
+      const float* pec = &ec.x; const float* peu = &eu.x; const float* px = &xv.x; const float* pn = &xn.x;
+      float* pd = &dv[v].x;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float e = train_cfg ? (peu[j] + g * (pec[j] - peu[j])) : pec[j];
+        const float d = pn[j] - ddim_mean(k, c.pred_type, e, px[j]);
+        acc += -(d * d) * inv2v + cst;
+        pd[j] = d;
+      }
+    }
+  }
+  const float part = block_sum(acc, red);
+  if (threadIdx.x == 0) {
+    s_last = 0;
+    float tot = part;
+    if (S > 1) {
+      // payload and flag are both write-through (sc1) accesses at agent scope, the payload drained before the flag: no release / acquire fence
+      // (an agent-scope release writes back the whole L2 — measured: the fenced form of this kernel took 18 us against 13 for one workgroup per sample)
+      __hip_atomic_store(&g_ppo_part[b * PPO_MAXS + sl], part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_fetch_add(&g_ppo_cnt[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int spin = 0;
+      while (__hip_atomic_load(&g_ppo_cnt[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)S) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spin > (1 << 24)) { g_ppo_timeout = 1u; break; }          // (every sibling is resident: S * B <= 256 workgroups of 256 threads)
+      }
+      tot = 0.f;
+      for (int q = 0; q < S; ++q) tot += __hip_atomic_load(&g_ppo_part[b * PPO_MAXS + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // the last sibling to have read the partials re-arms the sample's counters for the next launch
+      if (__hip_atomic_fetch_add(&g_ppo_done[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(S - 1)) {
+        __hip_atomic_store(&g_ppo_cnt[b], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&g_ppo_done[b], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    s_lp = tot / (float)chw;
+  }
+  __syncthreads();
+  const float lp = s_lp;
+  const float A = fminf(fmaxf(adv_in[b], -10.0f), 10.0f);        // ADV_CLIP_MAX
+  const float ratio = expf(lp - old_logp[b]);
+  const float unclipped = -A * ratio;
+  const float clipped = -A * fminf(fmaxf(ratio, 1.0f - clip), 1.0f + clip);
+  const float dl = (unclipped >= clipped) ? (-A * ratio / (float)group) : 0.0f;
+  if (sl == 0 && threadIdx.x == 0) {
+    __hip_atomic_store(&per_sample[b * 4 + 0], lp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&per_sample[b * 4 + 1], ratio, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&per_sample[b * 4 + 2], fmaxf(unclipped, clipped), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&per_sample[b * 4 + 3], (fabsf(ratio - 1.0f) > clip) ? 1.0f : 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // micro-batch info: the workgroup that completes the micro-batch reduces its per-sample rows (write-through rows, drained, then the ticket)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int mb = b / group;
+    if (__hip_atomic_fetch_add(&g_ppo_grp[mb], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(group - 1)) {
+      __hip_atomic_store(&g_ppo_grp[mb], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = 1;
+    }
+  }
+  float dmu_de;
+  if (c.pred_type == DDPO_PRED_EPSILON) dmu_de = k.dirc - k.sqrt_ap * k.sqrt_bt / k.sqrt_at;
+  else if (c.pred_type == DDPO_PRED_V) dmu_de = k.dirc * k.sqrt_at - k.sqrt_ap * k.sqrt_bt;
+  else dmu_de = k.sqrt_ap;
+  const float coef = dl * dmu_de / ((k.std_c * k.std_c) * (float)chw);
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int i4 = lo4 + threadIdx.x + v * 256;
+    if (i4 < hi4) {
+      const int64_t o = base + (int64_t)i4 * 4;
+      const float* pd = &dv[v].x;
+      float4 dc, du;
+      float* pdc = &dc.x; float* pdu = &du.x;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float de = coef * pd[j];
+        pdc[j] = train_cfg ? g * de : de;
+        pdu[j] = (1.0f - g) * de;
+      }
+      *reinterpret_cast<float4*>(d_eps_c + o) = dc;
+      if (train_cfg) *reinterpret_cast<float4*>(d_eps_u + o) = du;
+    }
+  }
+  __syncthreads();
+  if (s_last && threadIdx.x < 64) {               // (ppo_info_kernel's reduction, lane for lane)
+    const int b0 = (b / group) * group;
+    float kl = 0.f, cf = 0.f, ls = 0.f;
+    for (int q = b0 + (int)threadIdx.x; q < b0 + group; q += 64) {
+      const float lpq = __hip_atomic_load(&per_sample[q * 4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const float d = lpq - old_logp[q];
+      kl += d * d;
+      cf += __hip_atomic_load(&per_sample[q * 4 + 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ls += __hip_atomic_load(&per_sample[q * 4 + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    kl = wave_sum(kl); cf = wave_sum(cf); ls = wave_sum(ls);
+    if (threadIdx.x == 0) {
+      info[(b / group) * 3 + 0] = 0.5f * kl / (float)group;
+      info[(b / group) * 3 + 1] = cf / (float)group;
+      info[(b / group) * 3 + 2] = ls / (float)group;
+    }
+  }
+}
+
 // one block per micro-batch (`group` consecutive rows): info[blockIdx.x] = {approx_kl, clipfrac, loss} of that micro-batch
 __global__ void ppo_info_kernel(const float* __restrict__ per_sample, const float* __restrict__ old_logp,
                                 float* __restrict__ info, int group) {
@@ -295,6 +440,19 @@ extern "C" int ddpo_ddim_logprob_ppo_fwd_bwd_grouped(const float* eps_c, const f
   if (!eps_c || !x || !x_next || !ts || !old_logp || !advantages || !c || !d_eps_c || !per_sample || !info) return DDPO_EINVAL;
   if (train_cfg && (!eps_u || !d_eps_u)) return DDPO_EINVAL;
   if (B <= 0 || group <= 0 || B % group || chw <= 0 || (chw & 3)) return DDPO_EINVAL;
+  // cluster form: S workgroups of 256 threads per sample, all resident (S * B <= 256), each thread holding NV <= 8 float4 per tensor
+  int S = PPO_MAXS;
+  while (S > 1 && S * B > 256) S >>= 1;
+  const int n4 = chw >> 2, per_wg = (n4 + S - 1) / S, nv = (per_wg + 255) / 256;
+  if (B <= PPO_MAXB && nv <= 8) {
+    const dim3 grid(B * S), blk(256);
+#define PPO_LAUNCH(NV) hipLaunchKernelGGL((ppo_cluster_kernel<NV>), grid, blk, 0, as_stream(stream), eps_c, eps_u, x, x_next, ts, old_logp, advantages, \
+                                         guidance_scale, clip_range, train_cfg, *c, d_eps_c, d_eps_u, per_sample, info, group, chw, S)
+    if (nv <= 1) PPO_LAUNCH(1); else if (nv <= 2) PPO_LAUNCH(2); else if (nv <= 4) PPO_LAUNCH(4); else PPO_LAUNCH(8);
+#undef PPO_LAUNCH
+    DDPO_LAUNCH_CHECK();
+    return DDPO_OK;
+  }
   hipLaunchKernelGGL(ppo_fwd_bwd_kernel, dim3(B), dim3(1024), 0, as_stream(stream), eps_c, eps_u, x, x_next, ts, old_logp,
                      advantages, guidance_scale, clip_range, train_cfg, *c, d_eps_c, d_eps_u, per_sample, group, chw);
   DDPO_LAUNCH_CHECK();
