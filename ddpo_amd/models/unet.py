@@ -505,7 +505,16 @@ class UNet2DCondition:
 
         dup = bool(cfg_dup) and tape is None and B % 2 == 0 and cfg.cross_attn_down[0]
         Bh = B // 2 if dup else B
-        twice = (lambda a: torch.cat([a, a])) if dup else (lambda a: a)
+        def twice(a):
+            """[a; a] along the rows (the CFG halves of a tensor computed once), by the engine's own copy kernel: no torch op inside the
+            captured step."""
+            if not dup:
+                return a
+            n, c = a.shape
+            out2 = torch.empty(2 * n, c, dtype=a.dtype, device=a.device)
+            L.copy_cols(a, out2[:n], 0, n, c)
+            L.copy_cols(a, out2[n:], 0, n, c)
+            return out2
         # Skip concatenation without copies (sampling; round 4): every tensor of the down path that is also a skip connection is written by its
         # producer straight into ITS column range of the concat buffer of the up block that consumes it, and so is the up path's running
         # activation (column range 0 .. c0) — the two ddpo_copy_cols launches per up block (1248 per 50-step sampling call, re-reading and
@@ -534,8 +543,9 @@ class UNet2DCondition:
         d0 = skip_dest(B * H * W)
         if d0 is not None:
             t, _, _ = L.conv2d(x, P["conv_in.kernel"], P["conv_in.bias"], Bh, H, W, Cin, boc[0], 3, out=d0[:Bh * H * W], ld_out=int(d0.stride(0)))
-            if dup:
-                d0[Bh * H * W:].copy_(d0[:Bh * H * W])
+            if dup:                              # second CFG half of the skip: a row-strided column range of its consumer's concat buffer
+                n0 = Bh * H * W
+                L.copy_cols(d0[:n0], d0[n0:], 0, n0, boc[0], ld_src=int(d0.stride(0)), ld_dst=int(d0.stride(0)))
             t_full = d0
         else:
             t, _, _ = L.conv2d(x, P["conv_in.kernel"], P["conv_in.bias"], Bh, H, W, Cin, boc[0], 3)
@@ -680,6 +690,7 @@ class UNet2DCondition:
 
     def release_context(self):
         self._ctx_kv_active = False
+        self._graph_ctx_token = None              # (forward_graphed_cfg: the next sampling call copies its own context)
 
     def _heads_of(self, attn_name):
         """Number of heads of the attention layer `attn_name` (…down_blocks_i / up_blocks_i / mid_block…): cfg.num_heads per level."""
@@ -775,6 +786,31 @@ class UNet2DCondition:
         s_in.copy_(sample)
         t_in.copy_(timesteps)
         c_in.copy_(context)
+        graph.replay()
+        return out
+
+    def forward_graphed_cfg(self, x, step, timesteps, context, cfg_dup=True):
+        """One classifier-free-guidance sampling step from the captured graph: forward_graphed([x; x], ...) with the graph's inputs staged by ONE
+        launch of the engine (ddpo_stage_cfg_inputs: both halves of the latents, the step's row of the time-projection table when `step` is not
+        None, the timesteps) instead of six stock copy launches per step.  The text context is copied into the graph's
+        buffer once per sampling call (precompute_context resets the token).  The first call per geometry captures through forward_graphed."""
+        B = x.shape[0]
+        key = ((2 * B,) + tuple(x.shape[1:]), tuple(context.shape), L.current_datapath(), self._ctx_kv_active, bool(cfg_dup), self._temb_active)
+        ent = getattr(self, "_graphs", {}).get(key)
+        if ent is None or ent == "eager":
+            if step is not None:
+                self.select_timestep(step)
+            self._graph_ctx_token = None
+            return self.forward_graphed(torch.cat([x, x]), timesteps, context, cfg_dup=cfg_dup)
+        graph, s_in, t_in, c_in, out = ent
+        tm = self._temb if step is not None else None
+        L.stage_cfg_inputs(x if x.is_contiguous() else x.contiguous(), s_in,
+                           None if tm is None else tm["table"][step], None if tm is None else tm["row"],
+                           timesteps.to(torch.int32).contiguous(), t_in)
+        token = (id(context), context._version, key)
+        if getattr(self, "_graph_ctx_token", None) != token:
+            c_in.copy_(context)
+            self._graph_ctx_token = token
         graph.replay()
         return out
 

@@ -382,6 +382,12 @@ int ddpo_timestep_embedding(const int32_t* ts, float* out, int B, int dim, void*
 int ddpo_nchw_to_nhwc(const float* x, float* y, int B, int C, int HW, void* stream);
 int ddpo_nhwc_to_nchw(const float* x, float* y, int B, int C, int HW, void* stream);
 int ddpo_copy_cols(const float* src, int ld_src, float* dst, int ld_dst, int64_t rows, int cols, void* stream);
+/* ABI v14.  The inputs of one classifier-free-guidance sampling step, staged in ONE launch into the static input buffers of a captured U-Net
+ * graph: s_in[0:n] = s_in[n:2n] = x[0:n] (the reference's jnp.concatenate([latents] * 2), pipeline_flax_stable_diffusion.py:219), and — each
+ * optional, both pointers NULL to skip — row_dst[0:row_n] = row_src[0:row_n] (this step's row of the precomputed time-projection table) and
+ * ts_dst[0:ts_n] = ts_src[0:ts_n].  n % 4 == 0, row_n % 4 == 0, float pointers 16-byte aligned. */
+int ddpo_stage_cfg_inputs(const float* x, float* s_in, int64_t n, const float* row_src, float* row_dst, int row_n,
+                          const int32_t* ts_src, int32_t* ts_dst, int ts_n, void* stream);
 int ddpo_softmax_rows(float* x, int64_t rows, int cols, float scale, void* stream);    /* in place */
 /* backward element-wise pieces */
 int ddpo_geglu_bwd(const float* x, const float* dy, float* dx, int64_t rows, int F, void* stream);
