@@ -268,21 +268,24 @@ __global__ void __launch_bounds__(1024) ppo_fwd_bwd_kernel(const float* __restri
   }
 }
 
-// Round 6 (13.5 us for 21 MB, one workgroup per sample-timestep = 32 of the 256 CUs): the SAME arithmetic on a CLUSTER of S
-// workgroups per sample (S * B <= 256: every workgroup resident, one per CU).  Each workgroup keeps its slice of the four inputs in registers
-// (NV float4 per thread and tensor), publishes the partial sum of its slice and waits for its S - 1 siblings (write-through payload, drained, then a
-// per-sample arrival ticket; write-through reads behind it: cdna_hip_programming.md G16 / MI355X_MICROARCH.md handoff-flag — the siblings sit on different XCDs); every sibling then adds the S partials IN SLICE
-// ORDER, so all of them hold the same log-prob bit for bit, and writes its slice of the gradients from the registers: the inputs are read once,
-// not twice.  The per-micro-batch info row is computed by the workgroup that completes the micro-batch (second arrival counter) with the
-// reduction tree of ppo_info_kernel.  Counters live in device globals, are zero between launches (the last reader resets them) and are only
-// ever touched by one launch at a time (the entry points are called from the training thread's stream only: SURVEY 8b).
-// The partial sums change the fp32 summation order of the log-prob relative to the one-workgroup form (~1e-7 relative): both entry points
-// (grouped and not) use the cluster form whenever it applies, so fused and unfused micro-steps keep agreeing bit for bit.
-#define PPO_MAXB 256
-#define PPO_MAXS 8
-__device__ float g_ppo_part[PPO_MAXB * PPO_MAXS];
+// Round 6 (13.5 us for 21 MB, one workgroup per sample-timestep = 32 of the 256 CUs): the SAME arithmetic IN THE SAME ORDER on a
+// CLUSTER of four workgroups of 256 threads per sample (4 B <= 256: every workgroup resident).  Thread t of workgroup s is thread 256 s + t of the
+// 1024-thread form: it accumulates the same elements (float4 number T + 1024 k) in the same order, its wave is wave 4 s + (t >> 6) of that form and
+// reduces with the same butterfly; the 16 wave sums of a sample are exchanged (write-through payload, drained, then a ticket on the sample's arrival
+// counter; write-through reads behind it: cdna_hip_programming.md G16 / MI355X_MICROARCH.md handoff-flag — the siblings sit on different XCDs) and
+// EVERY sibling folds them with block_sum's second stage (lanes 0..15 hold the wave sums, one more butterfly).  The log-prob is therefore bit-equal
+// to ppo_fwd_bwd_kernel's and to ddim_step_kernel's — the ratio of a sampled transition scored before the first update stays exactly 1
+// (tests/test_gpu_f16mx_model.py::test_sampler_ratio_is_one_before_the_first_update_tiny; the first cluster form of this round summed per-slice
+// partials and broke exactly that).  x' - mu stays in registers between the two phases: the inputs are read once, not twice.  The per-micro-batch
+// info row is computed by the workgroup that completes the micro-batch (second arrival counter) with ppo_info_kernel's tree.  No release / acquire
+// fence (an agent-scope release writes back the whole L2: the fenced form took 18 us against 13 for one workgroup per sample).  Counters live in
+// device globals, are zero between launches (the last reader re-arms them) and are only ever touched by one launch at a time (the entry points are
+// called from the training thread's stream only: SURVEY 8b).
+#define PPO_MAXB 64
+#define PPO_S 4
+__device__ float g_ppo_part[PPO_MAXB * 16];
 __device__ unsigned g_ppo_cnt[PPO_MAXB], g_ppo_done[PPO_MAXB], g_ppo_grp[PPO_MAXB];
-__device__ unsigned g_ppo_timeout;               // != 0: a cluster gave up waiting (never observed; the entry point's debug query)
+__device__ unsigned g_ppo_timeout;               // != 0: a cluster gave up waiting (never observed)
 
 template <int NV>
 __global__ void __launch_bounds__(256) ppo_cluster_kernel(const float* __restrict__ eps_c, const float* __restrict__ eps_u,
@@ -290,24 +293,24 @@ __global__ void __launch_bounds__(256) ppo_cluster_kernel(const float* __restric
                                                          const int32_t* __restrict__ ts, const float* __restrict__ old_logp,
                                                          const float* __restrict__ adv_in, float g, float clip, int train_cfg,
                                                          ddpo_ddim_consts c, float* __restrict__ d_eps_c, float* __restrict__ d_eps_u,
-                                                         float* __restrict__ per_sample, float* __restrict__ info, int group, int chw, int S) {
-  __shared__ float red[16];
+                                                         float* __restrict__ per_sample, float* __restrict__ info, int group, int chw) {
   __shared__ float s_lp;
   __shared__ int s_last;
-  const int b = blockIdx.x / S, sl = blockIdx.x - b * S;
+  const int b = blockIdx.x / PPO_S, sl = blockIdx.x - b * PPO_S;
+  const int T = sl * 256 + (int)threadIdx.x;       // this thread's index in the 1024-thread form
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const DdimCoef k = ddim_coef(c, ts[b]);
   const int64_t base = (int64_t)b * chw;
-  const int n4 = chw >> 2, chunk4 = (n4 + S - 1) / S;
-  const int lo4 = sl * chunk4, hi4 = min(n4, lo4 + chunk4);
+  const int n4 = chw >> 2;
   const float inv2v = 1.0f / (2.0f * (k.std_c * k.std_c));
   const float cst = -logf(k.std_c) - LOG_SQRT_2PI;
   float4 dv[NV];                                   // x' - mu of this thread's elements (all the backward needs)
   float acc = 0.f;
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
-    const int i4 = lo4 + threadIdx.x + v * 256;
+    const int i4 = T + v * 1024;
     dv[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (i4 < hi4) {
+    if (i4 < n4) {
       const int64_t o = base + (int64_t)i4 * 4;
       const float4 ec = *reinterpret_cast<const float4*>(eps_c + o);
       float4 eu = ec;
@@ -325,30 +328,32 @@ __global__ void __launch_bounds__(256) ppo_cluster_kernel(const float* __restric
       }
     }
   }
-  const float part = block_sum(acc, red);
-  if (threadIdx.x == 0) {
-    s_last = 0;
-    float tot = part;
-    if (S > 1) {
-      // payload and flag are both write-through (sc1) accesses at agent scope, the payload drained before the flag: no release / acquire fence
-      // (an agent-scope release writes back the whole L2 — measured: the fenced form of this kernel took 18 us against 13 for one workgroup per sample)
-      __hip_atomic_store(&g_ppo_part[b * PPO_MAXS + sl], part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const float wsum = wave_sum(acc);                // == red[4 sl + wv] of the 1024-thread form
+  if (lane == 0) __hip_atomic_store(&g_ppo_part[b * 16 + sl * 4 + wv], wsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (threadIdx.x == 0) s_last = 0;
+  __syncthreads();                                 // the four wave sums of this workgroup are drained
+  if (wv == 0) {
+    if (lane == 0) {
       __hip_atomic_fetch_add(&g_ppo_cnt[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       int spin = 0;
-      while (__hip_atomic_load(&g_ppo_cnt[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)S) {
+      while (__hip_atomic_load(&g_ppo_cnt[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)PPO_S) {
         __builtin_amdgcn_s_sleep(1);
-        if (++spin > (1 << 24)) { g_ppo_timeout = 1u; break; }          // (every sibling is resident: S * B <= 256 workgroups of 256 threads)
+        if (++spin > (1 << 24)) { g_ppo_timeout = 1u; break; }          // (every sibling is resident: 4 B <= 256 workgroups of 256 threads)
       }
-      tot = 0.f;
-      for (int q = 0; q < S; ++q) tot += __hip_atomic_load(&g_ppo_part[b * PPO_MAXS + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      // the last sibling to have read the partials re-arms the sample's counters for the next launch
-      if (__hip_atomic_fetch_add(&g_ppo_done[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(S - 1)) {
+    }
+    // (lane 0 leaves its loop before the wave goes on: the loads below are behind the ticket)
+    asm volatile("" ::: "memory");
+    float t = (lane < 16) ? __hip_atomic_load(&g_ppo_part[b * 16 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+    t = wave_sum(t);                               // block_sum's second stage
+    if (lane == 0) {
+      s_lp = t / (float)chw;
+      // the last sibling to have read the wave sums re-arms the sample's counters for the next launch
+      if (__hip_atomic_fetch_add(&g_ppo_done[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(PPO_S - 1)) {
         __hip_atomic_store(&g_ppo_cnt[b], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&g_ppo_done[b], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
-    s_lp = tot / (float)chw;
   }
   __syncthreads();
   const float lp = s_lp;
@@ -377,8 +382,8 @@ __global__ void __launch_bounds__(256) ppo_cluster_kernel(const float* __restric
   const float coef = dl * dmu_de / ((k.std_c * k.std_c) * (float)chw);
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
-    const int i4 = lo4 + threadIdx.x + v * 256;
-    if (i4 < hi4) {
+    const int i4 = T + v * 1024;
+    if (i4 < n4) {
       const int64_t o = base + (int64_t)i4 * 4;
       const float* pd = &dv[v].x;
       float4 dc, du;
@@ -440,15 +445,14 @@ extern "C" int ddpo_ddim_logprob_ppo_fwd_bwd_grouped(const float* eps_c, const f
   if (!eps_c || !x || !x_next || !ts || !old_logp || !advantages || !c || !d_eps_c || !per_sample || !info) return DDPO_EINVAL;
   if (train_cfg && (!eps_u || !d_eps_u)) return DDPO_EINVAL;
   if (B <= 0 || group <= 0 || B % group || chw <= 0 || (chw & 3)) return DDPO_EINVAL;
-  // cluster form: S workgroups of 256 threads per sample, all resident (S * B <= 256), each thread holding NV <= 8 float4 per tensor
-  int S = PPO_MAXS;
-  while (S > 1 && S * B > 256) S >>= 1;
-  const int n4 = chw >> 2, per_wg = (n4 + S - 1) / S, nv = (per_wg + 255) / 256;
-  if (B <= PPO_MAXB && nv <= 8) {
-    const dim3 grid(B * S), blk(256);
+  // cluster form: four workgroups of 256 threads per sample, all resident (4 B <= 256), each thread holding NV <= 16 float4 of x' - mu
+  const int nv = ((chw >> 2) + 1023) / 1024;
+  if (B <= PPO_MAXB && nv <= 16) {
+    const dim3 grid(B * PPO_S), blk(256);
 #define PPO_LAUNCH(NV) hipLaunchKernelGGL((ppo_cluster_kernel<NV>), grid, blk, 0, as_stream(stream), eps_c, eps_u, x, x_next, ts, old_logp, advantages, \
-                                         guidance_scale, clip_range, train_cfg, *c, d_eps_c, d_eps_u, per_sample, info, group, chw, S)
-    if (nv <= 1) PPO_LAUNCH(1); else if (nv <= 2) PPO_LAUNCH(2); else if (nv <= 4) PPO_LAUNCH(4); else PPO_LAUNCH(8);
+                                         guidance_scale, clip_range, train_cfg, *c, d_eps_c, d_eps_u, per_sample, info, group, chw)
+    if (nv <= 1) PPO_LAUNCH(1); else if (nv <= 2) PPO_LAUNCH(2); else if (nv <= 4) PPO_LAUNCH(4); else if (nv <= 8) PPO_LAUNCH(8); else if (nv <= 12) PPO_LAUNCH(12);
+    else PPO_LAUNCH(16);
 #undef PPO_LAUNCH
     DDPO_LAUNCH_CHECK();
     return DDPO_OK;
