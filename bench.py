@@ -721,6 +721,25 @@ def main(argv=None):
                           "note": f"the same workload with --datapath {alt} (U-Net forward error against float64: f16mx 4.2e-5, bf16x3 2.0e-5)"}
         except Exception as exc:
             extra[alt] = {"error": f"{type(exc).__name__}: {exc}"}
+    if world == 1 and args.datapath == "f16mx" and L.MX_CROSS and not args.no_alt_extra and not args.no_train_extra and args.model == "sd15":
+        # opt-in, NOT the headline and not what ships: the f16mx layers without their cross terms (one f16 pass per product: the reference's own
+        # arithmetic class — its TPUs run one bf16 pass — at 11 significant bits).  What the cross terms' matrix work and bytes cost on this
+        # power-bound chip; its parity margins (outside the 1e-3 contract on the gradients) are in profiles/r06_parity_f16x1.log.
+        try:
+            cmd = [sys.executable, os.path.abspath(__file__), "--datapath", "f16mx", "--steps", str(args.steps), "--warmup", str(args.warmup),
+                   "--no-cpu-baseline", "--no-train-extra", "--no-roofline", "--sample-batch-size", str(args.sample_batch_size)]
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+            env["DDPO_MX_CROSS"] = "0"
+            pr = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+            dj = json.loads([l for l in pr.stdout.splitlines() if l.startswith('{"metric"')][-1])
+            extra["f16x1"] = {"value": dj["value"], "unit": dj["unit"], "ms_per_step": dj["ms_per_step"],
+                              "dtype": "f32 storage; K >= 2560 layers: ONE f16 MFMA pass per product (no cross terms); elsewhere as the headline",
+                              "note": "DDPO_MX_CROSS=0: opt-in, NOT shipped, not the headline — it is OUTSIDE the north-star contract: U-Net forward 7.3e-4 rms against "
+                                      "float64 (shipped operator 4e-5), latents 7e-4 along the trajectory (6.6e-5), and at full size the train step's block "
+                                      "gradient norms 2.4e-3 and gradient vector 2.7e-2 against the 1e-3 / 2e-3 gates the shipped operator holds at 1.5e-4 / "
+                                      "1.2e-3 (profiles/r06_parity_f16x1.log).  Reported to price the cross terms: what they cost in throughput on this power-bound chip"}
+        except Exception as exc:
+            extra["f16x1"] = {"error": f"{type(exc).__name__}: {exc}"}
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args)
@@ -737,7 +756,9 @@ def sample_line(args, comm, value, dt, roofline, ar, extra, cpu):
         "metric": f"sampled images/sec ({args.resolution}^2, {args.n_inference_steps} DDIM steps)", "value": value, "unit": "images/sec", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": None if dt is None else dt / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": {"fp32": "f32", "bf16x3": "f32 (bf16x3-split MFMA)", "bf16": "bf16 products, f32 accumulate",
-                                                                 "f16mx": "f32 (f16mx: f16 MFMA + MX-fp8 cross terms on the long-reduction conv/GEMM layers, bf16x3-split MFMA elsewhere)"}[args.datapath],
+                                                                 "f16mx": "f32 (f16mx: f16 MFMA + MX-fp8 cross terms on the long-reduction conv/GEMM layers, bf16x3-split MFMA elsewhere)"
+                                                                          if os.environ.get("DDPO_MX_CROSS", "1") == "1" else
+                                                                          "f32 (DDPO_MX_CROSS=0, opt-in: ONE f16 MFMA pass on the long-reduction conv/GEMM layers, bf16x3-split MFMA elsewhere)"}[args.datapath],
         "data": "synthetic",
         "config": {"workload": f"BASELINE configs[{1 if args.model == 'sd15' else 4}]: {'compressed-animals' if args.model == 'sd15' else 'neg_jpeg'} geometry, "
                                f"{args.model} U-Net+VAE (random init), "

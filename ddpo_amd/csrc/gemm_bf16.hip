@@ -530,7 +530,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 64 ? 3 : 1)) g
   static_assert(BM % AR == 0 && WTM % 32 == 0 && WTN % 32 == 0, "tile / wave-grid mismatch");
   constexpr bool MX = NPASS == 4;                       // f16mx datapath (plane-fed only): f16 plane + 8-bit plane per operand
   static_assert(!MX || APL == 3 || APL == 7, "the f16mx datapath exists on the plane-fed 128-row tiles (APL 3) and on the tall tile (APL 7)");
-  constexpr int NPL = (NPASS >= 3) ? 2 : 1;
+  constexpr int NPL = (NPASS == 3 || NPASS == 4) ? 2 : 1;          // NPASS = 5: single-pass f16 (plane-fed only; the f16mx planes' 16-bit plane alone)
   constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int STAGE = NPL * (A_BYTES + B_BYTES);
@@ -638,14 +638,15 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 64 ? 3 : 1)) g
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
         }
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+        if constexpr (NPASS == 5) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f.ah[i]), __builtin_bit_cast(f16x8, f.bh[j]), acc[i][j], 0, 0, 0);
+        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
       }
     }
   };
 
   if constexpr (APL != 0) {
     // ---------------- LDS-DMA path: A planes + W planes straight into the swizzled LDS image ----------------
-    static_assert(NPASS == 1 || NPASS == 3 || NPASS == 4, "the plane-fed path: bf16x3 / f16mx (two planes per operand) or single-pass bf16 (one)");
+    static_assert(NPASS == 1 || NPASS == 3 || NPASS == 4 || NPASS == 5, "the plane-fed path: bf16x3 / f16mx (two planes per operand) or single-pass bf16 / f16 (one)");
     // two planes per operand: even waves move hi planes, odd waves lo planes (PAIRS loader groups per plane); ONE plane (NPASS = 1, round 6):
     // every wave is a loader group of the only plane.  NB is rounded up: with 8 waves the 20 weight pieces of a 320-column tile are 3 per wave,
     // the four surplus ones carry an out-of-range offset (they arrive as zeros, no memory traffic) and land in rows 320 .. 383 of a weight
@@ -975,7 +976,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 64 ? 3 : 1)) g
       // (every wave's fragment reads of it returned: lgkmcnt(0)), so tile kt + S - 1 is requested into it.  Stage offsets are runtime values
       // (one v_add per fragment base: the 160 KB image exceeds the 64 KB reach of the ds_read offset field).  Per accumulator the order is
       // k half 0, k half 1 of consecutive k-tiles — the fp32-fed single-pass kernel's — so the two agree bit for bit.
-      static_assert(NPASS == 1 && BM == 256 && BN == 320 && WM == 4 && WN == 2, "the single-pass tall tile");
+      static_assert((NPASS == 1 || NPASS == 5) && BM == 256 && BN == 320 && WM == 4 && WN == 2, "the single-pass tall tile");
       constexpr int S = 4, ST = A_BYTES + B_LDS, P = NA + NB;
       static_assert(S * ST <= 160 * 1024 && P * (S - 2) < 64, "stage ring must fit the LDS and the vmcnt field");
       const uint32_t lds_a8 = lds0 + pr * 1024, lds_w8 = lds0 + A_BYTES + pr * 1024;
@@ -1023,10 +1024,17 @@ __global__ void __launch_bounds__(64 * WM * WN, (BM * BN <= 128 * 64 ? 3 : 1)) g
           const bf16x8 bh0 = *reinterpret_cast<const bf16x8*>(sb + b_ld0 + j * 2048);
           const bf16x8 bh1 = *reinterpret_cast<const bf16x8*>(sb + b_ld1 + j * 2048);
           if (DBG_ABL(2)) { asm volatile("" :: "v"(ah0[0]), "v"(ah1[TM - 1]), "v"(bh0), "v"(bh1)); continue; }
+          if constexpr (NPASS == 5) {      // single-pass f16 (opt-in: the f16mx operator without its cross terms)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah0[i]), __builtin_bit_cast(f16x8, bh0), acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah1[i]), __builtin_bit_cast(f16x8, bh1), acc[i][j], 0, 0, 0);
+          } else {
 #pragma unroll
           for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0[i], bh0, acc[i][j], 0, 0, 0);
 #pragma unroll
           for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1[i], bh1, acc[i][j], 0, 0, 0);
+          }
           if (j == 1 && kt + S - 1 < nk && late && !DBG_ABL(1)) fill8(st_f);      // the upper half of the waves requests two column blocks later
         }
         st_c = st_c + ST == S * ST ? 0 : st_c + ST;
@@ -1488,7 +1496,7 @@ static int launch_bf16(const ddpo_gemm_desc& d, const uint16_t* w_hi, const uint
   ktps = (ktps + 1) & ~1;                                  // the pipelined loop consumes k-tiles in pairs
   splits = (nk_total + ktps - 1) / ktps;
   float* part = splits > 1 ? ws : nullptr;
-  constexpr int NPL = (NPASS >= 3) ? 2 : 1;
+  constexpr int NPL = (NPASS == 3 || NPASS == 4) ? 2 : 1;
   size_t lds = (APL == 3) ? NPL * (size_t)(2 * BM + 3 * BN) * 64 : 2 * NPL * (size_t)(BM + BN) * 64;     // APL 3: three weight stages
   if (lds < (size_t)BM * BN * 4) lds = (size_t)BM * BN * 4;     // the epilogue transposes the C tile through LDS
   static bool attr_set = false;
@@ -1645,6 +1653,7 @@ static int dispatch_bf16(const ddpo_gemm_desc& d, const uint16_t* w_hi, const ui
     if constexpr (APL == 3) {
       if (npass == 4) return launch_bf16<128, 128, 4, 2, 2, 3>(d, w_hi, w_lo, ldw, nullptr, 0, st);
       if (npass == 1) return launch_bf16<128, 128, 1, 2, 2, 3>(d, w_hi, w_lo, ldw, nullptr, 0, st);
+      if (npass == 5) return launch_bf16<128, 128, 5, 2, 2, 3>(d, w_hi, w_lo, ldw, nullptr, 0, st);
     }
     return npass == 3 ? launch_bf16<128, 128, 3, 2, 2, APL>(d, w_hi, w_lo, ldw, nullptr, 0, st) : launch_bf16<128, 128, 1>(d, w_hi, w_lo, ldw, nullptr, 0, st);
   }
@@ -1672,6 +1681,8 @@ static int dispatch_bf16(const ddpo_gemm_desc& d, const uint16_t* w_hi, const ui
       // single-pass bf16, plane-fed (round 6): the tall tile with the four-stage ring (APL = 8) under the same rule
       if (npass == 1 && d.N % 320 == 0 && d.epilogue == 0 && ntall >= 200 && eff_tall * 1.08 >= eff_wide)
         return launch_bf16_tall<8, 1>(d, w_hi, w_lo, ldw, st);
+      if (npass == 5 && d.N % 320 == 0 && d.epilogue == 0 && ntall >= 200 && eff_tall * 1.08 >= eff_wide)
+        return launch_bf16_tall<8, 5>(d, w_hi, w_lo, ldw, st);
       // f16mx layers on the tall tile (APL = 7) under the bf16x3 tall tile's rule: grids that fill whole rounds of the chip unsplit — the 64x64
       // level at batch 16 and the up-sampled 32x32 -> 64x64 convolution.  Measured round 5 (profiles/r05_probe_mx_tall.log, r05_ab_mx_tall.log):
       // conv 320->320 @64^2 0.259 -> 0.236 ms, 960->320 0.930 -> 0.709 ms, up-conv 640->640 1.084 -> 0.878 ms, bit-identical; sampling +1.4 %.
@@ -1690,6 +1701,7 @@ static int dispatch_bf16(const ddpo_gemm_desc& d, const uint16_t* w_hi, const ui
     if constexpr (APL == 3) {
       if (npass == 4) return launch_bf16_wide<4, 3>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st);
       if (npass == 1) return launch_bf16_wide<1, 3>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st);
+      if (npass == 5) return launch_bf16_wide<5, 3>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st);
     }
     return npass == 3 ? launch_bf16_wide<3, APL>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st) : launch_bf16_wide<1>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st);
   }
@@ -1706,6 +1718,8 @@ static int dispatch_bf16(const ddpo_gemm_desc& d, const uint16_t* w_hi, const ui
       return big ? launch_bf16<128, 128, 4, 2, 2, 3>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st) : launch_bf16<128, 64, 4, 2, 2, 3>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st);
     if (npass == 1)
       return big ? launch_bf16<128, 128, 1, 2, 2, 3>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st) : launch_bf16<128, 64, 1, 2, 2, 3>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st);
+    if (npass == 5)
+      return big ? launch_bf16<128, 128, 5, 2, 2, 3>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st) : launch_bf16<128, 64, 5, 2, 2, 3>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st);
   }
   if (npass == 3)
     return big ? launch_bf16<128, 128, 3, 2, 2, APL>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st) : launch_bf16<128, 64, 3, 2, 2, APL>(d, w_hi, w_lo, ldw, wsf, ws_bytes, st);
@@ -1774,8 +1788,10 @@ extern "C" int ddpo_gemm_conv_fwd_bf16_planes(const ddpo_gemm_desc* dp, const ui
 /* f16mx plane-fed variant (include/ddpo_hip.h): same kernel family, NPASS = 4 */
 extern "C" int ddpo_gemm_conv_fwd_f16mx_planes(const ddpo_gemm_desc* dp, const uint16_t* a16, const uint16_t* a8, int lda,
                                                const uint16_t* w16, const uint16_t* w8, void* ws, size_t ws_bytes, void* stream) {
-  if (!dp || !a16 || !a8 || !w16 || !w8 || !dp->w_scale) return DDPO_EINVAL;
+  if (!dp || !a16 || !w16 || (a8 == nullptr) != (w8 == nullptr) || (a8 && !dp->w_scale)) return DDPO_EINVAL;
+  const int npass = a8 ? 4 : 5;            // ABI v14: BOTH 8-bit planes NULL = single-pass f16 (a_h * w_h only: the operator without its cross terms; opt-in)
   ddpo_gemm_desc d = *dp;
+  if (npass == 5 && d.epilogue == 2) return DDPO_EINVAL;
   if (d.M <= 0 || d.N <= 0 || d.K <= 0 || lda < 0 || (lda & 31) || d.w_dgrad || d.w_layout != 1 || !planes_out_ok(d)) return DDPO_EINVAL;
   if ((reinterpret_cast<uintptr_t>(a16) | reinterpret_cast<uintptr_t>(a8) | reinterpret_cast<uintptr_t>(w16) | reinterpret_cast<uintptr_t>(w8)) & 15)
     return DDPO_EINVAL;
@@ -1793,7 +1809,7 @@ extern "C" int ddpo_gemm_conv_fwd_f16mx_planes(const ddpo_gemm_desc* dp, const u
 #ifdef DDPO_KLOOP_TIMING
   { const char* e = getenv("DDPO_DBG_ABL"); if (e) d.splits |= atoi(e) << 4; }
 #endif
-  return dispatch_bf16<3>(d, w16, w8, 0, 4, ws, ws_bytes, as_stream(stream));
+  return dispatch_bf16<3>(d, w16, w8, 0, npass, ws, ws_bytes, as_stream(stream));
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -255,7 +255,10 @@ int ddpo_gemm_conv_fwd_bf16_planes(const ddpo_gemm_desc* d, const uint16_t* a_hi
  *   w16 / w8 / d->w_scale  weight planes of ddpo_pack_weights_f16mx (k-blocked only: d->w_layout must be 1).
  * Tiles, split-K, output stage (incl. epilogue = 1 and plane emission in either format) as ddpo_gemm_conv_fwd_bf16_planes;
  * every tile class accumulates in the same order (bit-identical results for one layer whatever the batch).  Forward only:
- * data / weight gradients stay on bf16x3. */
+ * data / weight gradients stay on bf16x3. 
+ * ABI v14: a8 == NULL AND w8 == NULL (d->w_scale unused) runs the operator WITHOUT its cross terms — a_h * w_h on the f16 MFMA only, on the
+ * single-plane kernels (four-stage ring on the 256 x 320 tile): one f16 pass per product, 7e-4 instead of 4e-5 on a U-Net forward and outside the 1e-3 gradient contract at full size.  Opt-in
+ * (DDPO_MX_CROSS=0); exactly one of the two NULL is DDPO_EINVAL. */
 int ddpo_gemm_conv_fwd_f16mx_planes(const ddpo_gemm_desc* d, const uint16_t* a16, const uint16_t* a8, int lda,
                                     const uint16_t* w16, const uint16_t* w8, void* ws, size_t ws_bytes, void* stream);
 /* fp32 W (K, N) -> f16mx weight planes, k-blocked: w16 (ceil(K/32), N, 32) f16 = f16(w); w8 (ceil(K/32), N, 64) bytes =

@@ -179,3 +179,40 @@ def test_tall_tile_is_bit_identical_to_the_128_row_tiles(B, H, Cin, Cout, ks, up
         tall[mode] = L.gemm_tile_launch_counts()["tall_256x320"] - before
     assert tall["0"] == 0 and tall["1"] == 1, tall
     assert torch.equal(outs["0"], outs["1"])
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout,ks", [(2, 32, 320, 320, 3), (16, 64, 320, 320, 3), (2, 16, 640, 640, 3), (1, 640, 320, 1280, 0)])
+def test_single_pass_f16_is_the_f16_term_of_the_operator(B, H, Cin, Cout, ks):
+    """ABI v14, opt-in (DDPO_MX_CROSS=0): both 8-bit planes NULL at ddpo_gemm_conv_fwd_f16mx_planes runs a_h * w_h alone on the single-plane kernels
+    (128-row tiles on the three-weight-stage loop, the 256 x 320 tile on the four-stage ring).  Contract: the exact product of the DECODED f16
+    planes up to fp32 accumulation, i.e. the f16mx result minus its two cross terms; ~3e-4 rms against float64 on Gaussian operands."""
+    from ctypes import byref
+    torch.manual_seed(5)
+    conv = ks > 0
+    rows, K = (B * H * H, ks * ks * Cin) if conv else (B * H, Cin)
+    M = rows
+    x = torch.randn(rows, Cin, device="cuda")
+    w = torch.randn(K, Cout, device="cuda") / K ** 0.5
+    (p16, p8), wp = L.split_planes_f16mx(x), L.pack_weights_f16mx(w)
+    ah, _, _ = _dec_planes(p16, p8)
+    wh, _, _ = _dec_weights(wp)
+    if conv:
+        cv = lambda a, b_: TF.conv2d(a.view(B, H, H, Cin).permute(0, 3, 1, 2), b_.view(ks, ks, Cin, Cout).permute(3, 2, 0, 1), None, padding=ks // 2).permute(0, 2, 3, 1).reshape(M, Cout)
+    else:
+        cv = lambda a, b_: a @ b_
+    d = L.GemmDesc()
+    out = torch.empty(M, Cout, device="cuda")
+    d.out = out.data_ptr(); d.ld_out = Cout; d.alpha = 1.0; d.M, d.N, d.K = M, Cout, K; d.w_layout = 1
+    if conv:
+        for k_, v_ in dict(ksize=ks, stride=1, pad=ks // 2, upsample=0, B=B, H=H, W=H, Cin=Cin, OH=H, OW=H).items():
+            setattr(d, k_, v_)
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    f = L.load().ddpo_gemm_conv_fwd_f16mx_planes
+    assert f(byref(d), L._p(p16), None, Cin, L._p(wp["w16"]), L._p(wp["w8"]), L._p(ws), ws.numel(), None) == -1          # exactly one NULL: refused
+    assert f(byref(d), L._p(p16), None, Cin, L._p(wp["w16"]), None, L._p(ws), ws.numel(), None) == 0
+    torch.cuda.synchronize()
+    ref_planes, ref_true = cv(ah, wh), cv(x.double(), w.double())
+    scale = float(ref_true.abs().max())
+    assert float((out.double() - ref_planes).abs().max()) < 3e-6 * scale
+    err = float((out.double() - ref_true).pow(2).mean().sqrt() / ref_true.pow(2).mean().sqrt())
+    assert 5e-5 < err < 6e-4, err
