@@ -167,7 +167,8 @@ def test_train_step_at_the_reference_clip_range(family, ocfg, pred, ctx, datapat
 
 
 @pytest.mark.timeout(2400)
-def test_train_step_sd15_full_size_shipped_datapath():
+@pytest.mark.parametrize("fuse_default", [1, 2])
+def test_train_step_sd15_full_size_shipped_datapath(fuse_default):
     """SD-1.5 train_step at 64x64 latents (512^2 px) at the REFERENCE'S micro-batch — `train.batch_size = 2` per device, train_cfg
     (/root/reference/config/base.py:61-102): 2 forwards + 2 backwards of the 860 M-parameter U-Net over a U-Net batch of 4
     on the shipped kernels (f16mx on the long reductions; 128x320 / 128x128 tiles, split-K, 4096^2 d=40 attention forward + backward,
@@ -176,7 +177,12 @@ def test_train_step_sd15_full_size_shipped_datapath():
     bench.py's train line times — against the oracle's k accumulated steps (k x the host time; run once per round for the record,
     profiles/r05_parity_margins.log)."""
     dtype = torch.float64 if os.environ.get("DDPO_PARITY_F64") == "1" else torch.float32
-    fuse = int(os.environ.get("DDPO_TRAIN_PARITY_FUSE", "1"))
+    # the suite runs the single launch AND two micro-batches through one fused launch (round 6: the driver sees the fused path at full size,
+    # VERDICT r05 weak 1d); DDPO_TRAIN_PARITY_FUSE=k replaces both by k fused micro-batches (tools/r06_parity_long.sh: 16, the bench's shape)
+    env_fuse = os.environ.get("DDPO_TRAIN_PARITY_FUSE")
+    if env_fuse is not None and fuse_default != 1:
+        pytest.skip("DDPO_TRAIN_PARITY_FUSE set: one run with that many fused micro-steps")
+    fuse = int(env_fuse) if env_fuse is not None else fuse_default
     grid = [481, 21, 961, 241, 701, 121, 841, 361, 581, 61, 921, 301, 641, 181, 781, 421]          # timesteps of the 50-step grid (1 + 20 i)
     _check("sd15", OU.SD15, "epsilon", hw=64, b=2, ts=(grid * ((2 * fuse + 15) // 16))[:2 * fuse], ctx_dim=768, T=50, datapath=SHIPPED, dtype=dtype, seed=0, fuse=fuse)
 
